@@ -1,0 +1,110 @@
+"""ctypes binding of the C-ABI HIP library ``libaudiotools_amd.so``.
+
+The library is the product: every hot-path method of :class:`AudioSignal`
+on a HIP tensor goes through one of the ``at_*`` entry points declared in
+``include/audiotools_amd.h``.  There is deliberately NO CPU fallback here:
+if the shared object is missing or an entry point fails, a ``RuntimeError``
+is raised (``NativeError``).
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libaudiotools_amd.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+SOURCES = ["stft.hip", "loudness.hip"]
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NativeError(RuntimeError):
+    """Raised when the HIP library is unavailable or an entry point fails."""
+
+
+def hipcc_command(out=LIB_PATH):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
+    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+            "-o", out] + srcs
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``lib/libaudiotools_amd.so``
+    (hipcc cross-compiles without a GPU)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES] + [os.path.join(CSRC_DIR, "at_common.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+            return LIB_PATH
+    cmd = hipcc_command()
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_i64, _i32, _p, _f32, _f64 = (ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                              ctypes.c_float, ctypes.c_double)
+
+# name -> (restype, argtypes); mirrors include/audiotools_amd.h
+SIGNATURES = {
+    "at_stft_twiddles_host": (_i32, [_i32, _p]),
+    "at_stft_native_supported": (_i32, [_i32]),
+    "at_stft_mel_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
+                               _i32, _i64, _p, _p, _p, _p, _i32, _i32, _p, _p]),
+    "at_lufs_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32]),
+    "at_lufs_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _i32, _i32, _i32, _f64, _f32,
+                           _i32, _p, _p, _i64, _p]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise NativeError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str):
+    if code == 0:
+        return
+    if code == -1:
+        raise NativeError(f"{what}: invalid argument")
+    if code == -2:
+        raise NativeError(f"{what}: unsupported configuration")
+    raise NativeError(f"{what}: HIP error {-(code) - 1000}")
+
+
+def ptr(t):
+    """Raw device/host pointer of a tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,467 @@
+// ITU-R BS.1770 integrated loudness for gfx950.
+//
+// Replaces reference audiotools/core/loudness.py:
+//   :102-126  apply_filter_cpu  (cascade of float32 Direct-Form-I biquads, the CPU/IIR branch)
+//   :164-174  _unfold           (400 ms blocks, 75 % overlap, zero-padded tail)
+//   :176-247  integrated_loudness (block energies, absolute + relative gating)
+//
+// Kernel 1  kweight_hop_energy: one wave64 per (row, segment of hops).
+//   The wave walks its segment in super-blocks of 2048 samples: the 8 KB tile is read
+//   from HBM with 16-byte-per-lane coalesced loads, transposed through a padded LDS slab,
+//   and every lane then owns 32 CONSECUTIVE samples in registers.
+//   Each biquad stage is solved exactly in three steps:
+//     (a) per lane: FIR part + zero-state recursion over its 32 samples;
+//     (b) across lanes: the 2-vector recursion  F_c = z_c + P F_{c-1}  (P = companion^32)
+//         by a 6-step Kogge-Stone scan with the constant matrices P, P^2, P^4.. in f64;
+//     (c) per lane: re-run the recursion from the true entering state.
+//   The state entering a super-block is carried in registers from the previous one, so a
+//   segment is filtered exactly; a segment that does not start at sample 0 starts `warm`
+//   samples early from zero state, `warm` chosen by the host so that the largest pole
+//   radius^warm < 1e-9 (the discarded transient is below float32 resolution).
+//   Energy: per lane sum of y^2, reduced across the wave with xor-shuffles in f64, split at
+//   100 ms hop boundaries; 400 ms block energy = sum of 4 hop energies (K = m*S).
+// Kernel 2  lufs_gate: one wave per item; float64 gating exactly as the reference
+//   (z in f32, l/Gamma in f64).
+#include "at_common.h"
+
+namespace {
+
+constexpr int CHUNK = 32;            // samples per lane
+constexpr int SB = 64 * CHUNK;       // samples per super-block
+constexpr int ROWF = CHUNK + 4;      // padded LDS row (floats): 144 B
+constexpr int MAX_STAGE = 4;
+
+struct Stage {
+  float b0, b1, b2, a1, a2, g;
+};
+
+struct LufsArgs {
+  const float* x;      // (rows, T)
+  double* E;           // (rows, H) hop energies, pre-zeroed
+  float* y;            // optional (rows, T) filtered signal (general block path) or null
+  int64_t T;
+  int64_t rows;
+  int S;               // hop (samples)
+  int H;               // hops per row in E
+  int H_data;          // hops that contain samples: ceil(T/S)
+  int seg_hops;
+  int segs_per_row;
+  int warm;            // warm-up samples for segments that start after sample 0
+  int nstage;
+  int vec4;
+  Stage st[MAX_STAGE];
+  // P^(2^i), i = 0..6, per stage, row-major 2x2 doubles: wave-uniform, read through s_load
+  double Pp[MAX_STAGE][7][4];
+};
+
+struct M2 {  // 2x2 double matrix
+  double a, b, c, d;
+};
+__device__ __forceinline__ M2 mmul(const M2& x, const M2& y) {
+  return {x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d};
+}
+__device__ __forceinline__ double shfl_up_d(double v, int d) { return __shfl_up(v, d, 64); }
+
+// Solve one biquad stage in place on the lane's CHUNK samples.
+// in:  v[] = stage input; (hx1,hx2) = the two input samples preceding the lane's chunk
+// io:  (ky1,ky2) = output state entering the SUPER-BLOCK (wave-uniform); updated to the
+//      state leaving it.
+template <int SI>
+__device__ __forceinline__ void biquad_stage(float (&v)[CHUNK], const LufsArgs& A, float hx1, float hx2, double& ky1,
+                                             double& ky2, const M2& Q, int lane) {
+  const Stage s = A.st[SI];
+  // (a) FIR part in place + zero-state recursion
+  float x1 = hx1, x2 = hx2;
+  float y1 = 0.f, y2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CHUNK; ++i) {
+    const float xn = v[i];
+    float o = s.b2 * x2;
+    o = fmaf(s.b1, x1, o);
+    o = fmaf(s.b0, xn, o);
+    v[i] = o;
+    x2 = x1;
+    x1 = xn;
+    const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, o));
+    y2 = y1;
+    y1 = y;
+  }
+  // (b) scan: G_c = sum_{j<=c} P^(c-j) z_j
+  double g1 = (double)y1, g2 = (double)y2;
+#pragma unroll
+  for (int step = 0; step < 6; ++step) {
+    const int d = 1 << step;
+    const double u1 = shfl_up_d(g1, d), u2 = shfl_up_d(g2, d);
+    if (lane >= d) {
+      g1 += A.Pp[SI][step][0] * u1 + A.Pp[SI][step][1] * u2;
+      g2 += A.Pp[SI][step][2] * u1 + A.Pp[SI][step][3] * u2;
+    }
+  }
+  // F_c = G_c + P^(c+1) K ; entering state of lane c = F_{c-1} (lane 0: K)
+  const double f1 = g1 + Q.a * ky1 + Q.b * ky2;
+  const double f2 = g2 + Q.c * ky1 + Q.d * ky2;
+  double e1 = shfl_up_d(f1, 1), e2 = shfl_up_d(f2, 1);
+  if (lane == 0) { e1 = ky1; e2 = ky2; }
+  ky1 = __shfl(f1, 63, 64);
+  ky2 = __shfl(f2, 63, 64);
+  // (c) true recursion from the entering state
+  y1 = (float)e1;
+  y2 = (float)e2;
+#pragma unroll
+  for (int i = 0; i < CHUNK; ++i) {
+    const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
+    v[i] = s.g * y;
+    y2 = y1;
+    y1 = y;
+  }
+}
+
+template <int NS, bool VEC4, bool WRITE_Y>
+__global__ __launch_bounds__(256) void kweight_hop_energy(const LufsArgs A) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * 64 * ROWF];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t row = wid / A.segs_per_row;
+  if (row >= A.rows) return;
+  const int seg = (int)(wid % A.segs_per_row);
+  float* slab = lds + wave * 64 * ROWF;
+
+  const int h0 = seg * A.seg_hops;
+  const int h1 = min(h0 + A.seg_hops, A.H_data);
+  const int64_t n0 = (int64_t)h0 * A.S;
+  const int64_t n1 = min((int64_t)h1 * A.S, A.T);
+  int64_t start = n0 - A.warm;
+  if (start < 0) start = 0;
+  start &= ~(int64_t)3;
+  const float* __restrict__ xr = A.x + row * A.T;
+
+  // ---- per-lane scan constant Q = P^(lane+1) (f64), from the kernarg powers of P
+  M2 Q[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    M2 acc = {1.0, 0.0, 0.0, 1.0};
+    const int e = lane + 1;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      if (e & (1 << i)) {
+        const M2 p = {A.Pp[s][i][0], A.Pp[s][i][1], A.Pp[s][i][2], A.Pp[s][i][3]};
+        acc = mmul(acc, p);
+      }
+    }
+    Q[s] = acc;
+  }
+
+  double ky1[NS], ky2[NS];  // output state entering the super-block, per stage
+  float kx1[NS], kx2[NS];   // input history entering the super-block, per stage
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { ky1[s] = ky2[s] = 0.0; kx1[s] = kx2[s] = 0.f; }
+
+  int h_cur = -1;
+  double acc = 0.0;
+
+  for (int64_t sb = start; sb < n1; sb += SB) {
+    // ---- stage the 2048-sample tile through LDS (coalesced global reads)
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = i * 64 + lane;
+        const int64_t g = sb + 4 * (int64_t)p;
+        float4 val;
+        if (g + 3 < A.T) {
+          val = *reinterpret_cast<const float4*>(xr + g);
+        } else {
+          val.x = g + 0 < A.T ? xr[g + 0] : 0.f;
+          val.y = g + 1 < A.T ? xr[g + 1] : 0.f;
+          val.z = g + 2 < A.T ? xr[g + 2] : 0.f;
+          val.w = 0.f;
+        }
+        *reinterpret_cast<float4*>(slab + (p >> 3) * ROWF + (p & 7) * 4) = val;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CHUNK; ++i) {
+        const int e = i * 64 + lane;
+        const int64_t g = sb + e;
+        slab[(e >> 5) * ROWF + (e & 31)] = g < A.T ? xr[g] : 0.f;
+      }
+    }
+    at::wave_sync();
+    float v[CHUNK];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 q = *reinterpret_cast<const float4*>(slab + lane * ROWF + 4 * i);
+      v[4 * i + 0] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+    }
+    at::wave_sync();
+
+    // ---- biquad cascade
+#define AT_STAGE(SI)                                                     \
+    if constexpr (SI < NS) {                                             \
+      float hx1 = __shfl_up(v[CHUNK - 1], 1, 64);                        \
+      float hx2 = __shfl_up(v[CHUNK - 2], 1, 64);                        \
+      if (lane == 0) { hx1 = kx1[SI]; hx2 = kx2[SI]; }                   \
+      kx1[SI] = __shfl(v[CHUNK - 1], 63, 64);                            \
+      kx2[SI] = __shfl(v[CHUNK - 2], 63, 64);                            \
+      biquad_stage<SI>(v, A, hx1, hx2, ky1[SI], ky2[SI], Q[SI], lane);   \
+    }
+    AT_STAGE(0) AT_STAGE(1) AT_STAGE(2) AT_STAGE(3)
+#undef AT_STAGE
+
+    const int64_t base = sb + (int64_t)lane * CHUNK;
+    if constexpr (WRITE_Y) {
+      // general-block path: hand the filtered signal to block_energy_kernel
+      float* yr = A.y + row * A.T;
+#pragma unroll
+      for (int i = 0; i < CHUNK; ++i) {
+        const int64_t g = base + i;
+        if (g >= n0 && g < n1) yr[g] = v[i];
+      }
+    } else {
+      // ---- hop energies
+      const int64_t lo = max(sb, n0), hi = min(sb + (int64_t)SB, n1);
+      if (lo < hi) {
+        const int hf = (int)(lo / A.S), hl = (int)((hi - 1) / A.S);
+        for (int h = hf; h <= hl; ++h) {
+          const int64_t a = max(lo, (int64_t)h * A.S), b = min(hi, (int64_t)(h + 1) * A.S);
+          float e = 0.f;
+          if (a == sb && b == sb + SB) {
+#pragma unroll
+            for (int i = 0; i < CHUNK; ++i) e = fmaf(v[i], v[i], e);
+          } else {
+            const int ilo = (int)max((int64_t)0, min((int64_t)CHUNK, a - base));
+            const int ihi = (int)max((int64_t)0, min((int64_t)CHUNK, b - base));
+#pragma unroll
+            for (int i = 0; i < CHUNK; ++i) {
+              const float m = (i >= ilo && i < ihi) ? v[i] : 0.f;
+              e = fmaf(m, m, e);
+            }
+          }
+          const double tot = at::wave_sum((double)e);
+          if (h != h_cur) {
+            if (h_cur >= 0 && lane == 0) A.E[row * A.H + h_cur] = acc;
+            h_cur = h;
+            acc = 0.0;
+          }
+          acc += tot;
+        }
+      }
+    }
+  }
+  if constexpr (!WRITE_Y) {
+    if (h_cur >= 0 && lane == 0) A.E[row * A.H + h_cur] = acc;
+  }
+}
+
+// General block energies from a filtered signal (K not a multiple of S): one wave per (row, block).
+__global__ __launch_bounds__(256) void block_energy_kernel(const float* __restrict__ y, double* __restrict__ Z,
+                                                            int64_t rows, int64_t T, int K, int S, int nblk) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= rows * nblk) return;
+  const int64_t row = wid / nblk;
+  const int j = (int)(wid % nblk);
+  const int64_t lo = (int64_t)j * S, hi = min(lo + (int64_t)K, T);
+  const float* yr = y + row * T;
+  double acc = 0.0;
+  for (int64_t n = lo + lane; n < hi; n += 64) {
+    const float q = yr[n];
+    acc += (double)q * (double)q;
+  }
+  acc = at::wave_sum(acc);
+  if (lane == 0) Z[wid] = acc;
+}
+
+struct GateArgs {
+  const double* E;   // (B*C, H) hop energies   (hops_per_block > 0)  or (B*C, nblk) block energies (== 0)
+  float* out;        // (B)
+  int B, C, H, nblk, hops_per_block;
+  float inv_norm;    // f32(1/(T_g*rate))
+  float floor_db;    // clamp (NaN = none)
+};
+
+__device__ __forceinline__ float block_z(const GateArgs& A, int b, int c, int j) {
+  const double* e = A.E + ((int64_t)b * A.C + c) * A.H;
+  double s;
+  if (A.hops_per_block > 0) {
+    s = 0.0;
+    for (int i = 0; i < A.hops_per_block; ++i) s += e[j + i];
+  } else {
+    s = e[j];
+  }
+  return (float)s * A.inv_norm;  // loudness.py:214, float32
+}
+
+__global__ __launch_bounds__(64) void lufs_gate(const GateArgs A) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double Gc[5] = {1.0, 1.0, 1.0, 1.41, 1.41};  // loudness.py:49
+  const double GAMMA_A = -70.0;
+
+  // pass 1: absolute gate
+  double sum1[5] = {0, 0, 0, 0, 0};
+  double cnt1 = 0.0;
+  for (int j = lane; j < A.nblk; j += 64) {
+    double tot = 0.0;
+    float z[5];
+    for (int c = 0; c < A.C; ++c) { z[c] = block_z(A, b, c, j); tot += Gc[c] * (double)z[c]; }
+    const double l = -0.691 + 10.0 * log10(tot);
+    if (l > GAMMA_A) {
+      cnt1 += 1.0;
+      for (int c = 0; c < A.C; ++c) sum1[c] += (double)z[c];
+    }
+  }
+  cnt1 = at::wave_sum(cnt1);
+  double tot_r = 0.0;
+  for (int c = 0; c < A.C; ++c) {
+    const float zavg = (float)at::wave_sum(sum1[c]) / (float)cnt1;  // 0/0 -> NaN as in the reference
+    tot_r += (double)zavg * Gc[c];
+  }
+  const double gamma_r = -0.691 + 10.0 * log10(tot_r) - 10.0;
+
+  // pass 2: absolute + relative gate
+  double sum2[5] = {0, 0, 0, 0, 0};
+  double cnt2 = 0.0;
+  for (int j = lane; j < A.nblk; j += 64) {
+    double tot = 0.0;
+    float z[5];
+    for (int c = 0; c < A.C; ++c) { z[c] = block_z(A, b, c, j); tot += Gc[c] * (double)z[c]; }
+    const double l = -0.691 + 10.0 * log10(tot);
+    if (l > GAMMA_A && l > gamma_r) {  // NaN gamma_r -> nothing passes, as in the reference
+      cnt2 += 1.0;
+      for (int c = 0; c < A.C; ++c) sum2[c] += (double)z[c];
+    }
+  }
+  cnt2 = at::wave_sum(cnt2);
+  double tot_f = 0.0;
+  for (int c = 0; c < A.C; ++c) {
+    float zavg = (float)at::wave_sum(sum2[c]) / (float)cnt2;
+    if (isnan(zavg)) zavg = 0.f;
+    if (isinf(zavg)) zavg = zavg > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+    tot_f += Gc[c] * (double)zavg;
+  }
+  float lufs = (float)(-0.691 + 10.0 * log10(tot_f));
+  if (!isnan(A.floor_db)) lufs = fmaxf(lufs, A.floor_db);
+  if (lane == 0) A.out[b] = lufs;
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+// Workspace layout: [E: rows*H doubles][y: rows*T floats, only when K % S != 0]
+int64_t at_lufs_workspace_bytes(int64_t B, int64_t C, int64_t T, int K, int S) {
+  if (B < 0 || C <= 0 || T <= 0 || K <= 0 || S <= 0) return AT_ERR_INVALID;
+  const int64_t rows = B * C;
+  const int64_t Tk = T > K ? T : K;
+  const int64_t nblk = (Tk - K + S - 1) / S + 1;
+  if (K % S == 0) {
+    const int64_t H = nblk - 1 + K / S;
+    return align_up(rows * H * 8, 256);
+  }
+  return align_up(rows * nblk * 8, 256) + align_up(rows * T * 4, 256);
+}
+
+// sos: nstage x 6 doubles (b0,b1,b2,a0,a1,a2) as designed; gains: nstage passband gains.
+// Coefficients are rounded to float32 exactly as loudness.py:118-119 does (.float()).
+int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* sos, const double* gains, int nstage,
+                int K, int S, double inv_norm, float floor_db, int warm, float* out, void* workspace,
+                int64_t workspace_bytes, void* stream) {
+  if (!x || !sos || !gains || !out || B < 0 || C <= 0 || C > 5 || T <= 0 || nstage <= 0 || nstage > MAX_STAGE ||
+      K <= 0 || S <= 0 || warm < 0)
+    return AT_ERR_INVALID;
+  if (B == 0) return AT_OK;
+  const int64_t need = at_lufs_workspace_bytes(B, C, T, K, S);
+  if (!workspace || workspace_bytes < need) return AT_ERR_INVALID;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t rows = B * C;
+  const int64_t Tk = T > K ? T : K;
+  const int nblk = (int)((Tk - K + S - 1) / S + 1);
+  const bool hop_path = (K % S == 0);
+
+  LufsArgs A;
+  A.x = x; A.T = T; A.rows = rows; A.S = S; A.nstage = nstage; A.warm = warm;
+  for (int s = 0; s < nstage; ++s) {
+    const float a0 = (float)sos[6 * s + 3];
+    A.st[s].b0 = (float)sos[6 * s + 0] / a0;
+    A.st[s].b1 = (float)sos[6 * s + 1] / a0;
+    A.st[s].b2 = (float)sos[6 * s + 2] / a0;
+    A.st[s].a1 = (float)sos[6 * s + 4] / a0;
+    A.st[s].a2 = (float)sos[6 * s + 5] / a0;
+    A.st[s].g = (float)gains[s];
+    // P = companion^CHUNK of the float32-rounded recursion, then repeated squares
+    const double a1 = (double)A.st[s].a1, a2 = (double)A.st[s].a2;
+    double p1 = 1.0, p2 = 0.0, q1 = 0.0, q2 = 1.0;
+    for (int i = 0; i < CHUNK; ++i) {
+      const double pn = -a1 * p1 - a2 * p2; p2 = p1; p1 = pn;
+      const double qn = -a1 * q1 - a2 * q2; q2 = q1; q1 = qn;
+    }
+    double P[4] = {p1, q1, p2, q2};  // (y[31],y[30]) = P (y[-1],y[-2])
+    for (int i = 0; i < 7; ++i) {
+      for (int e = 0; e < 4; ++e) A.Pp[s][i][e] = P[e];
+      const double n[4] = {P[0] * P[0] + P[1] * P[2], P[0] * P[1] + P[1] * P[3], P[2] * P[0] + P[3] * P[2],
+                           P[2] * P[1] + P[3] * P[3]};
+      for (int e = 0; e < 4; ++e) P[e] = n[e];
+    }
+  }
+  A.vec4 = ((T % 4) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0) ? 1 : 0;
+  double* E = reinterpret_cast<double*>(workspace);
+  int H;
+  if (hop_path) {
+    H = nblk - 1 + K / S;
+    A.y = nullptr;
+  } else {
+    H = nblk;
+    A.y = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up(rows * (int64_t)nblk * 8, 256));
+  }
+  A.E = E; A.H = H;
+  // segmentation in units of S samples ("hops") even on the general path
+  const int64_t H_data = (T + S - 1) / S;
+  A.H_data = (int)H_data;
+  // aim for >= 4096 waves, but keep segments >= 4x the warm-up unless the batch is tiny
+  int64_t seg = (rows * H_data + 4095) / 4096;
+  const int64_t min_seg = (4 * (int64_t)warm + S - 1) / S;
+  if (seg < min_seg && rows * ((H_data + min_seg - 1) / min_seg) >= 1024) seg = min_seg;
+  if (seg < 1) seg = 1;
+  if (seg > H_data) seg = H_data;
+  A.seg_hops = (int)seg;
+  A.segs_per_row = (int)((H_data + seg - 1) / seg);
+
+  hipError_t e = hipMemsetAsync(E, 0, (size_t)rows * H * 8, st);
+  if (e != hipSuccess) return AT_ERR_HIP(e);
+  const int64_t waves = rows * A.segs_per_row;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+#define AT_LAUNCH_NS(NSV)                                                                          \
+  case NSV:                                                                                        \
+    if (hop_path) {                                                                                \
+      if (A.vec4) hipLaunchKernelGGL((kweight_hop_energy<NSV, true, false>), grid, block, 0, st, A);  \
+      else hipLaunchKernelGGL((kweight_hop_energy<NSV, false, false>), grid, block, 0, st, A);        \
+    } else {                                                                                       \
+      if (A.vec4) hipLaunchKernelGGL((kweight_hop_energy<NSV, true, true>), grid, block, 0, st, A);   \
+      else hipLaunchKernelGGL((kweight_hop_energy<NSV, false, true>), grid, block, 0, st, A);         \
+    }                                                                                              \
+    break;
+  switch (nstage) {
+    AT_LAUNCH_NS(1) AT_LAUNCH_NS(2) AT_LAUNCH_NS(3) AT_LAUNCH_NS(4)
+  }
+#undef AT_LAUNCH_NS
+  if (!hop_path) {
+    AT_LAUNCH_CHECK();
+    const int64_t w2 = rows * nblk;
+    hipLaunchKernelGGL(block_energy_kernel, dim3((unsigned)((w2 + 3) / 4)), block, 0, st, A.y, E, rows, T, K, S, nblk);
+  }
+  AT_LAUNCH_CHECK();
+
+  GateArgs G;
+  G.E = E; G.out = out; G.B = (int)B; G.C = (int)C; G.H = H; G.nblk = nblk;
+  G.hops_per_block = hop_path ? K / S : 0;
+  G.inv_norm = (float)inv_norm;
+  G.floor_db = floor_db;
+  hipLaunchKernelGGL(lufs_gate, dim3((unsigned)B), dim3(64), 0, st, G);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+}  // extern "C"

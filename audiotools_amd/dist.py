@@ -1,0 +1,112 @@
+"""Multi-GPU execution of the hot path: one process per GPU, the batch dimension sharded in
+contiguous slabs, shared read-only tables broadcast once from rank 0 over RCCL/xGMI
+(``torch.distributed`` backend "nccl" IS RCCL on ROCm), no collective on the data path
+(SURVEY.md 8(e)).  Every hot-path op is independent per batch item, so there is nothing to
+reduce; the optional gather of per-item results is a convenience for the caller.
+
+CPU tests drive the same code with the ``gloo`` backend (tests/test_dist_gloo.py).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import tables
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
+            int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def init(backend: str = None):
+    """Join the process group described by the environment (no-op for a single process).
+    Returns (rank, world_size, device)."""
+    rank, local_rank, world = env_world()
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if use_cuda else "gloo"
+        kwargs = {"device_id": device} if (backend == "nccl" and use_cuda) else {}
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kwargs)
+    return rank, world, device
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous slab [lo, hi) of the batch owned by ``rank`` (sizes differ by at most 1)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def broadcast_table(key, builder, device, src: int = 0):
+    """Build a table (numpy array / tuple of arrays) on ``src`` only, broadcast it, and install
+    it in the per-device table cache of every rank.  Returns the device tensor(s)."""
+    import numpy as np
+
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        return tables.device_table(key, device, builder)
+    rank = dist.get_rank()
+    meta = [None]
+    arrays = None
+    if rank == src:
+        val = builder()
+        arrays = list(val) if isinstance(val, tuple) else [val]
+        arrays = [np.ascontiguousarray(a) for a in arrays]
+        meta = [([(a.shape, str(a.dtype)) for a in arrays], isinstance(val, tuple))]
+    dist.broadcast_object_list(meta, src=src)
+    specs, is_tuple = meta[0]
+    out = []
+    for i, (shape, dtype) in enumerate(specs):
+        if rank == src:
+            t = torch.from_numpy(arrays[i]).to(device)
+        else:
+            t = torch.empty(shape, dtype=getattr(torch, dtype), device=device)
+        dist.broadcast(t, src=src)
+        out.append(t)
+    val = tuple(out) if is_tuple else out[0]
+    tables.install_table(key, device, val)
+    return val
+
+
+def broadcast_stft_mel_tables(sample_rate, n_fft, window_type, n_mels, device, fmin=0.0, fmax=None):
+    """The shared tables of the STFT+mel kernel: window, twiddles, mel unit tables."""
+    import numpy as np
+
+    from . import _native
+
+    def tw():
+        out = np.empty(2 * n_fft, dtype=np.float32)
+        _native.check(_native.lib().at_stft_twiddles_host(n_fft, out.ctypes.data), "at_stft_twiddles_host")
+        return out
+
+    broadcast_table(("window", window_type, n_fft), lambda: tables.window_np(window_type, n_fft), device)
+    broadcast_table(("stft_tw", n_fft), tw, device)
+    broadcast_table(("mel_units", sample_rate, n_fft, n_mels, fmin, fmax),
+                    lambda: tables.mel_units_np(tables.mel_filters_np(sample_rate, n_fft, n_mels, fmin, fmax)), device)
+
+
+def gather_items(local: torch.Tensor, n_items: int):
+    """All-gather per-item results (e.g. the (B_local,) LUFS vector) into the full batch order."""
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        return local
+    sizes = [shard_range(n_items, r, world) for r in range(world)]
+    width = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)

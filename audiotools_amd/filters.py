@@ -1,0 +1,197 @@
+"""Time-domain filtering, resampling, overlap-add windows and STFT-domain
+masks of ``AudioSignal`` (reference ``audiotools/core/dsp.py:9-390`` and
+``audio_signal.py:716-736``).
+
+The FIR work (per-item windowed-sinc low/high-pass, polyphase resampling) runs
+on the HIP kernels of ``csrc/fir.hip`` for HIP float32 tensors; tensors that
+need autograd, or live on the CPU, use the equivalent torch formulation below.
+"""
+import typing
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import kernels, tables, util
+
+
+def _conv_rows_replicate(x: torch.Tensor, taps: torch.Tensor, half: int) -> torch.Tensor:
+    """Cross-correlate every row of x (R, T) with one FIR (L,), replicate padding."""
+    y = F.pad(x[:, None], (half, half), mode="replicate")
+    return F.conv1d(y, taps.to(x)[None, None])[:, 0]
+
+
+def lowpass_torch(audio: torch.Tensor, cutoffs: torch.Tensor, zeros: float, highpass: bool) -> torch.Tensor:
+    """Torch formulation of the reference's per-item julius low/high-pass
+    (dsp.py:173-179 / 205-211); items sharing a cutoff are filtered together."""
+    B, C, T = audio.shape
+    cut = cutoffs.detach().reshape(B).cpu()
+    out = torch.empty_like(audio)
+    for c in torch.unique(cut):
+        idx = (cut == c).nonzero()[:, 0].to(audio.device)
+        taps = tables.lowpass_taps(c, zeros)
+        half = (taps.numel() - 1) // 2
+        rows = audio[idx].reshape(-1, T)
+        low = _conv_rows_replicate(rows, taps, half).reshape(len(idx), C, T)
+        out[idx] = (audio[idx] - low) if highpass else low
+    return out
+
+
+def resample_torch(audio: torch.Tensor, old_sr: int, new_sr: int) -> torch.Tensor:
+    """Torch formulation of julius.resample_frac (audio_signal.py:732)."""
+    plan = tables.resample_bank(int(old_sr), int(new_sr))
+    if plan is None:
+        return audio
+    bank, old, new, width = plan
+    shape = audio.shape
+    T = shape[-1]
+    x = audio.reshape(-1, T)
+    x = F.pad(x[:, None], (width, width + old), mode="replicate")
+    ys = F.conv1d(x, bank.to(audio)[:, None], stride=old)
+    y = ys.transpose(1, 2).reshape(list(shape[:-1]) + [-1])
+    out_len = int(np.floor(new * T / old))
+    return y[..., :out_len]
+
+
+class DSPMixin:
+    _original_batch_size = None
+    _original_num_channels = None
+    _padded_signal_length = None
+
+    # ------------------------------------------------------------- resample
+    def resample(self, sample_rate: int):
+        """Windowed-sinc resampling to ``sample_rate`` (no-op if equal).  As in
+        the reference, ``stft_params`` are NOT re-derived for the new rate."""
+        if sample_rate == self.sample_rate:
+            return self
+        audio = self.audio_data
+        if kernels.is_native(audio) and kernels.have("at_resample_f32"):
+            self.audio_data = kernels.resample(audio, self.sample_rate, int(sample_rate))
+        else:
+            self.audio_data = resample_torch(audio, self.sample_rate, int(sample_rate))
+        self.sample_rate = sample_rate
+        return self
+
+    # ------------------------------------------------- windows / overlap-add
+    def _preprocess_signal_for_windowing(self, window_duration, hop_duration):
+        self._original_batch_size = self.batch_size
+        self._original_num_channels = self.num_channels
+        window_length = int(window_duration * self.sample_rate)
+        hop_length = int(hop_duration * self.sample_rate)
+        if window_length % hop_length != 0:
+            window_length = (window_length // hop_length) * hop_length
+        self.zero_pad(hop_length, hop_length)
+        self._padded_signal_length = self.signal_length
+        return window_length, hop_length
+
+    def windows(self, window_duration: float, hop_duration: float, preprocess: bool = True):
+        """Generator over windows (dsp.py:37-68)."""
+        if preprocess:
+            window_length, hop_length = self._preprocess_signal_for_windowing(window_duration, hop_duration)
+        self.audio_data = self.audio_data.reshape(-1, 1, self.signal_length)
+        for b in range(self.batch_size):
+            start = 0
+            while start + window_length <= self.signal_length:
+                yield self[b, ..., start: start + window_length]
+                start += hop_length
+
+    def collect_windows(self, window_duration: float, hop_duration: float, preprocess: bool = True):
+        """Reshape into a batch of windows (dsp.py:70-108)."""
+        if preprocess:
+            window_length, hop_length = self._preprocess_signal_for_windowing(window_duration, hop_duration)
+        rows = self.audio_data.reshape(-1, self.signal_length)
+        frames = rows.unfold(-1, window_length, hop_length)  # (rows, n, L)
+        self.audio_data = frames.reshape(-1, 1, window_length)
+        return self
+
+    def overlap_and_add(self, hop_duration: float):
+        """Inverse of collect_windows: overlap-add, divide by the overlap count (dsp.py:110-151)."""
+        hop_length = int(hop_duration * self.sample_rate)
+        window_length = self.signal_length
+        nb, nch = self._original_batch_size, self._original_num_channels
+        unfolded = self.audio_data.reshape(nb * nch, -1, window_length).permute(0, 2, 1)
+        size = dict(output_size=(1, self._padded_signal_length), kernel_size=(1, window_length),
+                    stride=(1, hop_length))
+        folded = F.fold(unfolded, **size)
+        norm = F.fold(torch.ones_like(unfolded), **size)
+        self.audio_data = (folded / norm).reshape(nb, nch, -1)
+        self.trim(hop_length, hop_length)
+        return self
+
+    # -------------------------------------------------------- low/high pass
+    def _sinc_filter(self, cutoffs, zeros, highpass):
+        cutoffs = util.ensure_tensor(cutoffs, 2, self.batch_size)
+        cutoffs = cutoffs / self.sample_rate
+        audio = self.audio_data
+        if kernels.is_native(audio) and kernels.have("at_fir_per_item_f32"):
+            filtered = kernels.sinc_filter(audio, cutoffs, zeros, highpass)
+        else:
+            filtered = lowpass_torch(audio, cutoffs, zeros, highpass)
+        self.audio_data = filtered
+        self.stft_data = None
+        return self
+
+    def low_pass(self, cutoffs: typing.Union[torch.Tensor, np.ndarray, float], zeros: int = 51):
+        """Per-item windowed-sinc low-pass, cutoffs in Hz (dsp.py:153-183)."""
+        return self._sinc_filter(cutoffs, zeros, highpass=False)
+
+    def high_pass(self, cutoffs: typing.Union[torch.Tensor, np.ndarray, float], zeros: int = 51):
+        """Per-item high-pass = signal - low-pass (dsp.py:185-215)."""
+        return self._sinc_filter(cutoffs, zeros, highpass=True)
+
+    # ----------------------------------------------------------- STFT masks
+    def mask_frequencies(self, fmin_hz, fmax_hz, val: float = 0.0):
+        """Set magnitude AND phase to ``val`` for fmin <= f < fmax (dsp.py:217-261)."""
+        mag, phase = self.magnitude, self.phase
+        fmin_hz = util.ensure_tensor(fmin_hz, ndim=mag.ndim)
+        fmax_hz = util.ensure_tensor(fmax_hz, ndim=mag.ndim)
+        assert torch.all(fmin_hz < fmax_hz)
+        nbins = mag.shape[-2]
+        bins_hz = torch.linspace(0, self.sample_rate / 2, nbins, device=self.device)
+        bins_hz = bins_hz[None, None, :, None].repeat(self.batch_size, 1, 1, mag.shape[-1])
+        mask = (fmin_hz.to(self.device) <= bins_hz) & (bins_hz < fmax_hz.to(self.device))
+        mag = mag.masked_fill(mask, val)
+        phase = phase.masked_fill(mask, val)
+        self.stft_data = mag * torch.exp(1j * phase)
+        return self
+
+    def mask_timesteps(self, tmin_s, tmax_s, val: float = 0.0):
+        """Set magnitude AND phase to ``val`` for tmin <= t < tmax (dsp.py:263-306)."""
+        mag, phase = self.magnitude, self.phase
+        tmin_s = util.ensure_tensor(tmin_s, ndim=mag.ndim)
+        tmax_s = util.ensure_tensor(tmax_s, ndim=mag.ndim)
+        assert torch.all(tmin_s < tmax_s)
+        nt = mag.shape[-1]
+        bins_t = torch.linspace(0, self.signal_duration, nt, device=self.device)
+        bins_t = bins_t[None, None, None, :].repeat(self.batch_size, 1, mag.shape[-2], 1)
+        mask = (tmin_s.to(self.device) <= bins_t) & (bins_t < tmax_s.to(self.device))
+        mag = mag.masked_fill(mask, val)
+        phase = phase.masked_fill(mask, val)
+        self.stft_data = mag * torch.exp(1j * phase)
+        return self
+
+    def mask_low_magnitudes(self, db_cutoff, val: float = 0.0):
+        """Mask bins whose log-magnitude is below ``db_cutoff`` (dsp.py:308-334)."""
+        mag = self.magnitude
+        log_mag = self.log_magnitude()
+        db_cutoff = util.ensure_tensor(db_cutoff, ndim=mag.ndim).to(self.device)
+        self.magnitude = mag.masked_fill(log_mag < db_cutoff, val)
+        return self
+
+    def shift_phase(self, shift):
+        shift = util.ensure_tensor(shift, ndim=self.phase.ndim).to(self.device)
+        self.phase = self.phase + shift
+        return self
+
+    def corrupt_phase(self, scale):
+        scale = util.ensure_tensor(scale, ndim=self.phase.ndim).to(self.device)
+        self.phase = self.phase + scale * torch.randn_like(self.phase)
+        return self
+
+    def preemphasis(self, coef: float = 0.85):
+        """y[n] = x[n-1] - coef * x[n]  (the reference's 3-tap conv, dsp.py:372-390)."""
+        kernel = torch.tensor([1, -coef, 0]).view(1, 1, -1).to(self.device)
+        x = self.audio_data.reshape(-1, 1, self.signal_length)
+        x = F.conv1d(x, kernel, padding=1)
+        self.audio_data = x.reshape(*self.audio_data.shape)
+        return self

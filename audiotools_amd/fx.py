@@ -1,0 +1,268 @@
+"""Effects of ``AudioSignal``: mixing, FFT convolution with impulse responses,
+loudness normalisation, mel-band equaliser, simple distortions, and the
+impulse-response DRR tools (reference ``audiotools/core/effects.py:9-647``).
+
+Fused formulations used here (results equal to the reference's within float32
+round-off):
+
+* ``equalizer``: the band split is a difference of low-passes, so the weighted
+  band sum is ONE FIR per item, ``h = w_last*delta + sum_k (w_k - w_{k+1}) h_k``;
+  the (B, C, T, n_bands) tensor is never materialised.
+* ``convolve``: the reference's "delta" FFT pair is an identity, so the
+  rescale factor is ``1 / clamp(max|ir|, 1e-5)`` of the rolled IR directly.
+"""
+import typing
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import kernels, tables, util
+
+
+def _roll_to_peak(ir: torch.Tensor) -> torch.Tensor:
+    """Rotate every (item, channel-0 arg-max) so the abs-peak sits at index 0
+    (effects.py:92-100, vectorised: no per-item host sync)."""
+    B, C, T = ir.shape
+    idx = ir.abs().argmax(dim=-1)  # (B, C)
+    if C != 1:
+        # the reference does idx[i].item(), which only works for mono IRs
+        raise RuntimeError("start_at_max requires a single-channel impulse response")
+    ar = torch.arange(T, device=ir.device)[None, None, :]
+    src = (ar + idx[..., None]) % T
+    return torch.gather(ir, -1, src)
+
+
+def fftconv_torch(x: torch.Tensor, ir: torch.Tensor) -> torch.Tensor:
+    """Circular convolution at length T via rFFT (effects.py:102-111)."""
+    T = x.shape[-1]
+    return torch.fft.irfft(torch.fft.rfft(ir, T) * torch.fft.rfft(x, T), T)
+
+
+def band_split_torch(audio: torch.Tensor, sample_rate: int, n_bands: int) -> torch.Tensor:
+    """(n_bands, B, C, T) mel band split (effects.py:399-403 -> julius.SplitBands)."""
+    bank, half = tables.band_split_bank(int(sample_rate), int(n_bands))
+    if bank is None:
+        return audio[None]
+    B, C, T = audio.shape
+    x = F.pad(audio.reshape(-1, 1, T), (half, half), mode="replicate")
+    lows = F.conv1d(x, bank.to(audio)[:, None]).permute(1, 0, 2).reshape(-1, B, C, T)
+    bands = [lows[0]] + [lows[i] - lows[i - 1] for i in range(1, lows.shape[0])] + [audio - lows[-1]]
+    return torch.stack(bands)
+
+
+def equalizer_taps(sample_rate: int, weights: torch.Tensor):
+    """Composite per-item FIR (B, L) equivalent to sum_k weights[:, k] * band_k."""
+    n_bands = weights.shape[-1]
+    bank, half = tables.band_split_bank(int(sample_rate), int(n_bands))
+    if bank is None:
+        return weights[:, :1].clone(), 0
+    w = weights.float().cpu()
+    diff = w[:, :-1] - w[:, 1:]            # (B, n_bands-1)
+    taps = diff @ bank                     # (B, L)
+    taps[:, half] += w[:, -1]
+    return taps, half
+
+
+class EffectMixin:
+    GAIN_FACTOR = np.log(10) / 20
+    """Gain factor for converting between amplitude and decibels."""
+
+    # ------------------------------------------------------------------ mix
+    def mix(self, other, snr: typing.Union[torch.Tensor, np.ndarray, float] = 10,
+            other_eq: typing.Union[torch.Tensor, np.ndarray] = None):
+        """Add ``other`` at ``snr`` dB below this signal's loudness (effects.py:27-64)."""
+        snr = util.ensure_tensor(snr).to(self.device)
+        other.zero_pad(0, max(0, self.signal_length - other.signal_length))
+        other.truncate_samples(self.signal_length)
+        if other_eq is not None:
+            other = other.equalizer(other_eq)
+        other = other.normalize(self.loudness() - snr)
+        self.audio_data = self.audio_data + other.audio_data
+        return self
+
+    # ------------------------------------------------------------- convolve
+    def convolve(self, other, start_at_max: bool = True):
+        """Circular FFT convolution with ``other`` (padded/truncated in place
+        to this signal's length), rescaled by 1/max|ir| (effects.py:66-123)."""
+        pad_len = self.signal_length - other.signal_length
+        if pad_len > 0:
+            other.zero_pad(0, pad_len)
+        else:
+            other.truncate_samples(self.signal_length)
+        ir = other.audio_data
+        if start_at_max:
+            ir = _roll_to_peak(ir)
+        scale = 1 / ir.abs().max(dim=-1, keepdim=True)[0].clamp(1e-5)
+        x = self.audio_data
+        if kernels.is_native(x) and kernels.is_native(ir) and kernels.have("at_fftconv_circ_f32"):
+            y = kernels.fftconv(x, ir, scale)
+        else:
+            y = fftconv_torch(x, ir) * scale
+        self.audio_data = y
+        return self
+
+    def __matmul__(self, other):
+        return self.convolve(other)
+
+    def apply_ir(self, ir, drr=None, ir_eq=None, use_original_phase: bool = False):
+        """Room simulation: optional IR EQ and DRR change, convolve, restore
+        the input peak (effects.py:125-179)."""
+        if ir_eq is not None:
+            ir = ir.equalizer(ir_eq)
+        if drr is not None:
+            ir = ir.alter_drr(drr)
+        max_spk = self.audio_data.abs().max(dim=-1, keepdims=True).values
+        # The reference evaluates ``self.phase`` here unconditionally (effects.py:165): a full
+        # STFT + angle whose result is unused unless ``use_original_phase``, leaving a STALE
+        # ``stft_data`` behind.  Deliberate deviation (DESIGN.md "Deviations"): the phase is only
+        # computed when it is used, and ``stft_data`` is left untouched otherwise.
+        phase = self.phase if use_original_phase else None
+        self.convolve(ir)
+        if use_original_phase:
+            self.stft()
+            self.stft_data = self.magnitude * torch.exp(1j * phase)
+            self.istft()
+        max_transformed = self.audio_data.abs().max(dim=-1, keepdims=True).values
+        scale_factor = max_spk.clamp(1e-8) / max_transformed.clamp(1e-8)
+        self = self * scale_factor
+        return self
+
+    # --------------------------------------------------------------- levels
+    def ensure_max_of_audio(self, max: float = 1.0):
+        peak = self.audio_data.abs().max(dim=-1, keepdims=True)[0]
+        gain = torch.where(peak > max, max / peak, torch.ones_like(peak))
+        self.audio_data = self.audio_data * gain
+        return self
+
+    def normalize(self, db: typing.Union[torch.Tensor, np.ndarray, float] = -24.0):
+        db = util.ensure_tensor(db).to(self.device)
+        gain = torch.exp((db - self.loudness()) * self.GAIN_FACTOR)
+        self.audio_data = self.audio_data * gain[:, None, None]
+        return self
+
+    def volume_change(self, db: typing.Union[torch.Tensor, np.ndarray, float]):
+        db = util.ensure_tensor(db, ndim=1).to(self.device)
+        gain = torch.exp(db * self.GAIN_FACTOR)
+        self.audio_data = self.audio_data * gain[:, None, None]
+        return self
+
+    def _to_2d(self):
+        return self.audio_data.reshape(-1, self.signal_length)
+
+    def _to_3d(self, waveform):
+        return waveform.reshape(self.batch_size, self.num_channels, -1)
+
+    # ------------------------------------------------ sox / codec escapes
+    def pitch_shift(self, n_semitones: int, quick: bool = True):
+        raise NotImplementedError(
+            "pitch_shift is a CPU libsox round-trip in the reference (effects.py:247-277); "
+            "out of scope of the accelerated path (SURVEY.md 8(f) rank 4)")
+
+    def time_stretch(self, factor: float, quick: bool = True):
+        raise NotImplementedError(
+            "time_stretch is a CPU libsox round-trip in the reference (effects.py:279-309); "
+            "out of scope of the accelerated path (SURVEY.md 8(f) rank 4)")
+
+    def apply_codec(self, preset: str = None, format: str = "wav", encoding: str = None,
+                    bits_per_sample: int = None, compression: int = None):
+        raise NotImplementedError("apply_codec needs torchaudio codecs (effects.py:311-384); out of scope")
+
+    # ------------------------------------------------------------ equaliser
+    def mel_filterbank(self, n_bands: int):
+        """(B, C, T, n_bands) mel-spaced band split that sums to the input (effects.py:386-403)."""
+        return band_split_torch(self.audio_data, self.sample_rate, n_bands).permute(1, 2, 3, 0)
+
+    def equalizer(self, db: typing.Union[torch.Tensor, np.ndarray]):
+        """Per-band gains ``10 ** db`` (sic, effects.py:429) applied to the mel band split."""
+        db = util.ensure_tensor(db)
+        n_bands = db.shape[-1]
+        if db.ndim == 2:
+            if db.shape[0] != 1:
+                assert db.shape[0] == self.batch_size
+        else:
+            db = db.unsqueeze(0)
+        weights = (10 ** db).float()
+        audio = self.audio_data
+        if kernels.is_native(audio) and kernels.have("at_fir_per_item_f32"):
+            taps, half = equalizer_taps(self.sample_rate, weights.expand(self.batch_size, n_bands))
+            self.audio_data = kernels.fir_per_item(audio, taps.to(audio.device), replicate=True)
+        else:
+            fbank = self.mel_filterbank(n_bands)
+            self.audio_data = (fbank * weights.to(self.device)[:, None, None, :]).sum(-1)
+        return self
+
+    # ----------------------------------------------------------- distortions
+    def clip_distortion(self, clip_percentile: typing.Union[torch.Tensor, np.ndarray, float]):
+        clip_percentile = util.ensure_tensor(clip_percentile, ndim=1).to(self.device)
+        lo = torch.quantile(self.audio_data, clip_percentile / 2, dim=-1)
+        hi = torch.quantile(self.audio_data, 1 - (clip_percentile / 2), dim=-1)
+        nc = self.audio_data.shape[1]
+        self.audio_data = self.audio_data.clamp(lo[:, :nc, :], hi[:, :nc, :])
+        return self
+
+    def quantization(self, quantization_channels: typing.Union[torch.Tensor, np.ndarray, int]):
+        q = util.ensure_tensor(quantization_channels, ndim=3).to(self.device)
+        x = self.audio_data
+        x = ((x + 1) / 2 * q).floor() / q
+        x = 2 * x - 1
+        residual = (self.audio_data - x).detach()
+        self.audio_data = self.audio_data - residual
+        return self
+
+    def mulaw_quantization(self, quantization_channels: typing.Union[torch.Tensor, np.ndarray, int]):
+        mu = util.ensure_tensor(quantization_channels - 1.0, ndim=3).to(self.device)
+        x = self.audio_data
+        x = torch.sign(x) * torch.log1p(mu * torch.abs(x)) / torch.log1p(mu)
+        x = ((x + 1) / 2 * mu + 0.5).to(torch.int64)
+        x = (x / mu) * 2 - 1.0
+        x = torch.sign(x) * (torch.exp(torch.abs(x) * torch.log1p(mu)) - 1.0) / mu
+        residual = (self.audio_data - x).detach()
+        self.audio_data = self.audio_data - residual
+        return self
+
+
+class ImpulseResponseMixin:
+    """Direct-to-reverberant-ratio tools (effects.py:529-647; Bryan 2019,
+    "Impulse response data augmentation and deep neural networks for blind
+    room acoustic parameter estimation")."""
+
+    def decompose_ir(self):
+        """(early_response, late_field, window): early = +-2.5 ms around the
+        arg-max sample, window = Hann over the early span."""
+        x = self.audio_data
+        td = torch.argmax(x, dim=-1, keepdim=True)
+        t0 = int(self.sample_rate * 0.0025)
+        idx = torch.arange(x.shape[-1], device=self.device)[None, None, :].expand(self.batch_size, -1, -1)
+        early_idx = (idx >= td - t0) * (idx <= td + t0)
+        early = torch.where(early_idx, x, torch.zeros_like(x))
+        late = torch.where(early_idx, torch.zeros_like(x), x)
+        window = torch.zeros_like(x)
+        for b in range(self.batch_size):
+            w_idx = early_idx[b, 0].nonzero()
+            window[b, ..., w_idx] = self.get_window("hann", w_idx.shape[-1], str(self.device))
+        return early, late, window
+
+    def measure_drr(self):
+        early, late, _ = self.decompose_ir()
+        return 10 * torch.log10((early ** 2).sum(dim=-1) / (late ** 2).sum(dim=-1))
+
+    @staticmethod
+    def solve_alpha(early_response, late_field, wd, target_drr):
+        """Quadratic for the direct-path gain that reaches ``target_drr`` (eq. 5)."""
+        e_sq = early_response ** 2
+        a = ((wd ** 2) * e_sq).sum(dim=-1)
+        b = (2 * (1 - wd) * wd * e_sq).sum(dim=-1)
+        c = (((1 - wd) ** 2) * e_sq).sum(dim=-1) - torch.pow(10, target_drr / 10) * (late_field ** 2).sum(dim=-1)
+        disc = ((b ** 2) - 4 * a * c).sqrt()
+        return torch.maximum((-b - disc) / (2 * a), (-b + disc) / (2 * a))
+
+    def alter_drr(self, drr: typing.Union[torch.Tensor, np.ndarray, float]):
+        drr = util.ensure_tensor(drr, 2, self.batch_size).to(self.device)
+        early, late, window = self.decompose_ir()
+        alpha = self.solve_alpha(early, late, window, drr)
+        min_alpha = late.abs().max(dim=-1)[0] / early.abs().max(dim=-1)[0]
+        alpha = torch.maximum(alpha, min_alpha)[..., None]
+        self.audio_data = alpha * window * early + ((1 - window) * early) + late
+        self.ensure_max_of_audio()
+        return self

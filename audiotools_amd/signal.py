@@ -1,0 +1,397 @@
+"""``AudioSignal``: the batched audio container of the reference
+(``audiotools/core/audio_signal.py:53-1682``) with its hot-path methods
+running on hand-written gfx950 kernels.
+
+Only the container logic lives here; the DSP methods are mixed in from
+``spectral.py`` (STFT / iSTFT / mel / MFCC / magnitude / phase),
+``meter.py`` (LUFS), ``filters.py`` (low/high-pass, STFT masks, OLA windows),
+``fx.py`` (mix, convolve, apply_ir, normalize, equalizer, ...).
+
+Semantics kept bug-compatible with the reference where observable
+(SURVEY.md 7.3 "In-place fluent API + caches"): methods mutate and return
+``self``; assigning ``audio_data`` drops the cached loudness; assigning
+``stft_params`` drops ``stft_data``; ``resample`` does not touch
+``stft_params``.
+"""
+import copy
+import pathlib
+import typing
+import warnings
+
+import numpy as np
+import torch
+
+from . import util
+from .filters import DSPMixin
+from .fx import EffectMixin, ImpulseResponseMixin
+from .meter import LoudnessMixin
+from .spectral import STFTParams, SpectralMixin
+
+__all__ = ["AudioSignal", "STFTParams"]
+
+
+class AudioSignal(SpectralMixin, EffectMixin, LoudnessMixin, ImpulseResponseMixin, DSPMixin):
+    """Batch of audio: ``audio_data`` (B, C, T) float32, ``stft_data``
+    (B, C, F, N) complex64 or None, ``sample_rate``, ``stft_params``."""
+
+    def __init__(self, audio_path_or_array, sample_rate: int = None, stft_params: STFTParams = None,
+                 offset: float = 0, duration: float = None, device: str = None):
+        is_path = isinstance(audio_path_or_array, (str, pathlib.Path))
+        is_array = isinstance(audio_path_or_array, np.ndarray) or torch.is_tensor(audio_path_or_array)
+        if not (is_path or is_array):
+            raise ValueError("audio_path_or_array must be either a Path, string, numpy array, or torch Tensor!")
+
+        self.path_to_file = None
+        self.audio_data = None
+        self.sources = None
+        self.stft_data = None
+        if is_path:
+            self.load_from_file(audio_path_or_array, offset=offset, duration=duration, device=device)
+        else:
+            assert sample_rate is not None, "Must set sample rate!"
+            self.load_from_array(audio_path_or_array, sample_rate, device=device)
+        self.window = None
+        self.stft_params = stft_params
+        self.metadata = {"offset": offset, "duration": duration}
+
+    # ------------------------------------------------------------ factories
+    @property
+    def path_to_input_file(self):
+        return self.path_to_file
+
+    @classmethod
+    def zeros(cls, duration: float, sample_rate: int, num_channels: int = 1, batch_size: int = 1, **kwargs):
+        return cls(torch.zeros(batch_size, num_channels, int(duration * sample_rate)), sample_rate, **kwargs)
+
+    @classmethod
+    def wave(cls, frequency: float, duration: float, sample_rate: int, num_channels: int = 1,
+             shape: str = "sine", **kwargs):
+        """Simple test tone ("sine", "square", "sawtooth", "triangle")."""
+        from scipy import signal as sps
+
+        t = torch.linspace(0, duration, int(duration * sample_rate))
+        ph = 2 * np.pi * frequency * t
+        if shape == "sawtooth":
+            wave = torch.from_numpy(sps.sawtooth(ph.numpy(), 0.5))
+        elif shape == "square":
+            wave = torch.from_numpy(sps.square(ph.numpy()))
+        elif shape == "sine":
+            wave = torch.sin(ph)
+        elif shape == "triangle":
+            wave = torch.from_numpy(sps.sawtooth(ph.numpy(), 0.5))
+        else:
+            raise ValueError(f"Invalid shape {shape}")
+        wave = wave.unsqueeze(0).unsqueeze(0).repeat(1, num_channels, 1)
+        return cls(wave, sample_rate, **kwargs)
+
+    @classmethod
+    def batch(cls, audio_signals: list, pad_signals: bool = False, truncate_signals: bool = False,
+              resample: bool = False, dim: int = 0):
+        """Concatenate signals along ``dim`` after equalising rate/length
+        (RuntimeError if they differ and no policy is given)."""
+        rates = [s.sample_rate for s in audio_signals]
+        if len(set(rates)) != 1:
+            if not resample:
+                raise RuntimeError(
+                    f"Not all signals had the same sample rate! Got {rates}. "
+                    f"All signals must have the same sample rate, or resample must be True. ")
+            for s in audio_signals:
+                s.resample(rates[0])
+        lengths = [s.signal_length for s in audio_signals]
+        if len(set(lengths)) != 1:
+            if pad_signals:
+                longest = max(lengths)
+                for s in audio_signals:
+                    s.zero_pad(0, longest - s.signal_length)
+            elif truncate_signals:
+                shortest = min(lengths)
+                for s in audio_signals:
+                    s.truncate_samples(shortest)
+            else:
+                raise RuntimeError(
+                    f"Not all signals had the same length! Got {lengths}. "
+                    f"All signals must be the same length, or pad_signals/truncate_signals must be True. ")
+        out = cls(torch.cat([s.audio_data for s in audio_signals], dim=dim), sample_rate=audio_signals[0].sample_rate)
+        out.path_to_file = [s.path_to_file for s in audio_signals]
+        return out
+
+    # ------------------------------------------------------------------ I/O
+    def load_from_file(self, audio_path, offset: float, duration: float = None, device: str = "cpu"):
+        """File decoding is outside the accelerated path (I/O
+        is out of scope); supported only when ``soundfile`` is installed."""
+        try:
+            import soundfile
+        except ImportError as e:
+            raise RuntimeError("loading audio files needs the optional `soundfile` package") from e
+        info = soundfile.info(str(audio_path))
+        start = int(offset * info.samplerate)
+        frames = -1 if duration is None else int(duration * info.samplerate)
+        data, sr = soundfile.read(str(audio_path), start=start, frames=frames, always_2d=True, dtype="float32")
+        if data.shape[0] == 0:
+            raise RuntimeError(f"Audio file {audio_path} with offset {offset} and duration {duration} is empty!")
+        self.audio_data = torch.from_numpy(data.T.copy()).unsqueeze(0)
+        self.original_signal_length = self.signal_length
+        self.sample_rate = sr
+        self.path_to_file = audio_path
+        return self.to(device)
+
+    def load_from_array(self, audio_array, sample_rate: int, device: str = "cpu"):
+        data = util.ensure_tensor(audio_array)
+        if data.dtype == torch.double:
+            data = data.float()
+        while data.ndim < 3:
+            data = data.unsqueeze(0)
+        self.audio_data = data
+        self.original_signal_length = self.signal_length
+        self.sample_rate = sample_rate
+        return self.to(device)
+
+    def write(self, audio_path):
+        import soundfile
+
+        if self.audio_data[0].abs().max() > 1:
+            warnings.warn("Audio amplitude > 1 clipped when saving")
+        soundfile.write(str(audio_path), self.audio_data[0].cpu().numpy().T, self.sample_rate)
+        self.path_to_file = audio_path
+        return self
+
+    # -------------------------------------------------------------- copying
+    def deepcopy(self):
+        return copy.deepcopy(self)
+
+    def copy(self):
+        return copy.copy(self)
+
+    def clone(self):
+        twin = type(self)(self.audio_data.clone(), self.sample_rate, stft_params=self.stft_params)
+        if self.stft_data is not None:
+            twin.stft_data = self.stft_data.clone()
+        if self._loudness is not None:
+            twin._loudness = self._loudness.clone()
+        twin.path_to_file = copy.deepcopy(self.path_to_file)
+        twin.metadata = copy.deepcopy(self.metadata)
+        return twin
+
+    def detach(self):
+        if self._loudness is not None:
+            self._loudness = self._loudness.detach()
+        if self.stft_data is not None:
+            self.stft_data = self.stft_data.detach()
+        self.audio_data = self.audio_data.detach()
+        return self
+
+    # ------------------------------------------------------ signal-level ops
+    def to_mono(self):
+        self.audio_data = self.audio_data.mean(1, keepdim=True)
+        return self
+
+    def to(self, device: str):
+        if self._loudness is not None:
+            self._loudness = self._loudness.to(device)
+        if self.stft_data is not None:
+            self.stft_data = self.stft_data.to(device)
+        if self.audio_data is not None:
+            self.audio_data = self.audio_data.to(device)
+        return self
+
+    def float(self):
+        self.audio_data = self.audio_data.float()
+        return self
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def numpy(self):
+        return self.audio_data.detach().cpu().numpy()
+
+    def zero_pad(self, before: int, after: int):
+        self.audio_data = torch.nn.functional.pad(self.audio_data, (before, after))
+        return self
+
+    def zero_pad_to(self, length: int, mode: str = "after"):
+        short = max(length - self.signal_length, 0)
+        if mode == "before":
+            self.zero_pad(short, 0)
+        elif mode == "after":
+            self.zero_pad(0, short)
+        return self
+
+    def trim(self, before: int, after: int):
+        end = None if after == 0 else -after
+        self.audio_data = self.audio_data[..., before:end]
+        return self
+
+    def truncate_samples(self, length_in_samples: int):
+        self.audio_data = self.audio_data[..., :length_in_samples]
+        return self
+
+    # ----------------------------------------------------------- properties
+    @property
+    def device(self):
+        if self.audio_data is not None:
+            return self.audio_data.device
+        if self.stft_data is not None:
+            return self.stft_data.device
+        return None
+
+    @property
+    def audio_data(self):
+        return self._audio_data
+
+    @audio_data.setter
+    def audio_data(self, data):
+        if data is not None:
+            assert torch.is_tensor(data), "audio_data should be torch.Tensor"
+            assert data.ndim == 3, "audio_data should be 3-dim (B, C, T)"
+        self._audio_data = data
+        self._loudness = None  # stale once the samples change
+
+    samples = audio_data
+
+    @property
+    def stft_data(self):
+        return self._stft_data
+
+    @stft_data.setter
+    def stft_data(self, data):
+        if data is not None:
+            assert torch.is_tensor(data) and torch.is_complex(data)
+            if self.stft_data is not None and self.stft_data.shape != data.shape:
+                warnings.warn("stft_data changed shape")
+        self._stft_data = data
+
+    @property
+    def batch_size(self):
+        return self.audio_data.shape[0]
+
+    @property
+    def signal_length(self):
+        return self.audio_data.shape[-1]
+
+    length = signal_length
+
+    @property
+    def shape(self):
+        return self.audio_data.shape
+
+    @property
+    def signal_duration(self):
+        return self.signal_length / self.sample_rate
+
+    duration = signal_duration
+
+    @property
+    def num_channels(self):
+        return self.audio_data.shape[1]
+
+    # ----------------------------------------------------------- arithmetic
+    def __add__(self, other):
+        out = self.clone()
+        out.audio_data += util._get_value(other)
+        return out
+
+    def __iadd__(self, other):
+        self.audio_data += util._get_value(other)
+        return self
+
+    def __radd__(self, other):
+        return self + other
+
+    def __sub__(self, other):
+        out = self.clone()
+        out.audio_data -= util._get_value(other)
+        return out
+
+    def __isub__(self, other):
+        self.audio_data -= util._get_value(other)
+        return self
+
+    def __mul__(self, other):
+        out = self.clone()
+        out.audio_data *= util._get_value(other)
+        return out
+
+    def __imul__(self, other):
+        self.audio_data *= util._get_value(other)
+        return self
+
+    def __rmul__(self, other):
+        return self * other
+
+    # ------------------------------------------------------- representation
+    def _info(self):
+        dur = f"{self.signal_duration:0.3f}" if self.signal_duration else "[unknown]"
+        return {
+            "duration": f"{dur} seconds",
+            "batch_size": self.batch_size,
+            "path": self.path_to_file if self.path_to_file else "path unknown",
+            "sample_rate": self.sample_rate,
+            "num_channels": self.num_channels if self.num_channels else "[unknown]",
+            "audio_data.shape": self.audio_data.shape,
+            "stft_params": self.stft_params,
+            "device": self.device,
+        }
+
+    def __str__(self):
+        return "\n".join(f"{k}: {v}" for k, v in self._info().items())
+
+    __repr__ = __str__
+
+    # ---------------------------------------------------- equality/indexing
+    def __eq__(self, other):
+        for k, v in list(self.__dict__.items()):
+            if torch.is_tensor(v):
+                if not torch.allclose(v, other.__dict__[k], atol=1e-6):
+                    print(f"Max abs error for {k}: {(v - other.__dict__[k]).abs().max()}")
+                    return False
+        return True
+
+    def __ne__(self, other):
+        return not self == other
+
+    __hash__ = object.__hash__
+
+    @staticmethod
+    def _is_whole_batch_key(key):
+        return torch.is_tensor(key) and key.ndim == 0 and key.item() is True
+
+    @staticmethod
+    def _is_batch_key(key):
+        return isinstance(key, (bool, int, list, slice, tuple)) or (torch.is_tensor(key) and key.ndim <= 1)
+
+    def __getitem__(self, key):
+        if self._is_whole_batch_key(key):
+            assert self.batch_size == 1
+            audio, loud, stft = self.audio_data, self._loudness, self.stft_data
+        elif self._is_batch_key(key):
+            audio = self.audio_data[key]
+            loud = self._loudness[key] if self._loudness is not None else None
+            stft = self.stft_data[key] if self.stft_data is not None else None
+        else:
+            raise TypeError(f"unsupported index {key!r}")
+        view = type(self)(audio, self.sample_rate, stft_params=self.stft_params)
+        view._loudness = loud
+        view._stft_data = stft
+        view.sources = None
+        return view
+
+    def __setitem__(self, key, value):
+        if not isinstance(value, type(self)):
+            self.audio_data[key] = value
+            return
+        if self._is_whole_batch_key(key):
+            assert self.batch_size == 1
+            self.audio_data = value.audio_data
+            self._loudness = value._loudness
+            self.stft_data = value.stft_data
+            return
+        if self._is_batch_key(key):
+            if self.audio_data is not None and value.audio_data is not None:
+                self.audio_data[key] = value.audio_data
+            if self._loudness is not None and value._loudness is not None:
+                self._loudness[key] = value._loudness
+            if self.stft_data is not None and value.stft_data is not None:
+                self.stft_data[key] = value.stft_data

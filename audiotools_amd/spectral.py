@@ -1,0 +1,195 @@
+"""STFT-domain methods of ``AudioSignal`` (reference
+``audiotools/core/audio_signal.py:28-50, 1009-1516``).
+
+HIP tensors (float32, no autograd) run the fused kernel in ``csrc/stft.hip``;
+tensors that need autograd, or CPU tensors, run the same maths through torch
+ops (the reference's own formulation) so that ``tests/core/test_grad.py``-style
+use keeps working.
+"""
+import collections
+import functools
+import math
+
+import numpy as np
+import torch
+
+from . import kernels, tables
+
+STFTParams = collections.namedtuple(
+    "STFTParams", ["window_length", "hop_length", "window_type", "match_stride", "padding_type"])
+STFTParams.__new__.__defaults__ = (None, None, None, None, None)
+STFTParams.__doc__ = """STFT configuration of an AudioSignal (audio_signal.py:28-50).
+
+window_length : int   default 2 ** ceil(log2(0.032 * sample_rate))
+hop_length    : int   default window_length // 4
+window_type   : str   scipy window name, "sqrt_hann" or "average"; default "hann"
+match_stride  : bool  pad so that frames * hop == samples (conv-stride alignment); default False
+padding_type  : str   torch pad mode for the match_stride padding; default "reflect"
+"""
+
+
+class SpectralMixin:
+    # ---------------------------------------------------------------- params
+    @staticmethod
+    @functools.lru_cache(None)
+    def get_window(window_type: str, window_length: int, device: str):
+        """Analysis window as a float32 tensor on ``device`` (cached)."""
+        return tables.window(window_type, int(window_length), torch.device(device))
+
+    @property
+    def stft_params(self):
+        return self._stft_params
+
+    @stft_params.setter
+    def stft_params(self, value: STFTParams):
+        win = int(2 ** (np.ceil(np.log2(0.032 * self.sample_rate))))
+        defaults = dict(window_length=win, hop_length=win // 4, window_type="hann",
+                        match_stride=False, padding_type="reflect")
+        given = value._asdict() if value else defaults
+        merged = {k: (defaults[k] if given[k] is None else given[k]) for k in defaults}
+        self._stft_params = STFTParams(**merged)
+        self.stft_data = None
+
+    def compute_stft_padding(self, window_length: int, hop_length: int, match_stride: bool):
+        """(right_pad, pad) added around the audio before torch.stft-style
+        centring when ``match_stride`` (audio_signal.py:1089-1121)."""
+        if not match_stride:
+            return 0, 0
+        assert hop_length == window_length // 4, "For match_stride, hop must equal n_fft // 4"
+        length = self.signal_length
+        right_pad = math.ceil(length / hop_length) * hop_length - length
+        pad = (window_length - hop_length) // 2
+        return right_pad, pad
+
+    def _resolve(self, window_length, hop_length, window_type, match_stride, padding_type=None):
+        p = self.stft_params
+        return (p.window_length if window_length is None else int(window_length),
+                p.hop_length if hop_length is None else int(hop_length),
+                p.window_type if window_type is None else window_type,
+                p.match_stride if match_stride is None else match_stride,
+                p.padding_type if padding_type is None else padding_type)
+
+    # ------------------------------------------------------------------ STFT
+    def _torch_stft(self, n_fft, hop, window, match_stride, padding_type, right_pad, pad):
+        x = torch.nn.functional.pad(self.audio_data, (pad, pad + right_pad), padding_type)
+        X = torch.stft(x.reshape(-1, x.shape[-1]), n_fft=n_fft, hop_length=hop, window=window,
+                       return_complex=True, center=True)
+        X = X.reshape(self.batch_size, self.num_channels, X.shape[1], X.shape[2])
+        return X[..., 2:-2] if match_stride else X
+
+    def stft(self, window_length: int = None, hop_length: int = None, window_type: str = None,
+             match_stride: bool = None, padding_type: str = None):
+        """Short-time Fourier transform -> complex64 (B, C, F, N); also stored
+        in ``stft_data`` (audio_signal.py:1123-1212)."""
+        n_fft, hop, wtype, match_stride, padding_type = self._resolve(
+            window_length, hop_length, window_type, match_stride, padding_type)
+        audio = self.audio_data
+        window = self.get_window(wtype, n_fft, str(audio.device))
+        right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
+        if kernels.is_native(audio) and kernels.stft_native_supported(n_fft):
+            X, _ = kernels.stft_mel(audio, window, n_fft, hop, pad=pad, right_pad=right_pad,
+                                    padding_type=padding_type, match_stride=match_stride)
+        else:
+            X = self._torch_stft(n_fft, hop, window, match_stride, padding_type, right_pad, pad)
+        self.stft_data = X
+        return X
+
+    def istft(self, window_length: int = None, hop_length: int = None, window_type: str = None,
+              match_stride: bool = None, length: int = None):
+        """Inverse STFT of ``stft_data`` into ``audio_data`` (audio_signal.py:1214-1296)."""
+        if self.stft_data is None:
+            raise RuntimeError("Cannot do inverse STFT without self.stft_data!")
+        n_fft, hop, wtype, match_stride, _ = self._resolve(window_length, hop_length, window_type, match_stride)
+        window = self.get_window(wtype, n_fft, str(self.stft_data.device))
+        nb, nch, nf, nt = self.stft_data.shape
+        X = self.stft_data.reshape(nb * nch, nf, nt)
+        right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
+        if length is None:
+            length = self.original_signal_length + 2 * pad + right_pad
+        if match_stride:
+            X = torch.nn.functional.pad(X, (2, 2))
+        x = torch.istft(X, n_fft=n_fft, hop_length=hop, window=window, length=length, center=True)
+        x = x.reshape(nb, nch, -1)
+        if match_stride:
+            x = x[..., pad: -(pad + right_pad)]
+        self.audio_data = x
+        return self
+
+    # ------------------------------------------------------------- mel, mfcc
+    @staticmethod
+    @functools.lru_cache(None)
+    def get_mel_filters(sr: int, n_fft: int, n_mels: int, fmin: float = 0.0, fmax: float = None):
+        """(n_mels, 1 + n_fft/2) float32 Slaney mel basis (audio_signal.py:1298-1331)."""
+        return tables.mel_filters_np(sr, n_fft, n_mels, fmin, fmax)
+
+    def mel_spectrogram(self, n_mels: int = 80, mel_fmin: float = 0.0, mel_fmax: float = None, **kwargs):
+        """|STFT| projected on a mel basis -> (B, C, n_mels, N)
+        (audio_signal.py:1333-1369).  Also refreshes ``stft_data`` exactly as
+        the reference's internal ``self.stft(**kwargs)`` does."""
+        n_fft, hop, wtype, match_stride, padding_type = self._resolve(
+            kwargs.get("window_length"), kwargs.get("hop_length"), kwargs.get("window_type"),
+            kwargs.get("match_stride"), kwargs.get("padding_type"))
+        audio = self.audio_data
+        if kernels.is_native(audio) and kernels.stft_native_supported(n_fft):
+            dev = audio.device
+            k0, w, ub = tables.mel_units(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, dev)
+            window = self.get_window(wtype, n_fft, str(dev))
+            right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
+            X, mel = kernels.stft_mel(audio, window, n_fft, hop, pad=pad, right_pad=right_pad,
+                                      padding_type=padding_type, match_stride=match_stride,
+                                      mel=(k0, w, ub, n_mels))
+            self.stft_data = X
+            return mel
+        X = self.stft(**kwargs)
+        magnitude = torch.abs(X)
+        nf = magnitude.shape[2]
+        basis = self.get_mel_filters(sr=self.sample_rate, n_fft=2 * (nf - 1), n_mels=n_mels,
+                                     fmin=mel_fmin, fmax=mel_fmax)
+        basis = torch.from_numpy(basis).to(self.device)
+        mel = magnitude.transpose(2, -1) @ basis.T
+        return mel.transpose(-1, 2)
+
+    @staticmethod
+    @functools.lru_cache(None)
+    def get_dct(n_mfcc: int, n_mels: int, norm: str = "ortho", device: str = None):
+        """DCT-II matrix (n_mels, n_mfcc) (audio_signal.py:1371-1396)."""
+        return torch.from_numpy(tables.dct_np(n_mfcc, n_mels, norm)).to(device)
+
+    def mfcc(self, n_mfcc: int = 40, n_mels: int = 80, log_offset: float = 1e-6, **kwargs):
+        """log-mel -> DCT (audio_signal.py:1398-1426)."""
+        mel = self.mel_spectrogram(n_mels, **kwargs)
+        mel = torch.log(mel + log_offset)
+        dct = self.get_dct(n_mfcc, n_mels, "ortho", self.device)
+        return (mel.transpose(-1, -2) @ dct).transpose(-1, -2)
+
+    # -------------------------------------------------------- magnitude/phase
+    @property
+    def magnitude(self):
+        if self.stft_data is None:
+            self.stft()
+        return torch.abs(self.stft_data)
+
+    @magnitude.setter
+    def magnitude(self, value):
+        self.stft_data = value * torch.exp(1j * self.phase)
+
+    def log_magnitude(self, ref_value: float = 1.0, amin: float = 1e-5, top_db: float = 80.0):
+        """10 log10(|X|^2) relative to ``ref_value`` with a floor ``top_db``
+        below the global peak (audio_signal.py:1457-1487)."""
+        mag = self.magnitude
+        amin = amin ** 2
+        log_spec = 10.0 * torch.log10(mag.pow(2).clamp(min=amin))
+        log_spec -= 10.0 * np.log10(np.maximum(amin, ref_value))
+        if top_db is not None:
+            log_spec = torch.maximum(log_spec, log_spec.max() - top_db)
+        return log_spec
+
+    @property
+    def phase(self):
+        if self.stft_data is None:
+            self.stft()
+        return torch.angle(self.stft_data)
+
+    @phase.setter
+    def phase(self, value):
+        self.stft_data = self.magnitude * torch.exp(1j * value)

@@ -1,0 +1,312 @@
+"""Host-side design of the small read-only tables the HIP kernels consume.
+
+These are one-off float64 numpy computations (cached), exactly the values the
+reference obtains from scipy / librosa / pyloudnorm / julius at
+``audio_signal.py:1030-1037`` (window), ``:1323-1331`` (mel basis),
+``loudness.py:253-260`` (weighting biquads).  Device copies are cached per
+(device, parameters) in ``_device_cache`` -- the counterpart of the
+reference's ``functools.lru_cache`` on ``get_window`` / ``get_mel_filters``.
+"""
+import functools
+import math
+
+import numpy as np
+import torch
+
+from . import _native
+
+# ------------------------------------------------------------------- windows
+
+
+@functools.lru_cache(None)
+def window_np(window_type: str, window_length: int) -> np.ndarray:
+    """``AudioSignal.get_window`` semantics (audio_signal.py:1030-1038):
+    scipy periodic windows, plus "average" and "sqrt_hann"; float32."""
+    from scipy import signal
+
+    if window_type == "average":
+        w = np.ones(window_length) / window_length
+    elif window_type == "sqrt_hann":
+        w = np.sqrt(signal.get_window("hann", window_length))
+    else:
+        w = signal.get_window(window_type, window_length)
+    return np.ascontiguousarray(w, dtype=np.float64).astype(np.float32)
+
+
+# ----------------------------------------------------------------- mel basis
+def _slaney_hz_to_mel(f):
+    f = np.atleast_1d(np.asarray(f, dtype=np.float64))
+    lin = f / (200.0 / 3.0)
+    logstep = np.log(6.4) / 27.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        log = 15.0 + np.log(np.maximum(f, 1e-300) / 1000.0) / logstep
+    return np.where(f >= 1000.0, log, lin)
+
+
+def _slaney_mel_to_hz(m):
+    m = np.atleast_1d(np.asarray(m, dtype=np.float64))
+    lin = m * (200.0 / 3.0)
+    logstep = np.log(6.4) / 27.0
+    log = 1000.0 * np.exp(logstep * (m - 15.0))
+    return np.where(m >= 15.0, log, lin)
+
+
+@functools.lru_cache(None)
+def mel_filters_np(sr: int, n_fft: int, n_mels: int, fmin: float = 0.0, fmax: float = None) -> np.ndarray:
+    """Slaney-scale, slaney-normalised triangular filterbank, float32
+    ``(n_mels, 1 + n_fft//2)`` -- what ``librosa.filters.mel(sr=, n_fft=,
+    n_mels=, fmin=, fmax=)`` returns for the reference (audio_signal.py:1325)."""
+    if fmax is None:
+        fmax = float(sr) / 2
+    n_bins = 1 + n_fft // 2
+    freqs = np.fft.rfftfreq(n=n_fft, d=1.0 / sr)
+    edges_mel = np.linspace(_slaney_hz_to_mel(fmin)[0], _slaney_hz_to_mel(fmax)[0], n_mels + 2)
+    edges = _slaney_mel_to_hz(edges_mel)
+    widths = np.diff(edges)
+    ramps = edges[:, None] - freqs[None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rising = -ramps[:-2] / widths[:-1, None]
+        falling = ramps[2:] / widths[1:, None]
+    tri = np.maximum(0.0, np.minimum(rising, falling)).astype(np.float32)
+    enorm = 2.0 / (edges[2: n_mels + 2] - edges[:n_mels])
+    # librosa multiplies the float32 triangles by the float64 norm in place
+    tri = (tri.astype(np.float64) * enorm[:, None]).astype(np.float32)
+    assert tri.shape == (n_mels, n_bins)
+    return tri
+
+
+MEL_UNIT = 16  # bins per mel work unit (matches csrc/stft.hip)
+
+
+def mel_units_np(basis: np.ndarray):
+    """Compress a banded (n_mels, F) filterbank into the unit tables of
+    ``at_stft_mel_f32``: unit u multiplies 16 consecutive bins starting at
+    ``unit_k0[u]`` with ``unit_w[u]`` for band m, ``mel_ubeg[m] <= u <
+    mel_ubeg[m+1]``.  Zero weights inside a band are kept, so any real matrix
+    is represented exactly (a dense one just costs more units)."""
+    n_mels, F = basis.shape
+    k0s, ws, ubeg = [], [], [0]
+    for m in range(n_mels):
+        nz = np.nonzero(basis[m])[0]
+        if len(nz):
+            lo, hi = int(nz[0]), int(nz[-1]) + 1
+            for k in range(lo, hi, MEL_UNIT):
+                w = np.zeros(MEL_UNIT, dtype=np.float32)
+                seg = basis[m, k: min(k + MEL_UNIT, hi)]
+                w[: len(seg)] = seg
+                k0s.append(k)
+                ws.append(w)
+        ubeg.append(len(k0s))
+    if not k0s:  # all-zero basis: one dummy unit
+        k0s, ws = [0], [np.zeros(MEL_UNIT, dtype=np.float32)]
+        ubeg = [0] + [0] * (n_mels - 1) + [0]
+    return (np.asarray(k0s, dtype=np.int32), np.stack(ws).astype(np.float32),
+            np.asarray(ubeg, dtype=np.int32))
+
+
+def dct_np(n_mfcc: int, n_mels: int, norm="ortho") -> np.ndarray:
+    """DCT-II basis (n_mels, n_mfcc) as ``torchaudio.functional.create_dct``
+    (audio_signal.py:1394)."""
+    n = np.arange(n_mels, dtype=np.float32)
+    k = np.arange(n_mfcc, dtype=np.float32)[:, None]
+    dct = np.cos(np.float32(math.pi / n_mels) * (n + np.float32(0.5)) * k).astype(np.float32)
+    if norm is None:
+        dct *= 2.0
+    else:
+        dct[0] *= np.float32(1.0 / math.sqrt(2.0))
+        dct *= np.float32(math.sqrt(2.0 / n_mels))
+    return np.ascontiguousarray(dct.T)
+
+
+# ------------------------------------------------------- weighting biquads
+def _rbj(kind, G, Q, fc, rate):
+    """RBJ cookbook biquad as pyloudnorm's IIRfilter designs it; returns
+    (b0,b1,b2,a0,a1,a2) normalised by a0."""
+    A = 10 ** (G / 40.0)
+    w0 = 2.0 * np.pi * (fc / rate)
+    al = np.sin(w0) / (2.0 * Q)
+    c = np.cos(w0)
+    rA = np.sqrt(A)
+    if kind == "high_shelf":
+        b = [A * ((A + 1) + (A - 1) * c + 2 * rA * al), -2 * A * ((A - 1) + (A + 1) * c),
+             A * ((A + 1) + (A - 1) * c - 2 * rA * al)]
+        a = [(A + 1) - (A - 1) * c + 2 * rA * al, 2 * ((A - 1) - (A + 1) * c),
+             (A + 1) - (A - 1) * c - 2 * rA * al]
+    elif kind == "high_pass":
+        b = [(1 + c) / 2, -(1 + c), (1 + c) / 2]
+        a = [1 + al, -2 * c, 1 - al]
+    elif kind == "peaking":
+        b = [1 + al * A, -2 * c, 1 - al * A]
+        a = [1 + al / A, -2 * c, 1 - al / A]
+    else:  # pragma: no cover
+        raise ValueError(kind)
+    b = np.asarray(b, dtype=np.float64) / a[0]
+    a = np.asarray(a, dtype=np.float64) / a[0]
+    return np.concatenate([b, a])
+
+
+_FILTER_CLASSES = {
+    # name -> list of (kind, G, Q, fc); order = application order (loudness.py:115)
+    "K-weighting": [("high_shelf", 4.0, 1 / np.sqrt(2), 1500.0), ("high_pass", 0.0, 0.5, 38.0)],
+    "Fenton/Lee 1": [("high_shelf", 5.0, 1 / np.sqrt(2), 1500.0), ("high_pass", 0.0, 0.5, 130.0),
+                     ("peaking", 0.0, 1 / np.sqrt(2), 500.0)],
+    "Fenton/Lee 2": [("high_shelf", 4.0, 1 / np.sqrt(2), 1500.0), ("high_pass", 0.0, 0.5, 38.0)],
+    "Dash et al.": [("high_pass", 0.0, 0.375, 149.0), ("peaking", -2.93820927, 1.68878655, 1000.0)],
+}
+
+
+@functools.lru_cache(None)
+def weighting_sos(rate: int, filter_class: str = "K-weighting"):
+    """(sos[nstage,6] float64, gains[nstage] float64) for a BS.1770 meter."""
+    if filter_class not in _FILTER_CLASSES:
+        raise ValueError("Invalid filter class:", filter_class)
+    sos = np.stack([_rbj(k, G, Q, fc, rate) for (k, G, Q, fc) in _FILTER_CLASSES[filter_class]])
+    gains = np.ones(len(sos), dtype=np.float64)
+    return sos, gains
+
+
+def lufs_warmup(sos: np.ndarray, tol: float = 1e-9, granule: int = 2048) -> int:
+    """Samples a filter segment must be started early (from zero state) so
+    the discarded transient has decayed below ``tol``: max pole radius ** n
+    < tol, rounded up to the kernel's super-block."""
+    rmax = 0.0
+    for row in sos:
+        a = np.asarray(row[3:], dtype=np.float32).astype(np.float64)
+        rmax = max(rmax, float(np.max(np.abs(np.roots(a)))))
+    if rmax <= 0.0:
+        return 0
+    if rmax >= 1.0:
+        return 1 << 30  # unstable/marginal filter: never split rows (start clamps to 0)
+    n = math.log(tol) / math.log(rmax)
+    return int(math.ceil(n / granule) * granule)
+
+
+# --------------------------------------------------------------- device cache
+_device_cache = {}
+
+
+def _dev_key(device):
+    d = torch.device(device)
+    return (d.type, d.index if d.index is not None else (torch.cuda.current_device() if d.type == "cuda" else -1))
+
+
+def device_table(key, device, builder):
+    """Cache ``builder()`` (numpy array or tuple of arrays) on ``device``."""
+    k = (key, _dev_key(device))
+    hit = _device_cache.get(k)
+    if hit is None:
+        val = builder()
+        if isinstance(val, tuple):
+            hit = tuple(torch.from_numpy(np.ascontiguousarray(v)).to(device) for v in val)
+        else:
+            hit = torch.from_numpy(np.ascontiguousarray(val)).to(device)
+        _device_cache[k] = hit
+    return hit
+
+
+def stft_twiddles(n_fft: int, device):
+    def make():
+        out = np.empty(2 * n_fft, dtype=np.float32)
+        _native.check(_native.lib().at_stft_twiddles_host(n_fft, out.ctypes.data), "at_stft_twiddles_host")
+        return out
+
+    return device_table(("stft_tw", n_fft), device, make)
+
+
+def window(window_type: str, window_length: int, device):
+    return device_table(("window", window_type, window_length), device,
+                        lambda: window_np(window_type, window_length))
+
+
+def mel_filters(sr, n_fft, n_mels, fmin, fmax, device):
+    return device_table(("mel", sr, n_fft, n_mels, fmin, fmax), device,
+                        lambda: mel_filters_np(sr, n_fft, n_mels, fmin, fmax))
+
+
+def mel_units(sr, n_fft, n_mels, fmin, fmax, device):
+    return device_table(("mel_units", sr, n_fft, n_mels, fmin, fmax), device,
+                        lambda: mel_units_np(mel_filters_np(sr, n_fft, n_mels, fmin, fmax)))
+
+
+def install_table(key, device, tensors):
+    """Install an already-on-device table (used by the multi-GPU broadcast)."""
+    _device_cache[(key, _dev_key(device))] = tensors
+
+
+# ------------------------------------------------------- sinc FIR design
+def _sinc_t(x: torch.Tensor) -> torch.Tensor:
+    one = torch.ones((), dtype=x.dtype)
+    return torch.where(x == 0, one, torch.sin(x) / x)
+
+
+def lowpass_half_size(cutoff, zeros: float) -> int:
+    """Half length of the windowed-sinc low-pass the reference builds through
+    julius (``dsp.py:178``): ``int(zeros / cutoff / 2)`` evaluated in the
+    dtype of ``cutoff`` (a float32 0-dim tensor when it comes from
+    ``low_pass``), so boundary cases round identically."""
+    return int(zeros / cutoff / 2)
+
+
+def lowpass_taps(cutoff, zeros: float, half_size: int = None) -> torch.Tensor:
+    """Float32 taps (2*half+1,) of a Hann-windowed sinc low-pass with
+    normalised cutoff ``cutoff`` (cycles/sample), unit DC gain.  ``cutoff == 0``
+    gives the all-zero filter.  Arithmetic is float32 torch, as upstream."""
+    if cutoff < 0:
+        raise ValueError("Minimum cutoff must be larger than zero.")
+    if cutoff > 0.5:
+        raise ValueError("A cutoff above 0.5 does not make sense.")
+    if half_size is None:
+        half_size = lowpass_half_size(cutoff, zeros)
+    win = torch.hann_window(2 * half_size + 1, periodic=False)
+    n = torch.arange(-half_size, half_size + 1)
+    if cutoff == 0:
+        return torch.zeros(2 * half_size + 1)
+    h = 2 * cutoff * win * _sinc_t(2 * cutoff * math.pi * n)
+    return (h / h.sum()).float()
+
+
+def htk_band_edges(sample_rate: float, n_bands: int) -> np.ndarray:
+    """Interior band edges (Hz) of the ``n_bands``-way mel split used by
+    ``equalizer`` / ``mel_filterbank`` (effects.py:400): HTK-mel-spaced
+    points between 0 and Nyquist, end points dropped."""
+    to_mel = lambda f: 2595 * np.log10(1 + f / 700)
+    to_hz = lambda m: 700 * (10 ** (m / 2595) - 1)
+    mels = np.linspace(to_mel(0.0), to_mel(sample_rate / 2), n_bands + 1)
+    return to_hz(mels)[1:-1]
+
+
+@functools.lru_cache(None)
+def band_split_bank(sample_rate: int, n_bands: int, zeros: float = 8):
+    """Low-pass bank (n_bands-1, 2*half+1) float32 + half size for the mel
+    band split; all filters share the length set by the LOWEST edge."""
+    edges = htk_band_edges(sample_rate, n_bands)
+    if len(edges) == 0:
+        return None, 0
+    cut = [c / sample_rate for c in edges]
+    half = int(zeros / min(c for c in cut if c > 0) / 2)
+    return torch.stack([lowpass_taps(c, zeros, half) for c in cut]), half
+
+
+@functools.lru_cache(None)
+def resample_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
+    """Polyphase windowed-sinc bank of the reference's resampler
+    (``audio_signal.py:732`` -> julius.resample_frac): returns
+    ``(bank[new, 2*width+old] float32, old, new, width)`` for the REDUCED
+    ratio, or ``None`` when the rates are equal."""
+    g = math.gcd(old_sr, new_sr)
+    old, new = old_sr // g, new_sr // g
+    if old == new:
+        return None
+    sr = min(new, old) * rolloff
+    width = math.ceil(zeros * old / sr)
+    idx = torch.arange(-width, width + old).float()
+    rows = []
+    for i in range(new):
+        t = (-i / new + idx / old) * sr
+        t = t.clamp_(-zeros, zeros)
+        t *= math.pi
+        win = torch.cos(t / zeros / 2) ** 2
+        k = _sinc_t(t) * win
+        k.div_(k.sum())
+        rows.append(k)
+    return torch.stack(rows), old, new, width

@@ -1,0 +1,128 @@
+"""Small host-side helpers shared by the signal object and the transforms
+(counterparts of the helpers the hot path uses from the reference's
+``audiotools/core/util.py``: ``ensure_tensor`` :56-89, ``_get_value`` :92-96,
+``random_state`` :99-126, ``seed`` :129-151, ``sample_from_dist`` :383-423,
+``collate`` :426-479, ``prepare_batch`` :346-380)."""
+import numbers
+import random
+import typing
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+
+
+def ensure_tensor(x, ndim: int = None, batch_size: int = None) -> torch.Tensor:
+    """Make ``x`` a tensor; right-pad its shape with singleton axes up to
+    ``ndim``; broadcast axis 0 to ``batch_size`` (a view, as in the reference)."""
+    t = x if torch.is_tensor(x) else torch.as_tensor(x)
+    if ndim is not None:
+        assert t.ndim <= ndim
+        if t.ndim < ndim:
+            t = t.reshape(tuple(t.shape) + (1,) * (ndim - t.ndim))
+    if batch_size is not None and t.shape[0] != batch_size:
+        t = t.expand(batch_size, *t.shape[1:])
+    return t
+
+
+def _get_value(other):
+    """Operand of AudioSignal arithmetic: another signal contributes its samples."""
+    from .signal import AudioSignal
+
+    return other.audio_data if isinstance(other, AudioSignal) else other
+
+
+def random_state(seed: typing.Union[int, np.random.RandomState, None]):
+    if seed is None or seed is np.random:
+        return np.random.mtrand._rand
+    if isinstance(seed, (numbers.Integral, np.integer, int)):
+        return np.random.RandomState(seed)
+    if isinstance(seed, np.random.RandomState):
+        return seed
+    raise ValueError("%r cannot be used to seed a numpy.random.RandomState instance" % seed)
+
+
+def seed(random_seed: int, set_cudnn: bool = False):
+    torch.manual_seed(random_seed)
+    np.random.seed(random_seed)
+    random.seed(random_seed)
+    if set_cudnn:
+        torch.backends.cudnn.deterministic = True
+        torch.backends.cudnn.benchmark = False
+
+
+@contextmanager
+def _close_temp_files(tmpfiles: list):
+    def _close():
+        for t in tmpfiles:
+            t.close()
+    try:
+        yield
+    finally:
+        _close()
+
+
+def sample_from_dist(dist_tuple: tuple, state: np.random.RandomState = None):
+    """Draw from ("const", v) | ("uniform", lo, hi) | ("normal", mu, sd) |
+    ("choice", [...]) with a seeded RandomState (transform hyper-parameters)."""
+    if dist_tuple[0] == "const":
+        return dist_tuple[1]
+    state = random_state(state)
+    fn = getattr(state, dist_tuple[0])
+    return fn(*dist_tuple[1:])
+
+
+def collate(list_of_dicts: list, n_splits: int = None):
+    """Merge per-item (possibly nested) dicts into one batched dict:
+    AudioSignals are batched with padding, tensors/arrays/scalars go through
+    torch's default collate; optionally split into ``n_splits`` chunks."""
+    from .signal import AudioSignal
+
+    def flat(d, pre=()):
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, dict) and v:
+                out.update(flat(v, pre + (k,)))
+            else:
+                out[pre + (k,)] = v
+        return out
+
+    def unflat(d):
+        out = {}
+        for ks, v in d.items():
+            cur = out
+            for k in ks[:-1]:
+                cur = cur.setdefault(k, {})
+            cur[ks[-1]] = v
+        return out
+
+    batches = []
+    list_len = len(list_of_dicts)
+    return_list = n_splits is not None
+    n_splits = 1 if n_splits is None else n_splits
+    n_items = int(np.ceil(list_len / n_splits))
+    for i in range(0, list_len, n_items):
+        items = [flat(d) for d in list_of_dicts[i: i + n_items]]
+        merged = {k: [d[k] for d in items] for k in items[0]}
+        batch = {}
+        for k, v in merged.items():
+            if isinstance(v, list):
+                if all(isinstance(s, AudioSignal) for s in v):
+                    batch[k] = AudioSignal.batch(v, pad_signals=True)
+                else:
+                    batch[k] = torch.utils.data._utils.collate.default_collate(v)
+        batches.append(unflat(batch))
+    return batches if return_list else batches[0]
+
+
+def prepare_batch(batch, device="cpu"):
+    """Move every tensor / AudioSignal of a (nested) batch to ``device``."""
+    if isinstance(batch, dict):
+        return {k: prepare_batch(v, device) for k, v in batch.items()}
+    if isinstance(batch, list):
+        return [prepare_batch(v, device) for v in batch]
+    if torch.is_tensor(batch):
+        return batch.to(device)
+    if hasattr(batch, "to") and hasattr(batch, "audio_data"):
+        return batch.to(device)
+    return batch

@@ -1,0 +1,87 @@
+/* audiotools_amd.h -- C ABI of libaudiotools_amd.so (AMD Instinct MI355X / gfx950).
+ *
+ * The reference (descriptinc/audiotools v0.7.4) is pure Python and has no FFI seam;
+ * its hot path reaches native code only through torch / julius / torchaudio calls.
+ * Each entry point below replaces ONE such call site (file:line relative to
+ * /root/reference) and is what a binding in the reference's host language (Python
+ * ctypes) would bind.
+ *
+ * Conventions
+ *  - plain pointers and sizes; device pointers unless a name ends in _host;
+ *  - the caller owns every buffer (torch allocates them in our host layer);
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *    enqueued asynchronously on it, nothing synchronises the device;
+ *  - return 0 on success, AT_ERR_INVALID (-1) for a bad argument,
+ *    AT_ERR_UNSUPPORTED (-2) when this entry point has no kernel for a valid request,
+ *    -1000-hipError_t for a HIP runtime failure.  No exceptions cross the ABI.
+ *  - row = one (batch item, channel) pair; audio is (rows, T) float32 contiguous.
+ */
+#ifndef AUDIOTOOLS_AMD_H
+#define AUDIOTOOLS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AT_OK 0
+#define AT_ERR_INVALID (-1)
+#define AT_ERR_UNSUPPORTED (-2)
+
+/* padding_type of AudioSignal.stft (torch.nn.functional.pad modes, audio_signal.py:1192) */
+#define AT_PAD_REFLECT 0
+#define AT_PAD_CONSTANT 1
+#define AT_PAD_REPLICATE 2
+#define AT_PAD_CIRCULAR 3
+
+/* ---- STFT (+ mel) -------------------------------------------------------------------
+ * Replaces  audiotools/core/audio_signal.py:1192-1202  F.pad + torch.stft(center=True,
+ *           return_complex=True) and  :1355-1368  torch.abs + (mag^T @ mel_basis^T).
+ *
+ * at_stft_twiddles_host: fills out_host[2*n_fft] with (cos, -sin)(2*pi*k/n_fft), k < n_fft
+ *   (float64 math, rounded to float32).  Upload once per n_fft and pass as `twiddles`.
+ * at_stft_native_supported: 1 if n_fft is a power of two in [32, 2048].
+ * at_stft_mel_f32:
+ *   x          (rows, T) f32
+ *   window     (n_fft) f32            AudioSignal.get_window (audio_signal.py:1009-1039)
+ *   pad, right_pad, pad_mode          match_stride outer padding (audio_signal.py:1089-1121)
+ *   frame_lo, n_frames_out            frames [frame_lo, frame_lo+n_frames_out) of the
+ *                                     1 + (T+2*pad+right_pad)/hop frames are produced
+ *                                     (match_stride drops 2 at each end, :1206-1209)
+ *   stft_out   (rows, n_frames_out, n_fft/2+1) complex64 as interleaved f32, or NULL
+ *              -- bin-contiguous, the physical layout of torch.stft's result
+ *   mel tables banded filterbank in "unit" form (see tables.mel_units_np):
+ *              mel_unit_k0[n_units] i32, mel_unit_w[n_units*16] f32, mel_ubeg[n_mels+1] i32
+ *   mel_out    (rows, n_frames_out, n_mels) f32, or NULL
+ */
+int at_stft_twiddles_host(int n_fft, float* out_host);
+int at_stft_native_supported(int n_fft);
+int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
+                    int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,
+                    float* stft_out, const int* mel_unit_k0, const float* mel_unit_w, const int* mel_ubeg,
+                    int n_units, int n_mels, float* mel_out, void* stream);
+
+/* ---- BS.1770 integrated loudness ---------------------------------------------------
+ * Replaces  audiotools/core/loudness.py:102-126  (2x torchaudio.functional.lfilter, the
+ *           CPU/IIR branch), :164-174 (julius.core.unfold), :176-247 (gated integration).
+ *   x         (B, C, T) f32, C <= 5
+ *   sos_host  nstage x 6 float64 (b0 b1 b2 a0 a1 a2), HOST memory, applied in order;
+ *             rounded to float32 inside, as loudness.py:118-119 does
+ *   gains_host nstage passband gains (float64, HOST)
+ *   K, S      block and stride in samples: int(T_g*rate), int(T_g*rate*0.25)
+ *   inv_norm  1/(T_g*rate)
+ *   floor_db  clamp of the result (LoudnessMixin.MIN_LOUDNESS = -70), NaN = no clamp
+ *   warm      samples a row segment is started early so the filter transient is gone
+ *   out       (B) f32 LUFS
+ *   workspace at_lufs_workspace_bytes(...) bytes of device scratch
+ */
+int64_t at_lufs_workspace_bytes(int64_t B, int64_t C, int64_t T, int K, int S);
+int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* sos_host, const double* gains_host,
+                int nstage, int K, int S, double inv_norm, float floor_db, int warm, float* out, void* workspace,
+                int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOTOOLS_AMD_H */

@@ -1,0 +1,90 @@
+"""Generate tests/golden/*.npz from the UNMODIFIED reference (shim-imported from
+/root/reference).  TEST INFRASTRUCTURE ONLY.  Run in the build container:
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+
+Inputs are stored next to the outputs (float16-exact values are not assumed), so the
+fixtures do not depend on torch's RNG staying stable.  Every array is produced by calling
+the reference's own public methods on CPU torch.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.ref_import import import_reference  # noqa: E402
+from tests import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    at = import_reference()
+    AudioSignal, STFTParams = at.AudioSignal, at.STFTParams
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+
+    # cfg1-shaped STFT (B reduced to 2 to keep the fixture small): 1 s mono @16 kHz, 512/128 hann
+    x = synth.audio_batch(2, 1, 16000, seed=101, gaps=False)
+    s = AudioSignal(x.clone(), 16000)
+    X = s.stft(512, 128, "hann")
+    y = s.clone().istft(512, 128, "hann").audio_data
+    Xm = AudioSignal(x.clone(), 16000).stft(512, 128, "sqrt_hann", match_stride=True)
+    np.savez_compressed(os.path.join(OUT, "stft_cfg1.npz"), x=x.numpy(), stft=X.numpy(), istft=y.numpy(),
+                        stft_match_stride_sqrt_hann=Xm.numpy())
+
+    # cfg2-shaped STFT + mel (B=1, 2 ch, 0.5 s @44.1 kHz, default params 2048/512 hann, 80 mels)
+    x = synth.audio_batch(1, 2, 22050, seed=102, gaps=False)
+    s = AudioSignal(x.clone(), 44100)
+    mel = s.mel_spectrogram(80)
+    mfcc = AudioSignal(x.clone(), 44100).mfcc()
+    np.savez_compressed(os.path.join(OUT, "mel_cfg2.npz"), x=x.numpy(), stft=s.stft_data.numpy(),
+                        mel=mel.numpy(), mfcc=mfcc.numpy(),
+                        mel_basis=AudioSignal.get_mel_filters(44100, 2048, 80, 0.0, None))
+
+    # loudness: the reference's seeded batch (tests/core/test_loudness.py:31-52) + level/gap batch
+    np.random.seed(0)
+    arr = np.random.randn(16, 2, 16000).astype(np.float32)
+    l16 = AudioSignal(torch.from_numpy(arr.copy()), 16000).loudness()
+    xg = synth.audio_batch(4, 2, 4 * 16000, seed=103, sample_rate=16000)
+    xg[1] = 0.0                                   # digital silence -> -70 clamp
+    xg[2, :, : 16000 * 3] *= 1e-4                 # mostly below the absolute gate
+    # store the float16-rounded input and the loudness of exactly that input
+    xg16 = torch.from_numpy(xg.numpy().astype(np.float16).astype(np.float32))
+    lg = AudioSignal(xg16.clone(), 16000).loudness()
+    sine = synth.sine(1000, 44100, 20.0, amp=0.99924)
+    ls = AudioSignal(sine.clone(), 44100).loudness()
+    fl = {fc: AudioSignal(xg16[:2, :, : 2 * 16000].clone(), 16000).loudness(filter_class=fc).numpy()
+          for fc in ("Fenton/Lee 1", "Dash et al.")}
+    np.savez_compressed(os.path.join(OUT, "loudness.npz"), seeded_randn_16k=l16.numpy(),
+                        gaps_x=xg.numpy().astype(np.float16), gaps_lufs=lg.numpy(), sine_1000_lufs=ls.numpy(),
+                        fenton_lee_1=fl["Fenton/Lee 1"], dash=fl["Dash et al."])
+
+    # filters / resample / equalizer / convolve on a short stereo clip @48 kHz (cfg4 family)
+    x = synth.audio_batch(3, 1, 24000, seed=104, gaps=False, sample_rate=48000)
+    cut = torch.tensor([4000.0, 8000.0, 16000.0])
+    lp = AudioSignal(x.clone(), 48000).low_pass(cut).audio_data
+    hp = AudioSignal(x.clone(), 48000).high_pass(torch.tensor([500.0, 1000.0, 2000.0])).audio_data
+    db = -torch.rand(3, 6, generator=torch.Generator().manual_seed(9))
+    eq = AudioSignal(x.clone(), 48000).equalizer(db).audio_data
+    g = torch.Generator().manual_seed(10)
+    ir = torch.randn(3, 1, 9600, generator=g) * torch.exp(-torch.arange(9600) / (0.05 * 48000))
+    cv = AudioSignal(x.clone(), 48000).convolve(AudioSignal(ir.clone(), 48000)).audio_data
+    rs = AudioSignal(x.clone(), 48000).resample(16000).audio_data
+    xr = synth.audio_batch(2, 2, 22050, seed=105, gaps=False)
+    rs2 = AudioSignal(xr.clone(), 44100).resample(16000).audio_data
+    np.savez_compressed(os.path.join(OUT, "effects_cfg4.npz"), x=x.numpy(), lp_cut=cut.numpy(), low_pass=lp.numpy(),
+                        high_pass=hp.numpy(), eq_db=db.numpy(), equalizer=eq.numpy(), ir=ir.numpy(),
+                        convolve=cv.numpy(), resample_48k_16k=rs.numpy(), xr=xr.numpy(),
+                        resample_441_16k=rs2.numpy())
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+"""The C-ABI shared library builds for gfx950, loads, and exports every symbol that
+include/audiotools_amd.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from audiotools_amd import _native
+
+    _native.build()
+    return _native.lib()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "audiotools_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(at_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    syms = _declared_symbols()
+    assert len(syms) >= 5
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/audiotools_amd.h but not exported"
+
+
+def test_python_signatures_cover_header(lib):
+    from audiotools_amd import _native
+
+    assert sorted(_native.SIGNATURES) == _declared_symbols()
+
+
+def test_host_only_entry_points(lib):
+    out = np.empty(2 * 16, dtype=np.float32)
+    assert lib.at_stft_twiddles_host(16, out.ctypes.data) == 0
+    k = np.arange(16)
+    assert np.allclose(out[0::2], np.cos(2 * np.pi * k / 16), atol=1e-7)
+    assert np.allclose(out[1::2], -np.sin(2 * np.pi * k / 16), atol=1e-7)
+    assert lib.at_stft_native_supported(2048) == 1
+    assert lib.at_stft_native_supported(4096) == 0
+    assert lib.at_stft_native_supported(150) == 0
+    assert lib.at_lufs_workspace_bytes(512, 2, 441000, 17640, 4410) >= 512 * 2 * 100 * 8
+
+
+def test_argument_validation_without_gpu(lib):
+    # NULL pointers / bad sizes are rejected before any HIP call
+    assert lib.at_stft_mel_f32(None, 1, 100, None, None, 512, 128, 0, 0, 0, 0, 1, None, None, None, None, 0, 0,
+                               None, None) == -1
+    assert lib.at_lufs_f32(None, 1, 1, 100, None, None, 2, 400, 100, 1.0, 0.0, 0, None, None, 0, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from audiotools_amd import _native
+
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeError):
+        _native.lib()

@@ -1,0 +1,106 @@
+"""Host-side logic of the drop-in API on CPU tensors (torch path): container semantics,
+table design against the oracle leaves, cache invalidation rules."""
+import numpy as np
+import pytest
+import torch
+
+import audiotools_amd as A
+from audiotools_amd import tables
+from oracle import restate
+from oracle.leaves import julius_leaf, misc_leaves, pyloudnorm_leaf
+from tests import synth
+
+
+def test_tables_match_leaves():
+    for sr, n_fft, nm in [(44100, 2048, 80), (16000, 512, 40), (48000, 1024, 128)]:
+        assert np.array_equal(tables.mel_filters_np(sr, n_fft, nm), misc_leaves.librosa_mel(sr=sr, n_fft=n_fft, n_mels=nm))
+    assert np.array_equal(tables.mel_filters_np(22050, 1024, 64, 50.0, 8000.0),
+                          misc_leaves.librosa_mel(sr=22050, n_fft=1024, n_mels=64, fmin=50.0, fmax=8000.0))
+    for fc in ("K-weighting", "Fenton/Lee 1", "Dash et al."):
+        sos, g = tables.weighting_sos(48000, fc)
+        ref = pyloudnorm_leaf.Meter(48000, fc)._filters
+        for row, f in zip(sos, ref.values()):
+            assert np.allclose(row[:3], f.b, rtol=0, atol=1e-15) and np.allclose(row[3:], f.a, rtol=0, atol=1e-15)
+    # ITU-R BS.1770 48 kHz table (4-digit agreement, the known pyloudnorm-vs-ITU gap)
+    sos, _ = tables.weighting_sos(48000)
+    assert np.allclose(sos[0], [1.53512486, -2.69169619, 1.19839281, 1.0, -1.69065929, 0.73248077], atol=2e-4)
+    assert np.allclose(sos[1][3:], [1.0, -1.99004745, 0.99007225], atol=2e-4)
+    for c in (4000 / 48000, 0.25, 50 / 44100):
+        ct = torch.tensor(c, dtype=torch.float32)
+        ours = tables.lowpass_taps(ct, 51)
+        ref = julius_leaf.LowPassFilters([ct], zeros=51).filters[0, 0]
+        assert torch.equal(ours, ref)
+    bank, old, new, width = tables.resample_bank(44100, 16000)
+    assert (old, new, width) == (441, 160, 70) and bank.shape == (160, 581)
+    assert torch.equal(bank, julius_leaf.ResampleFrac(44100, 16000).kernel[:, 0])
+    assert np.allclose(tables.dct_np(40, 80), misc_leaves.create_dct(40, 80, "ortho").numpy(), atol=2e-7)
+    assert np.array_equal(tables.window_np("sqrt_hann", 512), restate.get_window("sqrt_hann", 512).numpy())
+
+
+def test_mel_units_reconstruct_basis():
+    basis = tables.mel_filters_np(44100, 2048, 80)
+    k0, w, ub = tables.mel_units_np(basis)
+    rec = np.zeros_like(basis)
+    for m in range(80):
+        for u in range(ub[m], ub[m + 1]):
+            hi = min(k0[u] + 16, basis.shape[1])
+            rec[m, k0[u]:hi] += w[u][: hi - k0[u]]
+    assert np.array_equal(rec, basis)
+    assert len(k0) < 400
+
+
+def test_cpu_path_matches_oracle():
+    x = synth.audio_batch(3, 2, 22050, seed=3, gaps=False)
+    s = A.AudioSignal(x.clone(), 44100)
+    assert torch.equal(s.stft(), restate.stft(x, 2048, 512))
+    assert torch.equal(s.mel_spectrogram(80), restate.mel_spectrogram(restate.stft(x, 2048, 512), 44100, 80))
+    assert torch.allclose(s.loudness(), restate.loudness(x, 44100), atol=1e-4)
+    assert torch.allclose(s.clone().istft().audio_data, x, atol=1e-6)
+    cut = torch.tensor([4000.0, 8000.0, 1000.0])
+    assert torch.allclose(s.clone().low_pass(cut).audio_data, restate.low_pass(x, cut, 44100), atol=1e-6)
+    assert torch.allclose(s.clone().high_pass(cut).audio_data, restate.high_pass(x, cut, 44100), atol=1e-6)
+    db = -torch.rand(3, 6)
+    assert torch.allclose(s.clone().equalizer(db).audio_data, restate.equalizer(x, 44100, db), atol=1e-6)
+    assert torch.equal(s.clone().resample(16000).audio_data, restate.resample(x, 44100, 16000))
+    ir = torch.randn(3, 1, 4000) * torch.exp(-torch.arange(4000) / 500.0)
+    got = s.clone().convolve(A.AudioSignal(ir.clone(), 44100)).audio_data
+    assert torch.allclose(got, restate.convolve(x, ir), atol=1e-5)
+
+
+def test_container_semantics():
+    x = synth.audio_batch(4, 1, 16000, seed=4, gaps=False)
+    s = A.AudioSignal(x.clone(), 16000)
+    assert s.stft_params == A.STFTParams(512, 128, "hann", False, "reflect")
+    s.stft()
+    assert s.stft_data is not None
+    s.loudness()
+    assert s._loudness is not None
+    s.audio_data = s.audio_data * 0.5            # setter drops the cached loudness
+    assert s._loudness is None
+    s.stft_params = A.STFTParams(256, 64)        # setter drops stft_data
+    assert s.stft_data is None and s.stft_params.window_type == "hann"
+    s.stft()
+    s.low_pass(2000)                             # low_pass drops stft_data
+    assert s.stft_data is None
+    s.resample(8000)                             # resample keeps stft_params (bug-compatible)
+    assert s.sample_rate == 8000 and s.stft_params.window_length == 256 and s.signal_length == 8000
+    with pytest.raises(RuntimeError):
+        A.AudioSignal(x.clone(), 16000).istft()
+    with pytest.raises(AssertionError):
+        A.AudioSignal(x.clone())
+    with pytest.raises(ValueError):
+        A.AudioSignal(3.0, 16000)
+    with pytest.raises(AssertionError):
+        A.AudioSignal(x.clone(), 16000).stft(512, 100, match_stride=True)
+    sub = A.AudioSignal(x.clone(), 16000)[1:3]
+    assert sub.batch_size == 2
+    b = A.AudioSignal.batch([A.AudioSignal(x[i: i + 1, :, : 16000 - 100 * i].clone(), 16000) for i in range(3)],
+                            pad_signals=True)
+    assert b.shape == (3, 1, 16000)
+    with pytest.raises(RuntimeError):
+        A.AudioSignal.batch([A.AudioSignal(x[:1].clone(), 16000), A.AudioSignal(x[:1].clone(), 8000)])
+    m = torch.tensor([True, False, True, False])
+    t = A.AudioSignal(x.clone(), 16000)
+    t[m] = t[m] * 0.0
+    assert t.audio_data[0].abs().max() == 0 and t.audio_data[1].abs().max() > 0
+    assert (A.AudioSignal(x.clone(), 16000) * 2 - A.AudioSignal(x.clone(), 16000)) == A.AudioSignal(x.clone(), 16000)
