@@ -28,8 +28,8 @@ class NativeError(RuntimeError):
 def hipcc_command(out=LIB_PATH):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
-    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-            "-o", out] + srcs
+    extra = os.environ.get("AT_HIPCC_FLAGS", "").split()
+    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", out] + srcs
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -54,8 +54,9 @@ _i64, _i32, _p, _f32, _f64 = (ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
 SIGNATURES = {
     "at_stft_twiddles_host": (_i32, [_i32, _p]),
     "at_stft_native_supported": (_i32, [_i32]),
+    "at_mel_units_host": (_i32, [_p, _i32, _i32, _p, _p]),
     "at_stft_mel_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
-                               _i32, _i64, _p, _p, _p, _p, _i32, _i32, _p, _p]),
+                               _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
     "at_lufs_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32]),
     "at_lufs_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _i32, _i32, _i32, _f64, _f32,
                            _i32, _p, _p, _i64, _p]),

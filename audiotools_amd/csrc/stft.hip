@@ -26,6 +26,24 @@
 //    applied as "units" of 16 bins x 1 band from an LDS copy of |X| instead of a
 //    dense (F x n_mels) GEMM: 2 flop/bin instead of 2*n_mels flop/bin.
 #include "at_common.h"
+#include <stdlib.h>
+
+// build-time tuning knobs (see DESIGN.md "STFT kernel tuning")
+#ifndef AT_STFT_NW
+#define AT_STFT_NW 4            // waves per workgroup
+#endif
+#ifndef AT_STFT_WPS
+#define AT_STFT_WPS 2           // resident waves per SIMD the register budget allows
+#endif
+#ifndef AT_STFT_DEBUGMODES
+#define AT_STFT_DEBUGMODES 0     // 1: honour AT_STFT_DEBUG=1 (no stores) / 2 (store only) at run time
+#endif
+#ifndef AT_STFT_STAGGER
+#define AT_STFT_STAGGER 0       // start-up stagger per wave slot, in units of 64 cycles (0 = off)
+#endif
+#ifndef AT_STFT_RUN
+#define AT_STFT_RUN 16          // consecutive frame groups a wave handles before jumping ahead
+#endif
 
 namespace {
 
@@ -146,6 +164,15 @@ constexpr int WAVE_LDS_SLOTS = 1088;  // 64*16*(17/16) complex = 8704 B, same fo
 
 __device__ __forceinline__ int phys(int i) { return i + (i >> 4); }
 
+// |z| with the hardware v_sqrt_f32 (1 ulp): the IEEE sqrtf() expansion costs ~10x more VALU
+__device__ __forceinline__ float cabs_fast(float2 z) { return __builtin_amdgcn_sqrtf(fmaf(z.x, z.x, z.y * z.y)); }
+
+// value of lane (i + n) inside the 16-lane DPP row; 0 past the end of the row
+template <int n>
+__device__ __forceinline__ float dpp_row_shl(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 | n, 0xf, 0xf, true));
+}
+
 // One Stockham pass on the thread's 16 points: butterflies b use a[b + r*NB].
 // Writes results to LDS in autosort order.
 template <int R, int NS, int L>
@@ -181,138 +208,211 @@ struct StftArgs {
   const float2* tw;        // (n_fft): (cos, -sin)(2 pi k / n_fft)
   float2* out;             // (rows, n_out, M+1) or null
   float* mel;              // (rows, n_out, n_mels) or null
-  const int* unit_k0;      // (n_units)
-  const float* unit_w;     // (n_units, 16)
-  const int* mel_ubeg;     // (n_mels + 1)
+  const int* unit_info;    // (n_units_padded, 2): {row16 | mel << 16, shuffle mask}; see below
+  const float* unit_w;     // (n_units_padded, 16)
   int64_t T;
   int64_t rows;
   int64_t n_out;           // frames written per row
+  int64_t T2;              // T + 2*pad + right_pad
   int frame_lo;            // first frame computed (2 when match_stride drops edges)
   int hop;
   int pad;                 // outer left pad (match_stride)
-  int64_t T2;              // T + 2*pad + right_pad
   int pad_mode;
-  int chunk;               // frames per wave chunk (multiple of FW)
-  int chunks_per_row;
-  int n_units;
+  int groups_per_row;      // ceil(n_out / FW)
+  int64_t total_groups;    // rows * groups_per_row
+  int n_units;             // padded to a multiple of 64
   int n_mels;
-  int vec2;                // 1: float2 input loads are 8-byte aligned
+  int reuse_shift;         // hop / (2 L) when consecutive frames of a wave can reuse registers, else 0
+  int debug;               // development: 1 = compute but never store, 2 = store only (no FFT)
 };
 
 // sample fetch with centre reflect padding (torch.stft center=True) applied on
 // top of the outer padding (F.pad(audio, (pad, pad+right_pad), mode)).
-__device__ __forceinline__ float fetch_padded(const float* __restrict__ xr, int64_t s, const StftArgs& A) {
+__device__ __forceinline__ float fetch_padded(const float* __restrict__ xr, int64_t s, int64_t T, int64_t T2, int pad,
+                                              int pad_mode) {
   // s: index into the outer-padded signal of length T2, may be out of range
   int64_t u = s;
   if (u < 0) u = -u;
-  if (u >= A.T2) u = 2 * (A.T2 - 1) - u;
+  if (u >= T2) u = 2 * (T2 - 1) - u;
   if (u < 0) u = 0;
-  int64_t v = at::pad_index(u - A.pad, A.T, A.pad_mode);
+  int64_t v = at::pad_index(u - pad, T, pad_mode);
   return v < 0 ? 0.0f : xr[v];
 }
 
-template <int M, bool WRITE_STFT, bool MEL>
-__global__ __launch_bounds__(256) void stft_mel_kernel(const StftArgs A) {
+// ---- mel "unit" tables (built by at_mel_units_host) --------------------------------------
+// The Slaney filterbank is banded: band m is non-zero on a short run of bins.  Bins are cut
+// into rows of 16 (row r = bins 16r..16r+15); a UNIT is one (row, band) pair with its 16
+// weights.  Units are sorted by band, padded so that no band straddles a 64-lane round, and
+// every lane of a round owns one unit:   acc = sum_i w[i] * |X|[16 row + i]   (4+4 ds_read_b128)
+// The units of a band sit in adjacent lanes; they are summed with 3 shuffle-down steps whose
+// participation bits come from the table, and the first lane of each band stores the result.
+//   unit_info[2u]   = row16 | (mel << 16)       (mel = 0xffff for padding units)
+//   unit_info[2u+1] = bit0..2: add lane+1 / +2 / +4 ;  bit3: this lane stores band `mel`
+constexpr int MAG_ROW = 20;   // floats per padded LDS row of 16 magnitudes (80 B: conflict-free b128)
+constexpr int MELW_ROW = 20;  // floats per padded LDS row of 16 unit weights
+
+// LDS layout of one block (floats):
+//   [NW wave slabs: NW * 2 * WAVE_LDS_SLOTS][window: 2M][split twiddles: M (= M/2 float2)]
+//   [pass-2 twiddles: 16 rows (j mod 16) x 36 floats (16 float2 + pad, conflict-free b128 rows)]
+//   [mel unit weights: n_units x MELW_ROW]
+template <int M>
+__host__ __device__ constexpr int lds_fixed_floats(int nw) { return nw * 2 * WAVE_LDS_SLOTS + 2 * M + M + 16 * 36; }
+
+template <int M, int NW, bool VEC2, int NR /* mel rounds of 64 units; 0 = no mel */>
+__global__ __launch_bounds__(NW * 64) void stft_mel_kernel(const StftArgs A) {
+  constexpr bool MEL = NR > 0;
+  constexpr bool WRITE_STFT = true;
   using P = Plan<M>;
   constexpr int L = P::L, FW = P::FW, N = 2 * M;
-  __shared__ float2 lds[4 * WAVE_LDS_SLOTS];
+  constexpr int MAG_ROWS = M / 16 + 1;            // rows of 16 bins per frame (last row: Nyquist only)
+  // FW == 1: one frame per wave, every scheduled frame exists -> stores are unconditional
+  // straight-line code (the waitcnt pass can then count them behind the prefetched loads).
+#if AT_STFT_DEBUGMODES
+#define STORE_OK(v) (live && !(A.debug == 1 && (v) != 12345.678f))
+#else
+#define STORE_OK(v) (FW == 1 || live)
+#endif
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  float* s_win = lds_f + NW * 2 * WAVE_LDS_SLOTS;
+  float2* s_twp = reinterpret_cast<float2*>(s_win + N);
+  float* s_tw2 = s_win + N + M;
+  float* s_melw = s_tw2 + 16 * 36;
+
+  // ---- block-shared tables -> LDS (once per persistent block)
+  for (int i = threadIdx.x; i < N; i += NW * 64) s_win[i] = A.window[i];
+  for (int i = threadIdx.x; i < M / 2; i += NW * 64) s_twp[i] = A.tw[i];
+  if constexpr (P::R2 > 1) {
+    // row = j mod 16, column r: exp(-2 pi i r (j mod 16) / (16 R2))
+    for (int i = threadIdx.x; i < 16 * P::R2; i += NW * 64) {
+      const int jj = i / P::R2, r = i % P::R2;
+      reinterpret_cast<float2*>(s_tw2 + jj * 36)[r] = A.tw[r * jj * (N / (16 * P::R2))];
+    }
+  }
+  if constexpr (MEL) {
+    for (int i = threadIdx.x; i < A.n_units * 16; i += NW * 64)
+      s_melw[(i >> 4) * MELW_ROW + (i & 15)] = A.unit_w[i];
+  }
+  __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t row = wid / A.chunks_per_row;
-  if (row >= A.rows) return;  // whole wave exits together
-  const int chunk_id = (int)(wid % A.chunks_per_row);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fs = lane / L;  // frame slot inside the wave
   const int t = lane % L;   // thread inside the frame
 
-  float2* wbuf = lds + wave * WAVE_LDS_SLOTS;
+  float2* wbuf = reinterpret_cast<float2*>(lds_f) + wave * WAVE_LDS_SLOTS;
   float2* fbuf = wbuf + fs * P::SLOTS;
 
-  // ---- per-thread constants: window, pass twiddles, split twiddles
-  float2 win[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int n = t + L * q;
-    win[q] = make_float2(A.window[2 * n], A.window[2 * n + 1]);
-  }
+  // ---- per-thread constants
   constexpr int NB2 = 16 / P::R2;
   constexpr int NB3 = 16 / P::R3;
-  float2 tw2[P::R2 > 1 ? NB2 * P::R2 : 1];
-  float2 tw3[P::R3 > 1 ? NB3 * P::R3 : 1];
-  if constexpr (P::R2 > 1) {
-    constexpr int NS = 16;
-#pragma unroll
-    for (int b = 0; b < NB2; ++b) {
-      const int j = t + b * L;
-#pragma unroll
-      for (int r = 1; r < P::R2; ++r) tw2[b * P::R2 + r] = A.tw[r * (j % NS) * (N / (NS * P::R2))];
-    }
-  }
+  float2 tw3b[P::R3 > 1 ? NB3 : 1];  // base twiddle w^1 per butterfly of pass 3; w^2, w^3.. derived
   if constexpr (P::R3 > 1) {
     constexpr int NS = 16 * P::R2;
 #pragma unroll
     for (int b = 0; b < NB3; ++b) {
       const int j = t + b * L;
-#pragma unroll
-      for (int r = 1; r < P::R3; ++r) tw3[b * P::R3 + r] = A.tw[r * (j % NS) * (N / (NS * P::R3))];
+      tw3b[b] = A.tw[(j % NS) * (N / (NS * P::R3))];
     }
   }
-  float2 twp[8];
+  // mel: this lane's unit of every round (row of 16 bins, band, reduction masks as 0/1 floats)
+  constexpr int NRR = MEL ? NR : 1;
+  int u_row[NRR], u_mel[NRR], u_fl[NRR];
+  if constexpr (MEL) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) twp[q] = A.tw[t + L * q];  // (cos, -sin)(2 pi k/N), k = t + L q
-
-  const float* __restrict__ xr = A.x + row * A.T;
-  const int f_begin = chunk_id * A.chunk;                       // relative to frame_lo
-  const int f_end = min((int64_t)f_begin + A.chunk, A.n_out);
-
-  for (int f0 = f_begin; f0 < f_end; f0 += FW) {
-    const int fo = f0 + fs;  // output frame index of this thread's frame
-    const bool live = fo < f_end;
-    const int64_t frame = (int64_t)fo + A.frame_lo;
-    // first sample of the frame in outer-padded coordinates
-    const int64_t s0 = frame * A.hop - M;  // M = n_fft/2 centre pad
-    float2 a[16];
-    if (live) {
-      const bool interior = (A.pad == 0) && (s0 >= 0) && (s0 + N <= A.T);
-      if (interior) {
-        if (A.vec2) {
-          const float2* __restrict__ p = reinterpret_cast<const float2*>(xr + s0);
-#pragma unroll
-          for (int q = 0; q < 16; ++q) a[q] = p[t + L * q];
-        } else {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int n = t + L * q;
-            a[q] = make_float2(xr[s0 + 2 * n], xr[s0 + 2 * n + 1]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int n = t + L * q;
-          a[q] = make_float2(fetch_padded(xr, s0 + 2 * n, A), fetch_padded(xr, s0 + 2 * n + 1, A));
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) a[q] = make_float2(a[q].x * win[q].x, a[q].y * win[q].y);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) a[q] = make_float2(0.f, 0.f);
+    for (int r = 0; r < NR; ++r) {
+      const int info = A.unit_info[2 * (r * 64 + lane)];
+      u_fl[r] = A.unit_info[2 * (r * 64 + lane) + 1];
+      u_row[r] = (info & 0xffff) * MAG_ROW;
+      u_mel[r] = (u_fl[r] & 16) ? ((info >> 16) & 0xffff) : -1;   // -1: this lane stores nothing
     }
+  }
 
+  const int Ti = (int)A.T;
+  const int n_out = (int)A.n_out;
+  const int gpr = A.groups_per_row;
+  // Persistent schedule.  Workgroup b runs on XCD b % 8 (observed placement; used for speed
+  // only).  The (row, frame-group) space is cut into one CONTIGUOUS span per XCD and the waves
+  // of an XCD interleave inside their span: the 4x overlap between neighbouring frames is then
+  // served by that XCD's own L2 (HBM reads each sample once), and each XCD writes one compact
+  // moving window of the output.
+  const int n_x = gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int xcd = blockIdx.x % n_x;
+  const int lblk = blockIdx.x / n_x;
+  const int nblk_x = ((int)gridDim.x - xcd + n_x - 1) / n_x;       // blocks on this XCD
+  const int64_t g_lo = A.total_groups * xcd / n_x;
+  const int64_t g_hi = A.total_groups * (xcd + 1) / n_x;
+  constexpr int RUN = AT_STFT_RUN;
+  const int64_t Wtot = (int64_t)nblk_x * NW;                        // waves working on this span
+  const int64_t w0 = g_lo + ((int64_t)lblk * NW + wave) * RUN;      // first group of this wave
+
+  // De-phase the persistent waves: they all start together and execute identical work, so
+  // without a stagger the whole chip alternates between "everyone transforms" and "everyone
+  // stores" and the memory system idles half of the time.  Eight slots per CU (2 blocks x 4
+  // waves) spread over roughly one frame time.
+  if constexpr (AT_STFT_STAGGER > 0) {
+    const int slot = (wave + NW * (lblk & 1)) & 7;
+    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(AT_STFT_STAGGER);
+  }
+  constexpr int SH = 4;    // register shift between consecutive frames (hop = n_fft / 4)
+  const bool can_reuse = (FW == 1) && A.reuse_shift == SH;
+  float2 raw[16];          // un-windowed samples of the frame being processed (register reuse)
+  float2 nxt[SH];          // the SH new loads of the NEXT frame, issued ahead of this frame's stores
+
+  // ---- one frame group: window, FFT, split, stores (+ mel).  `a` holds the raw samples.
+  // Returns true when the loads of the next consecutive frame were issued into nxt[].
+  auto frame_body = [&](float2 (&a)[16], const float* __restrict__ xr, int64_t row, int gb, int64_t s0,
+                        bool want_next) __attribute__((always_inline)) -> bool {
+    const int fo = gb * FW + fs;       // output frame index of this thread's frame
+    const bool live = fo < n_out;
+    if (can_reuse) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) raw[q] = a[q];
+    }
+    {
+      const float2* w2 = reinterpret_cast<const float2*>(s_win);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float2 w = w2[t + L * q];
+        a[q] = make_float2(a[q].x * w.x, a[q].y * w.y);
+      }
+    }
+    float2* __restrict__ orow = A.out + ((int64_t)row * n_out + fo) * (M + 1);
+    bool have_nxt = false;
+
+    if (AT_STFT_DEBUGMODES && A.debug == 2) {  // store-only experiment: same addresses, no transform
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { orow[t + L * q] = a[q]; orow[M - (t + L * q)] = a[q + 8]; }
+        if (t == 0) orow[M / 2] = a[0];
+      }
+      return false;
+    }
     // ---- complex FFT of length M (Stockham, radix 16 / R2 / R3)
     pass_compute_store<16, 1, L>(a, fbuf, t, nullptr);
     wave_sync();
     if constexpr (P::R2 > 1) {
       load_points<L>(a, fbuf, t);
       wave_sync();
+      float2 tw2[NB2 * P::R2];
+#pragma unroll
+      for (int b = 0; b < NB2; ++b) {
+        const float2* rowp = reinterpret_cast<const float2*>(s_tw2 + ((t + b * L) & 15) * 36);
+#pragma unroll
+        for (int r = 1; r < P::R2; ++r) tw2[b * P::R2 + r] = rowp[r];
+      }
       pass_compute_store<P::R2, 16, L>(a, fbuf, t, tw2);
       wave_sync();
     }
     if constexpr (P::R3 > 1) {
       load_points<L>(a, fbuf, t);
       wave_sync();
+      float2 tw3[NB3 * P::R3];
+#pragma unroll
+      for (int b = 0; b < NB3; ++b) {
+        tw3[b * P::R3 + 1] = tw3b[b];
+#pragma unroll
+        for (int r = 2; r < P::R3; ++r) tw3[b * P::R3 + r] = cmul(tw3[b * P::R3 + r - 1], tw3b[b]);
+      }
       pass_compute_store<P::R3, 16 * P::R2, L>(a, fbuf, t, tw3);
       wave_sync();
     }
@@ -329,101 +429,227 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const StftArgs A) {
     if (t == 0) zh = fbuf[phys(M / 2)];
     wave_sync();  // all reads of Z done before the slab is reused for |X|
 
-    float* magbuf = reinterpret_cast<float*>(wbuf) + fs * (M + 1);
-    float2* __restrict__ orow = nullptr;
-    if constexpr (WRITE_STFT) orow = A.out + ((int64_t)row * A.n_out + fo) * (M + 1);
+    // Issue the next frame's new loads BEFORE this frame's stores: vmcnt retires in order, so a
+    // wait for loads issued after the stores would also wait for every store acknowledgement.
+    if (can_reuse && want_next && gb + 1 < gpr) {
+      const int64_t s0n = s0 + A.hop;
+      if (A.pad == 0 && s0n >= 0 && s0n + N <= Ti) {  // wave-uniform (FW == 1)
+        have_nxt = true;
+        if constexpr (VEC2) {
+          const float2* __restrict__ p = reinterpret_cast<const float2*>(xr + s0n);
+#pragma unroll
+          for (int q = 0; q < SH; ++q) nxt[q] = p[t + L * (16 - SH + q)];
+        } else {
+          const float* __restrict__ p = xr + s0n;
+#pragma unroll
+          for (int q = 0; q < SH; ++q)
+            nxt[q] = make_float2(p[2 * (t + L * (16 - SH + q))], p[2 * (t + L * (16 - SH + q)) + 1]);
+        }
+      }
+    }
+
+    // |X| of frame slot fs: rows of 16 bins padded to MAG_ROW floats
+    float* magbuf = reinterpret_cast<float*>(wbuf) + fs * (MAG_ROWS * MAG_ROW);
+    // Lane t computes the pair X[k], X[M-k] for k = t + L q.  X[k] is stored directly
+    // (addresses ascend with the lane).  The partner X[M-k] DEscends with the lane, and a
+    // store instruction whose lanes write descending addresses is ~10 % slower on this memory
+    // system (tools/micro/wrbench), so the partners are reversed across the L lanes of the frame
+    // (one ds_bpermute per component): lane t then holds bin (M - L q - L + 1) + t, ascending.
+    const int rev_lane = (lane - t) + (L - 1 - t);
+    float2 xbs[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = t + L * q;
       float2 xa, xb;
-      int kb;
-      if (q == 0 && t == 0) {  // k == 0: DC and Nyquist
+      if (q == 0 && t == 0) {  // k == 0: DC (here) and Nyquist (kept as this lane's partner)
         xa = make_float2(zk[0].x + zk[0].y, 0.f);
         xb = make_float2(zk[0].x - zk[0].y, 0.f);
-        kb = M;
       } else {
+        const float2 twp = s_twp[k];  // (cos, -sin)(2 pi k / N)
         const float sr = zk[q].x + zm[q].x, si = zk[q].y - zm[q].y;
         const float dr = zk[q].x - zm[q].x, di = zk[q].y + zm[q].y;
-        const float c = twp[q].x, s = -twp[q].y;
+        const float c = twp.x, s = -twp.y;
         const float pp = fmaf(s, dr, -c * di);
         const float qq = fmaf(s, di, c * dr);
         xa = make_float2(0.5f * (sr - pp), 0.5f * (si - qq));
         xb = make_float2(0.5f * (sr + pp), 0.5f * (-si - qq));
-        kb = M - k;
       }
-      if constexpr (WRITE_STFT) {
-        if (live) {
-          orow[k] = xa;
-          orow[kb] = xb;
-        }
-      }
-      if constexpr (MEL) {
-        magbuf[k] = sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
-        magbuf[kb] = sqrtf(fmaf(xb.x, xb.x, xb.y * xb.y));
-      }
+      if (STORE_OK(xa.x)) orow[k] = xa;
+      if constexpr (MEL) magbuf[k + 4 * (k >> 4)] = cabs_fast(xa);
+      xbs[q] = make_float2(__shfl(xb.x, rev_lane, 64), __shfl(xb.y, rev_lane, 64));
+    }
+    // ascending partner segments: q = 7 .. 0
+#pragma unroll
+    for (int q = 7; q >= 0; --q) {
+      const int kb = (M - L * q - L + 1) + t;   // lane L-1 of q == 0 holds the Nyquist bin M
+      if (STORE_OK(xbs[q].x)) orow[kb] = xbs[q];
+      if constexpr (MEL) magbuf[kb + 4 * (kb >> 4)] = cabs_fast(xbs[q]);
     }
     if (t == 0) {  // k == M/2: X = conj(Z[M/2])
       const float2 xh = make_float2(zh.x, -zh.y);
-      if constexpr (WRITE_STFT) {
-        if (live) orow[M / 2] = xh;
-      }
-      if constexpr (MEL) magbuf[M / 2] = sqrtf(fmaf(xh.x, xh.x, xh.y * xh.y));
+      if (STORE_OK(xh.x)) orow[M / 2] = xh;
+      if constexpr (MEL) magbuf[M / 2 + 4 * ((M / 2) >> 4)] = cabs_fast(xh);
     }
 
     if constexpr (MEL) {
       wave_sync();
-      float* part = reinterpret_cast<float*>(wbuf) + FW * (M + 1);
+#pragma unroll 1
       for (int fsl = 0; fsl < FW; ++fsl) {
-        const float* mg = reinterpret_cast<float*>(wbuf) + fsl * (M + 1);
-        for (int u = lane; u < A.n_units; u += 64) {
-          const int k0 = A.unit_k0[u];
-          const float4* wq = reinterpret_cast<const float4*>(A.unit_w + (int64_t)u * 16);
-          float acc = 0.f;
+        const int fo2 = gb * FW + fsl;
+        if (fo2 >= n_out) break;  // wave-uniform
+        const float* mg = reinterpret_cast<float*>(wbuf) + fsl * (MAG_ROWS * MAG_ROW);
+        float* mrow = A.mel + ((int64_t)row * n_out + fo2) * A.n_mels;
+        float acc[NRR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const float4* mq = reinterpret_cast<const float4*>(mg + u_row[r]);
+          const float4* wq = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW);
+          float v = 0.f;
 #pragma unroll
           for (int i4 = 0; i4 < 4; ++i4) {
             const float4 w = wq[i4];
-            const int kk = k0 + 4 * i4;
-            acc = fmaf(w.x, mg[min(kk + 0, M)], acc);
-            acc = fmaf(w.y, mg[min(kk + 1, M)], acc);
-            acc = fmaf(w.z, mg[min(kk + 2, M)], acc);
-            acc = fmaf(w.w, mg[min(kk + 3, M)], acc);
+            const float4 m = mq[i4];
+            v = fmaf(w.x, m.x, v);
+            v = fmaf(w.y, m.y, v);
+            v = fmaf(w.z, m.z, v);
+            v = fmaf(w.w, m.w, v);
           }
-          part[u] = acc;
+          acc[r] = v;
+        }
+        // segmented sums over the adjacent lanes (inside one 16-lane row) that hold one band:
+        // DPP row_shl:n hands lane i the value of lane i+n
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          float sh;  // the DPP read must run in every lane: shuffle first, select afterwards
+          sh = dpp_row_shl<1>(acc[r]); acc[r] += (u_fl[r] & 1) ? sh : 0.f;
+          sh = dpp_row_shl<2>(acc[r]); acc[r] += (u_fl[r] & 2) ? sh : 0.f;
+          sh = dpp_row_shl<4>(acc[r]); acc[r] += (u_fl[r] & 4) ? sh : 0.f;
+          sh = dpp_row_shl<8>(acc[r]); acc[r] += (u_fl[r] & 8) ? sh : 0.f;
+          if (u_mel[r] >= 0) mrow[u_mel[r]] = acc[r];
+        }
+      }
+      wave_sync();
+    }
+    return have_nxt;
+  };
+
+  for (int64_t gbase = w0; gbase < g_hi; gbase += Wtot * RUN) {
+    const int64_t g_end = min(gbase + RUN, g_hi);
+    int64_t g = gbase;
+    while (g < g_end) {
+      // ---- first frame of a stretch: all 16 loads (or the edge path)
+      const int64_t row = g / gpr;
+      int gb = (int)(g - row * gpr);
+      const float* __restrict__ xr = A.x + row * A.T;
+      const int fo = gb * FW + fs;
+      const bool live = fo < n_out;
+      int64_t s0 = ((int64_t)fo + A.frame_lo) * A.hop - M;  // first sample, outer-padded coords
+      const bool interior = !live || (A.pad == 0 && s0 >= 0 && s0 + N <= Ti);
+      float2 a[16];
+      if (__all(interior)) {
+        if (!live) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) a[q] = make_float2(0.f, 0.f);
+        } else if constexpr (VEC2) {
+          const float2* __restrict__ p = reinterpret_cast<const float2*>(xr + s0);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) a[q] = p[t + L * q];
+        } else {
+          const float* __restrict__ p = xr + s0;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) a[q] = make_float2(p[2 * (t + L * q)], p[2 * (t + L * q) + 1]);
+        }
+      } else {
+        // edge frames (padding by index math): rolled loop through the wave's LDS slab, which is
+        // free here; keeps the register arrays statically indexed
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) {
+          const int n = t + L * q;
+          float2 v = make_float2(0.f, 0.f);
+          if (live)
+            v = make_float2(fetch_padded(xr, s0 + 2 * n, A.T, A.T2, A.pad, A.pad_mode),
+                            fetch_padded(xr, s0 + 2 * n + 1, A.T, A.T2, A.pad, A.pad_mode));
+          fbuf[n] = v;
         }
         wave_sync();
-        const int fo2 = f0 + fsl;
-        if (fo2 < f_end) {
-          float* mrow = A.mel + ((int64_t)row * A.n_out + fo2) * A.n_mels;
-          for (int m = lane; m < A.n_mels; m += 64) {
-            const int ub = A.mel_ubeg[m], ue = A.mel_ubeg[m + 1];
-            float acc = 0.f;
-            for (int u = ub; u < ue; ++u) acc += part[u];
-            mrow[m] = acc;
-          }
-        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = fbuf[t + L * q];
         wave_sync();
+      }
+      bool more = frame_body(a, xr, row, gb, s0, g + 1 < g_end);
+      ++g;
+      // ---- steady state: consecutive frames of the same row.  This loop is ONLY entered with
+      // "SH loads, then the stores of one frame" in flight on every path, so the compiler's
+      // s_waitcnt for nxt[] tolerates the stores (vmcnt(17+)) instead of draining them.
+      while (more) {
+        ++gb;
+        s0 += A.hop;
+        float2 b[16];
+#pragma unroll
+        for (int q = 0; q < 16 - SH; ++q) b[q] = raw[q + SH];
+#pragma unroll
+        for (int q = 0; q < SH; ++q) b[16 - SH + q] = nxt[q];
+        more = frame_body(b, xr, row, gb, s0, g + 1 < g_end);
+        ++g;
       }
     }
   }
 }
 
-template <int M>
-int launch_m(const StftArgs& A, bool write_stft, bool mel, hipStream_t stream) {
-  const int64_t waves = A.rows * A.chunks_per_row;
-  const int64_t blocks = (waves + 3) / 4;
-  if (blocks > 0x7fffffffLL) return AT_ERR_INVALID;
-  dim3 grid((unsigned)blocks), block(256);
-  if (write_stft && mel)
-    hipLaunchKernelGGL((stft_mel_kernel<M, true, true>), grid, block, 0, stream, A);
-  else if (write_stft)
-    hipLaunchKernelGGL((stft_mel_kernel<M, true, false>), grid, block, 0, stream, A);
-  else
-    hipLaunchKernelGGL((stft_mel_kernel<M, false, true>), grid, block, 0, stream, A);
+template <int M, int NW, bool VEC2, int NR>
+int launch_one(const StftArgs& A, size_t lds_bytes, int max_blocks, hipStream_t stream) {
+  auto kern = stft_mel_kernel<M, NW, VEC2, NR>;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return AT_ERR_HIP(e);
+    attr_done = true;
+  }
+  int64_t blocks = (A.total_groups + NW - 1) / NW;
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, stream, A);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }
 
+template <int M, int NW, bool VEC2>
+int launch_mw(const StftArgs& A, int n_cu, hipStream_t stream) {
+  size_t fl = lds_fixed_floats<M>(NW) + (size_t)A.n_units * MELW_ROW;
+  const size_t bytes = fl * 4;
+  if (bytes > 160 * 1024) return AT_ERR_UNSUPPORTED;
+  // persistent grid: as many blocks as are co-resident (LDS-limited; the kernel needs ~200 VGPRs,
+  // i.e. 2 waves/SIMD = 8 waves/CU), times #CUs
+  int per_cu = (int)((160 * 1024) / bytes);
+  const int by_waves = (4 * AT_STFT_WPS) / NW > 0 ? (4 * AT_STFT_WPS) / NW : 1;
+  if (per_cu > by_waves) per_cu = by_waves;
+  if (per_cu < 1) per_cu = 1;
+  const int max_blocks = n_cu * per_cu;
+  switch (A.n_units / 64) {
+    case 0: return launch_one<M, NW, VEC2, 0>(A, bytes, max_blocks, stream);
+    case 2: return launch_one<M, NW, VEC2, 2>(A, bytes, max_blocks, stream);
+    case 4: return launch_one<M, NW, VEC2, 4>(A, bytes, max_blocks, stream);
+    case 6: return launch_one<M, NW, VEC2, 6>(A, bytes, max_blocks, stream);
+  }
+  return AT_ERR_UNSUPPORTED;
+}
+
+template <int M>
+int launch_m(const StftArgs& A, bool vec2, int n_cu, hipStream_t stream) {
+  return vec2 ? launch_mw<M, AT_STFT_NW, true>(A, n_cu, stream) : launch_mw<M, AT_STFT_NW, false>(A, n_cu, stream);
+}
+
 }  // namespace
+
+static int device_cu_count() {
+  static int n = [] {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return 256;
+    return cu;
+  }();
+  return n;
+}
 
 extern "C" {
 
@@ -442,52 +668,108 @@ int at_stft_native_supported(int n_fft) {
   return (n_fft >= 32 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0) ? 1 : 0;
 }
 
+// Host helper: compress a dense (n_mels, n_bins) float32 filterbank into the unit tables
+// consumed by at_stft_mel_f32.  Call with unit_info == NULL to get the unit count (a multiple
+// of 64); then with unit_info[2*n] ints and unit_w[16*n] floats.  Returns the unit count, or a
+// negative error (AT_ERR_UNSUPPORTED if a band needs more than 8 rows of 16 bins).
+int at_mel_units_host(const float* basis, int n_mels, int n_bins, int* unit_info, float* unit_w) {
+  if (!basis || n_mels <= 0 || n_mels >= 0xffff || n_bins <= 0) return AT_ERR_INVALID;
+  auto pad_unit = [&](int n) {
+    unit_info[2 * n] = 0 | (0xffff << 16);
+    unit_info[2 * n + 1] = 0;
+    for (int i = 0; i < 16; ++i) unit_w[16 * n + i] = 0.f;
+  };
+  int n = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool fill = pass == 1;
+    n = 0;
+    for (int m = 0; m < n_mels; ++m) {
+      const float* b = basis + (int64_t)m * n_bins;
+      int lo = -1, hi = -1;
+      for (int k = 0; k < n_bins; ++k)
+        if (b[k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+      int r0 = 0, r1 = 0;  // all-zero band: one unit of zeros so that the output is written
+      if (lo >= 0) { r0 = lo / 16; r1 = hi / 16; }
+      const int cnt = r1 - r0 + 1;
+      if (cnt > 16) return AT_ERR_UNSUPPORTED;
+      while ((n % 16) + cnt > 16) {  // a band never straddles a 16-lane DPP row
+        if (fill) pad_unit(n);
+        ++n;
+      }
+      for (int j = 0; j < cnt; ++j, ++n) {
+        if (!fill) continue;
+        const int r = r0 + j;
+        unit_info[2 * n] = r | (m << 16);
+        // shift-left tree over `cnt` adjacent lanes: lane j adds lane j+d when j % (2d) == 0 and j+d < cnt
+        int flags = 0;
+        for (int step = 0, d = 1; step < 4; ++step, d <<= 1)
+          if ((j % (2 * d)) == 0 && j + d < cnt) flags |= 1 << step;
+        if (j == 0) flags |= 16;  // this lane stores the band
+        unit_info[2 * n + 1] = flags;
+        for (int i = 0; i < 16; ++i) {
+          const int k = 16 * r + i;
+          unit_w[16 * n + i] = (k < n_bins) ? b[k] : 0.f;
+        }
+      }
+    }
+    // the kernel is instantiated for 2, 4 or 6 rounds of 64 units
+    const int target = n <= 128 ? 128 : (n <= 256 ? 256 : 384);
+    if (n > 384) return AT_ERR_UNSUPPORTED;
+    while (n < target) {
+      if (fill) pad_unit(n);
+      ++n;
+    }
+    if (!unit_info || !unit_w) return n;
+  }
+  return n;
+}
+
 int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
                     int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,
-                    float* stft_out, const int* mel_unit_k0, const float* mel_unit_w, const int* mel_ubeg,
-                    int n_units, int n_mels, float* mel_out, void* stream) {
+                    float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,
+                    float* mel_out, void* stream) {
   if (!x || !window || !twiddles || rows < 0 || T <= 0 || hop <= 0 || pad < 0 || right_pad < 0 ||
       frame_lo < 0 || n_frames_out < 0)
     return AT_ERR_INVALID;
   if (!at_stft_native_supported(n_fft)) return AT_ERR_UNSUPPORTED;
-  const bool write_stft = stft_out != nullptr;
   const bool mel = mel_out != nullptr;
-  if (!write_stft && !mel) return AT_ERR_INVALID;
-  if (mel && (!mel_unit_k0 || !mel_unit_w || !mel_ubeg || n_units <= 0 || n_mels <= 0)) return AT_ERR_INVALID;
+  if (!stft_out) return AT_ERR_INVALID;  // stft_data is always produced (audio_signal.py:1210)
+  if (mel && (!mel_unit_info || !mel_unit_w || (n_units != 128 && n_units != 256 && n_units != 384) || n_mels <= 0))
+    return AT_ERR_INVALID;
   const int M = n_fft / 2;
   const int64_t T2 = T + 2 * (int64_t)pad + right_pad;
   if (M >= T2) return AT_ERR_INVALID;  // torch.stft reflect padding needs n_fft/2 < length
   if (pad_mode == at::PAD_REFLECT && (pad >= T || pad + right_pad >= T)) return AT_ERR_INVALID;
   const int64_t n_total = 1 + T2 / hop;
   if (frame_lo + n_frames_out > n_total) return AT_ERR_INVALID;
+  if (T >= (1LL << 31) || n_frames_out >= (1LL << 31) / (M + 1)) return AT_ERR_UNSUPPORTED;
   if (rows == 0 || n_frames_out == 0) return AT_OK;
-  // LDS budget of the mel stage: FW*(M+1) magnitudes + n_units partials in 2176 floats
   const int FW = 64 / (M / 16);
-  if (mel && FW * (M + 1) + n_units > 2 * WAVE_LDS_SLOTS) return AT_ERR_UNSUPPORTED;
+  // mel stage limits: <= 6 rounds of 64 units; FW frames of padded magnitudes in the wave slab
+  if (mel && FW * (M / 16 + 1) * MAG_ROW > 2 * WAVE_LDS_SLOTS) return AT_ERR_UNSUPPORTED;
 
   StftArgs A;
   A.x = x; A.window = window; A.tw = reinterpret_cast<const float2*>(twiddles);
   A.out = reinterpret_cast<float2*>(stft_out); A.mel = mel_out;
-  A.unit_k0 = mel_unit_k0; A.unit_w = mel_unit_w; A.mel_ubeg = mel_ubeg;
+  A.unit_info = mel_unit_info; A.unit_w = mel_unit_w;
   A.T = T; A.rows = rows; A.n_out = n_frames_out; A.frame_lo = frame_lo; A.hop = hop; A.pad = pad;
-  A.T2 = T2; A.pad_mode = pad_mode; A.n_units = n_units; A.n_mels = n_mels;
-  A.vec2 = ((T % 2) == 0 && (hop % 2) == 0 && (M % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 8) == 0) ? 1 : 0;
-  // frames per wave chunk: long enough to amortise the per-wave constant loads and keep
-  // the overlapping input in L1/L2, short enough to give >= ~4096 waves.
-  int64_t chunk = 16 * FW;
-  const int64_t want_waves = 4096;
-  while (chunk > FW && rows * ((n_frames_out + chunk - 1) / chunk) < want_waves) chunk -= FW;
-  A.chunk = (int)chunk;
-  A.chunks_per_row = (int)((n_frames_out + chunk - 1) / chunk);
+  A.T2 = T2; A.pad_mode = pad_mode; A.n_units = mel ? n_units : 0; A.n_mels = n_mels;
+  A.groups_per_row = (int)((n_frames_out + FW - 1) / FW);
+  A.total_groups = rows * A.groups_per_row;
+  { const char* e = getenv("AT_STFT_DEBUG"); A.debug = e ? atoi(e) : 0; }
+  A.reuse_shift = (FW == 1 && hop % (2 * (M / 16)) == 0 && pad == 0) ? hop / (2 * (M / 16)) : 0;
+  { const char* e = getenv("AT_STFT_REUSE"); if (e && atoi(e) == 0) A.reuse_shift = 0; }
+  const bool vec2 = ((T % 2) == 0 && (hop % 2) == 0 && (M % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 8) == 0);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int n_cu = device_cu_count();
   switch (M) {
-    case 16: return launch_m<16>(A, write_stft, mel, s);
-    case 32: return launch_m<32>(A, write_stft, mel, s);
-    case 64: return launch_m<64>(A, write_stft, mel, s);
-    case 128: return launch_m<128>(A, write_stft, mel, s);
-    case 256: return launch_m<256>(A, write_stft, mel, s);
-    case 512: return launch_m<512>(A, write_stft, mel, s);
-    case 1024: return launch_m<1024>(A, write_stft, mel, s);
+    case 16: return launch_m<16>(A, vec2, n_cu, s);
+    case 32: return launch_m<32>(A, vec2, n_cu, s);
+    case 64: return launch_m<64>(A, vec2, n_cu, s);
+    case 128: return launch_m<128>(A, vec2, n_cu, s);
+    case 256: return launch_m<256>(A, vec2, n_cu, s);
+    case 512: return launch_m<512>(A, vec2, n_cu, s);
+    case 1024: return launch_m<1024>(A, vec2, n_cu, s);
   }
   return AT_ERR_UNSUPPORTED;
 }

@@ -82,7 +82,7 @@ def broadcast_table(key, builder, device, src: int = 0):
 
 
 def broadcast_stft_mel_tables(sample_rate, n_fft, window_type, n_mels, device, fmin=0.0, fmax=None):
-    """The shared tables of the STFT+mel kernel: window, twiddles, mel unit tables."""
+    """The shared tables of the STFT+mel kernel: window, twiddles, mel unit tables (info, weights)."""
     import numpy as np
 
     from . import _native

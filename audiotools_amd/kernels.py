@@ -45,7 +45,7 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
              want_stft: bool = True, mel=None):
     """Fused STFT (+ mel).  ``audio`` (B, C, T) float32 HIP tensor.
 
-    ``mel`` is ``None`` or a tuple ``(unit_k0, unit_w, mel_ubeg, n_mels)`` of
+    ``mel`` is ``None`` or a tuple ``(unit_info, unit_w, n_mels)`` of
     device tables from :func:`tables.mel_units`.
 
     Returns ``(stft, mel_spec)``: ``stft`` is a complex64 tensor of logical
@@ -63,18 +63,20 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
     frame_lo, n_out = stft_frames(T, n_fft, hop, pad, right_pad, match_stride)
     dev = audio.device
     tw = tables.stft_twiddles(n_fft, dev)
-    stft_buf = torch.empty((B, C, n_out, F), dtype=torch.complex64, device=dev) if want_stft else None
+    if not want_stft:
+        raise NotImplementedError("the fused kernel always produces stft_data")
+    stft_buf = torch.empty((B, C, n_out, F), dtype=torch.complex64, device=dev)
     mel_buf = None
-    k0 = w = ub = None
+    info = w = None
     n_units = n_mels = 0
     if mel is not None:
-        k0, w, ub, n_mels = mel
-        n_units = int(k0.numel())
+        info, w, n_mels = mel
+        n_units = int(info.shape[0])
         mel_buf = torch.empty((B, C, n_out, n_mels), dtype=torch.float32, device=dev)
     code = _native.lib().at_stft_mel_f32(
         _native.ptr(audio), B * C, T, _native.ptr(window), _native.ptr(tw), n_fft, hop, pad, right_pad,
-        PAD_MODES[padding_type], frame_lo, n_out, _native.ptr(stft_buf), _native.ptr(k0), _native.ptr(w),
-        _native.ptr(ub), n_units, n_mels, _native.ptr(mel_buf), _native.current_stream(dev))
+        PAD_MODES[padding_type], frame_lo, n_out, _native.ptr(stft_buf), _native.ptr(info), _native.ptr(w),
+        n_units, n_mels, _native.ptr(mel_buf), _native.current_stream(dev))
     _native.check(code, "at_stft_mel_f32")
     stft = stft_buf.transpose(2, 3) if stft_buf is not None else None
     mel_spec = mel_buf.transpose(2, 3) if mel_buf is not None else None

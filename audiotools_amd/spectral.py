@@ -132,12 +132,12 @@ class SpectralMixin:
         audio = self.audio_data
         if kernels.is_native(audio) and kernels.stft_native_supported(n_fft):
             dev = audio.device
-            k0, w, ub = tables.mel_units(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, dev)
+            info, w = tables.mel_units(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, dev)
             window = self.get_window(wtype, n_fft, str(dev))
             right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
             X, mel = kernels.stft_mel(audio, window, n_fft, hop, pad=pad, right_pad=right_pad,
                                       padding_type=padding_type, match_stride=match_stride,
-                                      mel=(k0, w, ub, n_mels))
+                                      mel=(info, w, n_mels))
             self.stft_data = X
             return mel
         X = self.stft(**kwargs)

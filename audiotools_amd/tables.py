@@ -80,28 +80,21 @@ MEL_UNIT = 16  # bins per mel work unit (matches csrc/stft.hip)
 
 def mel_units_np(basis: np.ndarray):
     """Compress a banded (n_mels, F) filterbank into the unit tables of
-    ``at_stft_mel_f32``: unit u multiplies 16 consecutive bins starting at
-    ``unit_k0[u]`` with ``unit_w[u]`` for band m, ``mel_ubeg[m] <= u <
-    mel_ubeg[m+1]``.  Zero weights inside a band are kept, so any real matrix
-    is represented exactly (a dense one just costs more units)."""
-    n_mels, F = basis.shape
-    k0s, ws, ubeg = [], [], [0]
-    for m in range(n_mels):
-        nz = np.nonzero(basis[m])[0]
-        if len(nz):
-            lo, hi = int(nz[0]), int(nz[-1]) + 1
-            for k in range(lo, hi, MEL_UNIT):
-                w = np.zeros(MEL_UNIT, dtype=np.float32)
-                seg = basis[m, k: min(k + MEL_UNIT, hi)]
-                w[: len(seg)] = seg
-                k0s.append(k)
-                ws.append(w)
-        ubeg.append(len(k0s))
-    if not k0s:  # all-zero basis: one dummy unit
-        k0s, ws = [0], [np.zeros(MEL_UNIT, dtype=np.float32)]
-        ubeg = [0] + [0] * (n_mels - 1) + [0]
-    return (np.asarray(k0s, dtype=np.int32), np.stack(ws).astype(np.float32),
-            np.asarray(ubeg, dtype=np.int32))
+    ``at_stft_mel_f32`` with the library's host helper ``at_mel_units_host``:
+    ``(unit_info int32 (n_units, 2), unit_w float32 (n_units, 16))``.  A unit is
+    one (row of 16 bins, band) pair; zero weights inside a band are kept, so
+    any banded real matrix is represented exactly."""
+    basis = np.ascontiguousarray(basis, dtype=np.float32)
+    n_mels, n_bins = basis.shape
+    lib = _native.lib()
+    n = lib.at_mel_units_host(basis.ctypes.data, n_mels, n_bins, None, None)
+    if n <= 0:
+        _native.check(int(n) if n < 0 else -1, "at_mel_units_host")
+    info = np.zeros((n, 2), dtype=np.int32)
+    w = np.zeros((n, 16), dtype=np.float32)
+    n2 = lib.at_mel_units_host(basis.ctypes.data, n_mels, n_bins, info.ctypes.data, w.ctypes.data)
+    assert n2 == n
+    return info, w
 
 
 def dct_np(n_mfcc: int, n_mels: int, norm="ortho") -> np.ndarray:

@@ -49,18 +49,25 @@ extern "C" {
  *   frame_lo, n_frames_out            frames [frame_lo, frame_lo+n_frames_out) of the
  *                                     1 + (T+2*pad+right_pad)/hop frames are produced
  *                                     (match_stride drops 2 at each end, :1206-1209)
- *   stft_out   (rows, n_frames_out, n_fft/2+1) complex64 as interleaved f32, or NULL
+ *   stft_out   (rows, n_frames_out, n_fft/2+1) complex64 as interleaved f32 (required)
  *              -- bin-contiguous, the physical layout of torch.stft's result
- *   mel tables banded filterbank in "unit" form (see tables.mel_units_np):
- *              mel_unit_k0[n_units] i32, mel_unit_w[n_units*16] f32, mel_ubeg[n_mels+1] i32
+ *   mel tables banded filterbank in "unit" form built by at_mel_units_host: a unit is one
+ *              (row of 16 bins, band) pair: mel_unit_info[2*n_units] i32, mel_unit_w[16*n_units] f32,
+ *              n_units in {128, 256, 384} (padded by the helper)
  *   mel_out    (rows, n_frames_out, n_mels) f32, or NULL
+ *
+ * at_mel_units_host: HOST helper that compresses a dense (n_mels, n_bins) float32 filterbank
+ *   (librosa.filters.mel layout, audio_signal.py:1323-1331) into unit tables.  Call with
+ *   unit_info == NULL to get the unit count, then again with buffers.  Returns the count (>0)
+ *   or a negative error.
  */
 int at_stft_twiddles_host(int n_fft, float* out_host);
 int at_stft_native_supported(int n_fft);
+int at_mel_units_host(const float* basis_host, int n_mels, int n_bins, int* unit_info_host, float* unit_w_host);
 int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
                     int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,
-                    float* stft_out, const int* mel_unit_k0, const float* mel_unit_w, const int* mel_ubeg,
-                    int n_units, int n_mels, float* mel_out, void* stream);
+                    float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,
+                    float* mel_out, void* stream);
 
 /* ---- BS.1770 integrated loudness ---------------------------------------------------
  * Replaces  audiotools/core/loudness.py:102-126  (2x torchaudio.functional.lfilter, the

@@ -51,7 +51,7 @@ def test_host_only_entry_points(lib):
 
 def test_argument_validation_without_gpu(lib):
     # NULL pointers / bad sizes are rejected before any HIP call
-    assert lib.at_stft_mel_f32(None, 1, 100, None, None, 512, 128, 0, 0, 0, 0, 1, None, None, None, None, 0, 0,
+    assert lib.at_stft_mel_f32(None, 1, 100, None, None, 512, 128, 0, 0, 0, 0, 1, None, None, None, 0, 0,
                                None, None) == -1
     assert lib.at_lufs_f32(None, 1, 1, 100, None, None, 2, 400, 100, 1.0, 0.0, 0, None, None, 0, None) == -1
 

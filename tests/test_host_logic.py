@@ -38,15 +38,39 @@ def test_tables_match_leaves():
 
 
 def test_mel_units_reconstruct_basis():
-    basis = tables.mel_filters_np(44100, 2048, 80)
-    k0, w, ub = tables.mel_units_np(basis)
-    rec = np.zeros_like(basis)
-    for m in range(80):
-        for u in range(ub[m], ub[m + 1]):
-            hi = min(k0[u] + 16, basis.shape[1])
-            rec[m, k0[u]:hi] += w[u][: hi - k0[u]]
-    assert np.array_equal(rec, basis)
-    assert len(k0) < 400
+    from audiotools_amd import _native
+
+    _native.build()
+    for sr, n_fft, nm in [(44100, 2048, 80), (16000, 512, 80), (8000, 256, 40), (44100, 64, 20)]:
+        basis = tables.mel_filters_np(sr, n_fft, nm)
+        info, w = tables.mel_units_np(basis)
+        assert info.shape[0] in (128, 256, 384)
+        rec = np.zeros_like(basis)
+        stored = set()
+        for u in range(info.shape[0]):
+            row, m, flags = info[u, 0] & 0xffff, (info[u, 0] >> 16) & 0xffff, info[u, 1]
+            if m == 0xffff:
+                assert flags == 0 and not w[u].any()
+                continue
+            hi = min(16 * row + 16, basis.shape[1])
+            rec[m, 16 * row:hi] += w[u][: hi - 16 * row]
+            if flags & 16:
+                assert m not in stored
+                stored.add(m)
+        assert np.array_equal(rec, basis)
+        assert stored == set(range(nm))
+        # emulate the in-wave shuffle-down tree: every band's units end up summed in its first lane
+        vals = np.arange(1, info.shape[0] + 1, dtype=np.float64)
+        acc = vals.copy()
+        for step, d in enumerate((1, 2, 4, 8)):
+            sh = np.concatenate([acc[d:], np.zeros(d)])
+            sh[(np.arange(len(sh)) % 16) + d >= 16] = 0.0   # DPP row_shl stays inside a 16-lane row
+            take = (info[:, 1] >> step) & 1
+            acc = acc + np.where(take == 1, sh, 0.0)
+        for m in range(nm):
+            us = [u for u in range(info.shape[0]) if ((info[u, 0] >> 16) & 0xffff) == m]
+            assert us == list(range(us[0], us[-1] + 1)) and us[0] // 16 == us[-1] // 16
+            assert acc[us[0]] == vals[us].sum()
 
 
 def test_cpu_path_matches_oracle():
