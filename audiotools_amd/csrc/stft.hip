@@ -254,12 +254,12 @@ constexpr int MELW_ROW = 20;  // floats per padded LDS row of 16 unit weights
 // LDS layout of one block (floats):
 //   [NW wave slabs: NW * 2 * WAVE_LDS_SLOTS][window: 2M][split twiddles: M (= M/2 float2)]
 //   [pass-2 twiddles: 16 rows (j mod 16) x 36 floats (16 float2 + pad, conflict-free b128 rows)]
-//   [mel unit weights: n_units x MELW_ROW]
+//   [mel unit weights: n_units x MELW_ROW][mel unit info: n_units x int2 {row offset, band | flags}]
 template <int M>
 __host__ __device__ constexpr int lds_fixed_floats(int nw) { return nw * 2 * WAVE_LDS_SLOTS + 2 * M + M + 16 * 36; }
 
 template <int M, int NW, bool VEC2, int NR /* mel rounds of 64 units; 0 = no mel */>
-__global__ __launch_bounds__(NW * 64) void stft_mel_kernel(const StftArgs A) {
+__global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const StftArgs A) {
   constexpr bool MEL = NR > 0;
   constexpr bool WRITE_STFT = true;
   using P = Plan<M>;
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(NW * 64) void stft_mel_kernel(const StftArgs A) {
   float2* s_twp = reinterpret_cast<float2*>(s_win + N);
   float* s_tw2 = s_win + N + M;
   float* s_melw = s_tw2 + 16 * 36;
+  int2* s_uinfo = reinterpret_cast<int2*>(s_melw + A.n_units * MELW_ROW);
 
   // ---- block-shared tables -> LDS (once per persistent block)
   for (int i = threadIdx.x; i < N; i += NW * 64) s_win[i] = A.window[i];
@@ -291,6 +292,11 @@ __global__ __launch_bounds__(NW * 64) void stft_mel_kernel(const StftArgs A) {
   if constexpr (MEL) {
     for (int i = threadIdx.x; i < A.n_units * 16; i += NW * 64)
       s_melw[(i >> 4) * MELW_ROW + (i & 15)] = A.unit_w[i];
+    for (int i = threadIdx.x; i < A.n_units; i += NW * 64) {
+      const int info = A.unit_info[2 * i], fl = A.unit_info[2 * i + 1];
+      // x: float offset of the unit's row of magnitudes; y: flags | band << 8 (band 0xffff = none)
+      s_uinfo[i] = make_int2((info & 0xffff) * MAG_ROW, (fl & 0xff) | (((info >> 16) & 0xffff) << 8));
+    }
   }
   __syncthreads();
 
@@ -314,19 +320,7 @@ __global__ __launch_bounds__(NW * 64) void stft_mel_kernel(const StftArgs A) {
       tw3b[b] = A.tw[(j % NS) * (N / (NS * P::R3))];
     }
   }
-  // mel: this lane's unit of every round (row of 16 bins, band, reduction masks as 0/1 floats)
   constexpr int NRR = MEL ? NR : 1;
-  int u_row[NRR], u_mel[NRR], u_fl[NRR];
-  if constexpr (MEL) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int info = A.unit_info[2 * (r * 64 + lane)];
-      u_fl[r] = A.unit_info[2 * (r * 64 + lane) + 1];
-      u_row[r] = (info & 0xffff) * MAG_ROW;
-      u_mel[r] = (u_fl[r] & 16) ? ((info >> 16) & 0xffff) : -1;   // -1: this lane stores nothing
-    }
-  }
-
   const int Ti = (int)A.T;
   const int n_out = (int)A.n_out;
   const int gpr = A.groups_per_row;
@@ -499,33 +493,43 @@ __global__ __launch_bounds__(NW * 64) void stft_mel_kernel(const StftArgs A) {
         if (fo2 >= n_out) break;  // wave-uniform
         const float* mg = reinterpret_cast<float*>(wbuf) + fsl * (MAG_ROWS * MAG_ROW);
         float* mrow = A.mel + ((int64_t)row * n_out + fo2) * A.n_mels;
-        float acc[NRR];
+        // two rounds at a time: enough independent work to cover the LDS latency, while the
+        // scheduling barrier keeps the other rounds' 32 loaded registers each from piling up
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const float4* mq = reinterpret_cast<const float4*>(mg + u_row[r]);
-          const float4* wq = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW);
-          float v = 0.f;
+        for (int r0 = 0; r0 < NR; r0 += 2) {
+          float acc[2];
+          int u_fl[2];
 #pragma unroll
-          for (int i4 = 0; i4 < 4; ++i4) {
-            const float4 w = wq[i4];
-            const float4 m = mq[i4];
-            v = fmaf(w.x, m.x, v);
-            v = fmaf(w.y, m.y, v);
-            v = fmaf(w.z, m.z, v);
-            v = fmaf(w.w, m.w, v);
+          for (int j = 0; j < 2; ++j) {
+            const int r = r0 + j;
+            const int2 ui = s_uinfo[r * 64 + lane];
+            u_fl[j] = ui.y;
+            const float4* mq = reinterpret_cast<const float4*>(mg + ui.x);
+            const float4* wq = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW);
+            float v = 0.f;
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+              const float4 w = wq[i4];
+              const float4 m = mq[i4];
+              v = fmaf(w.x, m.x, v);
+              v = fmaf(w.y, m.y, v);
+              v = fmaf(w.z, m.z, v);
+              v = fmaf(w.w, m.w, v);
+            }
+            acc[j] = v;
           }
-          acc[r] = v;
-        }
-        // segmented sums over the adjacent lanes (inside one 16-lane row) that hold one band:
-        // DPP row_shl:n hands lane i the value of lane i+n
+          // segmented sums over the adjacent lanes (inside one 16-lane row) that hold one band:
+          // DPP row_shl:n hands lane i the value of lane i+n
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          float sh;  // the DPP read must run in every lane: shuffle first, select afterwards
-          sh = dpp_row_shl<1>(acc[r]); acc[r] += (u_fl[r] & 1) ? sh : 0.f;
-          sh = dpp_row_shl<2>(acc[r]); acc[r] += (u_fl[r] & 2) ? sh : 0.f;
-          sh = dpp_row_shl<4>(acc[r]); acc[r] += (u_fl[r] & 4) ? sh : 0.f;
-          sh = dpp_row_shl<8>(acc[r]); acc[r] += (u_fl[r] & 8) ? sh : 0.f;
-          if (u_mel[r] >= 0) mrow[u_mel[r]] = acc[r];
+          for (int j = 0; j < 2; ++j) {
+            float sh;  // the DPP read must run in every lane: shuffle first, select afterwards
+            sh = dpp_row_shl<1>(acc[j]); acc[j] += (u_fl[j] & 1) ? sh : 0.f;
+            sh = dpp_row_shl<2>(acc[j]); acc[j] += (u_fl[j] & 2) ? sh : 0.f;
+            sh = dpp_row_shl<4>(acc[j]); acc[j] += (u_fl[j] & 4) ? sh : 0.f;
+            sh = dpp_row_shl<8>(acc[j]); acc[j] += (u_fl[j] & 8) ? sh : 0.f;
+            if (u_fl[j] & 16) mrow[u_fl[j] >> 8] = acc[j];
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       wave_sync();
@@ -615,7 +619,7 @@ int launch_one(const StftArgs& A, size_t lds_bytes, int max_blocks, hipStream_t 
 
 template <int M, int NW, bool VEC2>
 int launch_mw(const StftArgs& A, int n_cu, hipStream_t stream) {
-  size_t fl = lds_fixed_floats<M>(NW) + (size_t)A.n_units * MELW_ROW;
+  size_t fl = lds_fixed_floats<M>(NW) + (size_t)A.n_units * (MELW_ROW + 2);
   const size_t bytes = fl * 4;
   if (bytes > 160 * 1024) return AT_ERR_UNSUPPORTED;
   // persistent grid: as many blocks as are co-resident (LDS-limited; the kernel needs ~200 VGPRs,
