@@ -12,7 +12,7 @@
 //   Each biquad stage is solved exactly in three steps:
 //     (a) per lane: FIR part + zero-state recursion over its 32 samples;
 //     (b) across lanes: the 2-vector recursion  F_c = z_c + P F_{c-1}  (P = companion^32)
-//         by a 6-step Kogge-Stone scan with the constant matrices P, P^2, P^4.. in f64;
+//         by a DPP wave scan (row_shr 1/2/4/8, row_bcast15, row_bcast31) with powers of P;
 //     (c) per lane: re-run the recursion from the true entering state.
 //   The state entering a super-block is carried in registers from the previous one, so a
 //   segment is filtered exactly; a segment that does not start at sample 0 starts `warm`
@@ -30,6 +30,9 @@ constexpr int CHUNK = 32;            // samples per lane
 constexpr int SB = 64 * CHUNK;       // samples per super-block
 constexpr int ROWF = CHUNK + 4;      // padded LDS row (floats): 144 B
 constexpr int MAX_STAGE = 4;
+#ifndef AT_LUFS_WPS
+#define AT_LUFS_WPS 3   // waves per SIMD the register allocator must allow
+#endif
 
 struct Stage {
   float b0, b1, b2, a1, a2, g;
@@ -50,8 +53,9 @@ struct LufsArgs {
   int nstage;
   int vec4;
   Stage st[MAX_STAGE];
-  // P^(2^i), i = 0..6, per stage, row-major 2x2 doubles: wave-uniform, read through s_load
-  double Pp[MAX_STAGE][7][4];
+  // P^(2^i), i = 0..6, per stage, row-major 2x2: wave-uniform, read through s_load
+  double Pp[MAX_STAGE][7][4];   // float64: used once per wave to build the per-lane matrices
+  float Pf[MAX_STAGE][4][4];    // float32 P^1, P^2, P^4, P^8 for the in-row scan steps
 };
 
 struct M2 {  // 2x2 double matrix
@@ -60,15 +64,39 @@ struct M2 {  // 2x2 double matrix
 __device__ __forceinline__ M2 mmul(const M2& x, const M2& y) {
   return {x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d};
 }
-__device__ __forceinline__ double shfl_up_d(double v, int d) { return __shfl_up(v, d, 64); }
+struct M2f {  // 2x2 float matrix
+  float a, b, c, d;
+};
+
+// DPP data movement (gfx9): all VALU-rate, no LDS round trip
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp0(float v) {  // lanes without a source read 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int N> __device__ __forceinline__ float row_shr(float v) { return dpp0<0x110 | N, 0xf>(v); }  // lane i <- i-N in its 16-row
+__device__ __forceinline__ float row_bcast15(float v) { return dpp0<0x142, 0xa>(v); }  // rows 1,3 <- lane 15 / 47
+__device__ __forceinline__ float row_bcast31(float v) { return dpp0<0x143, 0xc>(v); }  // rows 2,3 <- lane 31
+__device__ __forceinline__ float wave_shr1(float v, float lane0) {                     // lane i <- i-1, lane 0 <- lane0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane0), __builtin_bit_cast(int, v),
+                                                                0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane63(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+struct LaneMats {  // per-lane float32 powers of P = companion^CHUNK
+  M2f q16;  // P^((lane & 15) + 1): folds in the previous 16-lane row
+  M2f q32;  // P^((lane & 31) + 1): folds in lanes 0..31
+  M2f q64;  // P^(lane + 1):        folds in the state entering the super-block
+};
 
 // Solve one biquad stage in place on the lane's CHUNK samples.
 // in:  v[] = stage input; (hx1,hx2) = the two input samples preceding the lane's chunk
-// io:  (ky1,ky2) = output state entering the SUPER-BLOCK (wave-uniform); updated to the
-//      state leaving it.
+// io:  (ky1,ky2) = output state entering the SUPER-BLOCK (wave-uniform) in the basis (y1, y1-y2);
+//      updated to the state leaving it.
 template <int SI>
-__device__ __forceinline__ void biquad_stage(float (&v)[CHUNK], const LufsArgs& A, float hx1, float hx2, double& ky1,
-                                             double& ky2, const M2& Q, int lane) {
+__device__ __forceinline__ void biquad_stage(float (&v)[CHUNK], const LufsArgs& A, float hx1, float hx2, float& ky1,
+                                             float& ky2, const LaneMats& Q, int lane) {
   const Stage s = A.st[SI];
   // (a) FIR part in place + zero-state recursion
   float x1 = hx1, x2 = hx2;
@@ -86,27 +114,41 @@ __device__ __forceinline__ void biquad_stage(float (&v)[CHUNK], const LufsArgs& 
     y2 = y1;
     y1 = y;
   }
-  // (b) scan: G_c = sum_{j<=c} P^(c-j) z_j
-  double g1 = (double)y1, g2 = (double)y2;
+  // (b) wave scan of the state recursion F_c = z_c + P F_{c-1}:
+  //     Hillis-Steele inside each 16-lane row (row_shr 1,2,4,8 with P, P^2, P^4, P^8),
+  //     then row_bcast15 / row_bcast31 fold the previous rows in with per-lane powers of P.
+  float g1 = y1, g2 = y1 - y2;  // state in the basis (y1, y1 - y2)
 #pragma unroll
-  for (int step = 0; step < 6; ++step) {
-    const int d = 1 << step;
-    const double u1 = shfl_up_d(g1, d), u2 = shfl_up_d(g2, d);
-    if (lane >= d) {
-      g1 += A.Pp[SI][step][0] * u1 + A.Pp[SI][step][1] * u2;
-      g2 += A.Pp[SI][step][2] * u1 + A.Pp[SI][step][3] * u2;
-    }
+  for (int step = 0; step < 4; ++step) {
+    float u1, u2;
+    if (step == 0) { u1 = row_shr<1>(g1); u2 = row_shr<1>(g2); }
+    if (step == 1) { u1 = row_shr<2>(g1); u2 = row_shr<2>(g2); }
+    if (step == 2) { u1 = row_shr<4>(g1); u2 = row_shr<4>(g2); }
+    if (step == 3) { u1 = row_shr<8>(g1); u2 = row_shr<8>(g2); }
+    const float n1 = fmaf(A.Pf[SI][step][0], u1, fmaf(A.Pf[SI][step][1], u2, g1));
+    const float n2 = fmaf(A.Pf[SI][step][2], u1, fmaf(A.Pf[SI][step][3], u2, g2));
+    g1 = n1; g2 = n2;
+  }
+  {
+    const float u1 = row_bcast15(g1), u2 = row_bcast15(g2);
+    const float n1 = fmaf(Q.q16.a, u1, fmaf(Q.q16.b, u2, g1));
+    const float n2 = fmaf(Q.q16.c, u1, fmaf(Q.q16.d, u2, g2));
+    g1 = n1; g2 = n2;
+  }
+  {
+    const float u1 = row_bcast31(g1), u2 = row_bcast31(g2);
+    const float n1 = fmaf(Q.q32.a, u1, fmaf(Q.q32.b, u2, g1));
+    const float n2 = fmaf(Q.q32.c, u1, fmaf(Q.q32.d, u2, g2));
+    g1 = n1; g2 = n2;
   }
   // F_c = G_c + P^(c+1) K ; entering state of lane c = F_{c-1} (lane 0: K)
-  const double f1 = g1 + Q.a * ky1 + Q.b * ky2;
-  const double f2 = g2 + Q.c * ky1 + Q.d * ky2;
-  double e1 = shfl_up_d(f1, 1), e2 = shfl_up_d(f2, 1);
-  if (lane == 0) { e1 = ky1; e2 = ky2; }
-  ky1 = __shfl(f1, 63, 64);
-  ky2 = __shfl(f2, 63, 64);
+  const float f1 = fmaf(Q.q64.a, ky1, fmaf(Q.q64.b, ky2, g1));
+  const float f2 = fmaf(Q.q64.c, ky1, fmaf(Q.q64.d, ky2, g2));
+  y1 = wave_shr1(f1, ky1);
+  y2 = y1 - wave_shr1(f2, ky2);   // back to (y[-1], y[-2])
+  ky1 = lane63(f1);
+  ky2 = lane63(f2);               // carried in the (y1, y1 - y2) basis
   // (c) true recursion from the entering state
-  y1 = (float)e1;
-  y2 = (float)e2;
 #pragma unroll
   for (int i = 0; i < CHUNK; ++i) {
     const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
@@ -117,7 +159,7 @@ __device__ __forceinline__ void biquad_stage(float (&v)[CHUNK], const LufsArgs& 
 }
 
 template <int NS, bool VEC4, bool WRITE_Y>
-__global__ __launch_bounds__(256) void kweight_hop_energy(const LufsArgs A) {
+__global__ __launch_bounds__(256, AT_LUFS_WPS) void kweight_hop_energy(const LufsArgs A) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 64 * ROWF];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -136,32 +178,37 @@ __global__ __launch_bounds__(256) void kweight_hop_energy(const LufsArgs A) {
   start &= ~(int64_t)3;
   const float* __restrict__ xr = A.x + row * A.T;
 
-  // ---- per-lane scan constant Q = P^(lane+1) (f64), from the kernarg powers of P
-  M2 Q[NS];
+  // ---- per-lane scan matrices (built once per wave in f64 from the kernarg powers of P)
+  LaneMats Q[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    M2 acc = {1.0, 0.0, 0.0, 1.0};
-    const int e = lane + 1;
+    auto power = [&](int e) {
+      M2 acc = {1.0, 0.0, 0.0, 1.0};
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      if (e & (1 << i)) {
-        const M2 p = {A.Pp[s][i][0], A.Pp[s][i][1], A.Pp[s][i][2], A.Pp[s][i][3]};
-        acc = mmul(acc, p);
+      for (int i = 0; i < 7; ++i) {
+        if (e & (1 << i)) {
+          const M2 p = {A.Pp[s][i][0], A.Pp[s][i][1], A.Pp[s][i][2], A.Pp[s][i][3]};
+          acc = mmul(acc, p);
+        }
       }
-    }
-    Q[s] = acc;
+      return M2f{(float)acc.a, (float)acc.b, (float)acc.c, (float)acc.d};
+    };
+    Q[s].q16 = power((lane & 15) + 1);
+    Q[s].q32 = power((lane & 31) + 1);
+    Q[s].q64 = power(lane + 1);
   }
 
-  double ky1[NS], ky2[NS];  // output state entering the super-block, per stage
-  float kx1[NS], kx2[NS];   // input history entering the super-block, per stage
+  float ky1[NS], ky2[NS];  // output state entering the super-block, per stage
+  float kx1[NS], kx2[NS];  // input history entering the super-block, per stage
 #pragma unroll
-  for (int s = 0; s < NS; ++s) { ky1[s] = ky2[s] = 0.0; kx1[s] = kx2[s] = 0.f; }
+  for (int s = 0; s < NS; ++s) { ky1[s] = ky2[s] = 0.f; kx1[s] = kx2[s] = 0.f; }
 
   int h_cur = -1;
   double acc = 0.0;
 
-  for (int64_t sb = start; sb < n1; sb += SB) {
-    // ---- stage the 2048-sample tile through LDS (coalesced global reads)
+  // raw tile of one super-block in registers: 8 x float4 (VEC4) or 32 x float (scalar path)
+  float4 R[8];
+  auto load_tile = [&](int64_t sb) __attribute__((always_inline)) {
     if constexpr (VEC4) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -176,14 +223,40 @@ __global__ __launch_bounds__(256) void kweight_hop_energy(const LufsArgs A) {
           val.z = g + 2 < A.T ? xr[g + 2] : 0.f;
           val.w = 0.f;
         }
-        *reinterpret_cast<float4*>(slab + (p >> 3) * ROWF + (p & 7) * 4) = val;
+        R[i] = val;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < CHUNK; ++i) {
-        const int e = i * 64 + lane;
-        const int64_t g = sb + e;
-        slab[(e >> 5) * ROWF + (e & 31)] = g < A.T ? xr[g] : 0.f;
+      for (int i = 0; i < 8; ++i) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t g = sb + (4 * i + j) * 64 + lane;
+          e[j] = g < A.T ? xr[g] : 0.f;
+        }
+        R[i] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+  };
+  load_tile(start);
+
+  for (int64_t sb = start; sb < n1; sb += SB) {
+    // ---- transpose the 2048-sample tile through LDS: lane c ends up with samples 32c..32c+31
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = i * 64 + lane;
+        *reinterpret_cast<float4*>(slab + (p >> 3) * ROWF + (p & 7) * 4) = R[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float e[4] = {R[i].x, R[i].y, R[i].z, R[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = (4 * i + j) * 64 + lane;
+          slab[(idx >> 5) * ROWF + (idx & 31)] = e[j];
+        }
       }
     }
     at::wave_sync();
@@ -194,15 +267,16 @@ __global__ __launch_bounds__(256) void kweight_hop_energy(const LufsArgs A) {
       v[4 * i + 0] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
     }
     at::wave_sync();
+    // prefetch the next tile now: its HBM latency hides behind the ~700 VALU ops below
+    if (sb + SB < n1) load_tile(sb + SB);
 
     // ---- biquad cascade
 #define AT_STAGE(SI)                                                     \
     if constexpr (SI < NS) {                                             \
-      float hx1 = __shfl_up(v[CHUNK - 1], 1, 64);                        \
-      float hx2 = __shfl_up(v[CHUNK - 2], 1, 64);                        \
-      if (lane == 0) { hx1 = kx1[SI]; hx2 = kx2[SI]; }                   \
-      kx1[SI] = __shfl(v[CHUNK - 1], 63, 64);                            \
-      kx2[SI] = __shfl(v[CHUNK - 2], 63, 64);                            \
+      const float hx1 = wave_shr1(v[CHUNK - 1], kx1[SI]);                \
+      const float hx2 = wave_shr1(v[CHUNK - 2], kx2[SI]);                \
+      kx1[SI] = lane63(v[CHUNK - 1]);                                    \
+      kx2[SI] = lane63(v[CHUNK - 2]);                                    \
       biquad_stage<SI>(v, A, hx1, hx2, ky1[SI], ky2[SI], Q[SI], lane);   \
     }
     AT_STAGE(0) AT_STAGE(1) AT_STAGE(2) AT_STAGE(3)
@@ -400,7 +474,11 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
     }
     double P[4] = {p1, q1, p2, q2};  // (y[31],y[30]) = P (y[-1],y[-2])
     for (int i = 0; i < 7; ++i) {
-      for (int e = 0; e < 4; ++e) A.Pp[s][i][e] = P[e];
+      // stored in the basis (y1, y1 - y2): P' = T P T with T = T^-1 = [[1,0],[1,-1]].  A filter with
+      // poles next to z = 1 (the 38 Hz high-pass) has |entries of P| ~ 30 with opposite signs
+      // acting on two nearly equal states; in this basis the entries are O(1) and float32 is enough.
+      const double Pt[4] = {P[0] + P[1], -P[1], P[0] - P[2] + P[1] - P[3], -(P[1] - P[3])};
+      for (int e = 0; e < 4; ++e) { A.Pp[s][i][e] = Pt[e]; if (i < 4) A.Pf[s][i][e] = (float)Pt[e]; }
       const double n[4] = {P[0] * P[0] + P[1] * P[2], P[0] * P[1] + P[1] * P[3], P[2] * P[0] + P[3] * P[2],
                            P[2] * P[1] + P[3] * P[3]};
       for (int e = 0; e < 4; ++e) P[e] = n[e];
@@ -420,8 +498,8 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
   // segmentation in units of S samples ("hops") even on the general path
   const int64_t H_data = (T + S - 1) / S;
   A.H_data = (int)H_data;
-  // aim for >= 4096 waves, but keep segments >= 4x the warm-up unless the batch is tiny
-  int64_t seg = (rows * H_data + 4095) / 4096;
+  // aim for >= 8192 waves, but keep segments >= 4x the warm-up unless the batch is tiny
+  int64_t seg = (rows * H_data + 8191) / 8192;
   const int64_t min_seg = (4 * (int64_t)warm + S - 1) / S;
   if (seg < min_seg && rows * ((H_data + min_seg - 1) / min_seg) >= 1024) seg = min_seg;
   if (seg < 1) seg = 1;
