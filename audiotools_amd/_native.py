@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libaudiotools_amd.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["stft.hip", "loudness.hip"]
+SOURCES = ["stft.hip", "loudness.hip", "fir.hip", "fftconv.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -29,7 +29,8 @@ def hipcc_command(out=LIB_PATH):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
     extra = os.environ.get("AT_HIPCC_FLAGS", "").split()
-    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", out] + srcs
+    return ([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", out] + srcs
+            + ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -57,6 +58,10 @@ SIGNATURES = {
     "at_mel_units_host": (_i32, [_p, _i32, _i32, _p, _p]),
     "at_stft_mel_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
+    "at_fir_per_item_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "at_resample_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "at_fftconv_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
+    "at_fftconv_circ_f32": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _p]),
     "at_lufs_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32]),
     "at_lufs_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _i32, _i32, _i32, _f64, _f32,
                            _i32, _p, _p, _i64, _p]),

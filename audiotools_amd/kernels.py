@@ -135,3 +135,98 @@ def integrated_loudness(audio_bct: torch.Tensor, rate: int, filter_class: str = 
 def have(symbol: str) -> bool:
     """True when the loaded library exports ``symbol`` (kernels land incrementally)."""
     return hasattr(_native.lib(), symbol)
+
+
+# ------------------------------------------------------------------ FIR family
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False, replicate: bool = True):
+    """Per-item FIR with replicate padding.  ``taps`` (B or 1, L) odd-length, centred."""
+    _require_native_ok(audio)
+    assert replicate
+    B, C, T = audio.shape
+    audio = audio.contiguous()
+    rows, L = taps.shape
+    assert L % 2 == 1 and rows in (1, B)
+    half = (L - 1) // 2
+    Lp = _pad8(L)
+    tp = torch.zeros((rows, Lp), dtype=torch.float32, device=audio.device)
+    tp[:, :L] = taps.to(audio.device, torch.float32)
+    out = torch.empty_like(audio)
+    code = _native.lib().at_fir_per_item_f32(_native.ptr(audio), B, C, T, _native.ptr(tp), rows, Lp, half,
+                                             1 if highpass else 0, _native.ptr(out), _native.current_stream(audio.device))
+    _native.check(code, "at_fir_per_item_f32")
+    return out
+
+
+def sinc_taps_batched(cutoffs: torch.Tensor, zeros: float):
+    """Vectorised design of the per-item windowed-sinc low-pass taps of ``low_pass`` /
+    ``high_pass`` (dsp.py:177-179 -> julius.LowPassFilter): every item has its own length
+    2*half_i+1, ``half_i = int(zeros / c_i / 2)`` in float32 exactly as upstream; the rows are
+    centred in a common (B, 2*Hmax+1) array.  Runs on ``cutoffs.device``."""
+    c = cutoffs.reshape(-1).to(torch.float32)
+    if bool((c < 0).any()):
+        raise ValueError("Minimum cutoff must be larger than zero.")
+    if bool((c > 0.5).any()):
+        raise ValueError("A cutoff above 0.5 does not make sense.")
+    pos = c > 0
+    half = torch.where(pos, (zeros / torch.where(pos, c, torch.ones_like(c)) / 2).to(torch.int64), torch.zeros_like(c, dtype=torch.int64))
+    H = int(half.max())
+    n = torch.arange(-H, H + 1, device=c.device)
+    nf = n.to(torch.float32)[None, :]
+    hf = half.to(torch.float32)[:, None]
+    inside = n[None, :].abs() <= half[:, None]
+    # symmetric (non-periodic) Hann of length 2h+1 evaluated on the common grid
+    win = 0.5 - 0.5 * torch.cos(2 * math.pi * (nf + hf) / torch.clamp(2 * hf, min=1.0))
+    win = torch.where(half[:, None] == 0, torch.ones_like(win), win)
+    arg = 2 * c[:, None] * math.pi * nf
+    sinc = torch.where(arg == 0, torch.ones_like(arg), torch.sin(arg) / arg)
+    h = torch.where(inside, 2 * c[:, None] * win * sinc, torch.zeros_like(arg))
+    h = h / h.sum(-1, keepdim=True)
+    h = torch.where(pos[:, None], h, torch.zeros_like(h))
+    return h
+
+
+def sinc_filter(audio: torch.Tensor, cutoffs_norm: torch.Tensor, zeros: float, highpass: bool):
+    B = audio.shape[0]
+    taps = sinc_taps_batched(cutoffs_norm.to(audio.device).reshape(B), zeros)
+    return fir_per_item(audio, taps, highpass=highpass)
+
+
+def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
+    _require_native_ok(audio)
+    plan = tables.resample_sparse_bank(int(old_sr), int(new_sr))
+    if plan is None:
+        return audio
+    ws_np, k0_np, old, new, width, Wd = plan
+    dev = audio.device
+    ws, k0 = tables.device_table(("resample_sparse", old, new), dev, lambda: (ws_np, k0_np))
+    B, C, T = audio.shape
+    audio = audio.contiguous()
+    out_len = int(math.floor(new * T / old))
+    out = torch.empty((B, C, out_len), dtype=torch.float32, device=dev)
+    code = _native.lib().at_resample_f32(_native.ptr(audio), B * C, T, _native.ptr(ws), _native.ptr(k0), old, new, width,
+                                         Wd, _native.ptr(out), out_len, _native.current_stream(dev))
+    _native.check(code, "at_resample_f32")
+    return out
+
+
+def fftconv(x: torch.Tensor, ir: torch.Tensor, scale: torch.Tensor = None):
+    """Circular convolution of x (B,C,T) with ir (B,1|C,T) at length T, times scale (B,1|C,1)."""
+    _require_native_ok(x)
+    B, C, T = x.shape
+    Cir = ir.shape[1]
+    x = x.contiguous()
+    ir = ir.contiguous()
+    if scale is not None:
+        scale = scale.reshape(B, Cir).to(torch.float32).contiguous()
+    lib = _native.lib()
+    need = int(lib.at_fftconv_workspace_bytes(B, C, Cir, T))
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    out = torch.empty_like(x)
+    code = lib.at_fftconv_circ_f32(_native.ptr(x), _native.ptr(ir), _native.ptr(scale), B, C, Cir, T, _native.ptr(out),
+                                   _native.ptr(ws), need, _native.current_stream(x.device))
+    _native.check(code, "at_fftconv_circ_f32")
+    return out

@@ -303,3 +303,29 @@ def resample_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.
         k.div_(k.sum())
         rows.append(k)
     return torch.stack(rows), old, new, width
+
+
+@functools.lru_cache(None)
+def resample_sparse_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
+    """Sparse, transposed form of :func:`resample_bank` for ``at_resample_f32``: per output
+    phase only the contiguous run of taps with |t| < zeros is non-negligible (the cos^2 window
+    is ~1e-17 at the clamp), so the (new, 2w+old) bank is stored as ``ws[Wd, new]`` with the
+    run of phase i starting at dense index ``k0[i]``.  Returns
+    ``(ws float32, k0 int32, old, new, width, Wd)`` or None for equal rates."""
+    plan = resample_bank(old_sr, new_sr, zeros, rolloff)
+    if plan is None:
+        return None
+    bank, old, new, width = plan
+    b = bank.numpy()
+    thr = 1e-12 * np.abs(b).max()
+    k0 = np.zeros(new, dtype=np.int32)
+    k1 = np.zeros(new, dtype=np.int32)
+    for i in range(new):
+        nz = np.nonzero(np.abs(b[i]) > thr)[0]
+        k0[i], k1[i] = nz[0], nz[-1] + 1
+    Wd = int((k1 - k0).max())
+    k0 = np.minimum(k0, b.shape[1] - Wd).astype(np.int32)   # keep k0 + Wd inside the dense row
+    ws = np.zeros((Wd, new), dtype=np.float32)
+    for i in range(new):
+        ws[:, i] = b[i, k0[i]: k0[i] + Wd]
+    return ws, k0, old, new, width, Wd

@@ -88,6 +88,37 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
                 int nstage, int K, int S, double inv_norm, float floor_db, int warm, float* out, void* workspace,
                 int64_t workspace_bytes, void* stream);
 
+/* ---- per-item FIR (low_pass / high_pass / equalizer) ------------------------------------
+ * Replaces  audiotools/core/dsp.py:177-179, 209-211  (Python loop over the batch building a
+ *           julius.LowPassFilter / HighPassFilter per item) and  audiotools/core/effects.py:399-403,
+ *           429-432  (julius.SplitBands + weighted band sum, collapsed to one composite FIR per item).
+ *   x      (B, C, T) f32
+ *   taps   (taps_rows, L_padded) f32, taps_rows == 1 (shared) or B (per item); every row is an
+ *          odd-length FIR centred at index `half`, zero-padded to L_padded (multiple of 8)
+ *   out    (B, C, T): cross-correlation with replicate padding; highpass != 0 gives x - FIR(x)
+ */
+int at_fir_per_item_f32(const float* x, int64_t B, int64_t C, int64_t T, const float* taps, int taps_rows,
+                        int L_padded, int half, int highpass, float* out, void* stream);
+
+/* ---- polyphase resampling ---------------------------------------------------------------
+ * Replaces  audiotools/core/audio_signal.py:732  julius.resample_frac(x, old, new) (zeros 24,
+ *           rolloff 0.945): replicate pad (width, width+old), conv1d with the (new, 2*width+old)
+ *           bank at stride old, interleave phases, cut to floor(new*T/old).
+ *   ws (Wd, new_sr) f32, k0 (new_sr) i32: the bank stored sparse and transposed -- phase i uses
+ *          dense taps k0[i] .. k0[i]+Wd-1 (tables.resample_sparse_bank); old_sr/new_sr REDUCED.
+ */
+int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* ws, const int* k0, int old_sr, int new_sr,
+                    int width, int Wd, float* out, int64_t out_len, void* stream);
+
+/* ---- circular FFT convolution -----------------------------------------------------------
+ * Replaces  audiotools/core/effects.py:102-121  (rfft x 3, irfft x 2 at length T, rescale).
+ *   x (B,C,T), ir (B,Cir,T) with Cir == 1 or C (already padded/rolled), scale (B,Cir) or NULL,
+ *   out (B,C,T) = irfft(rfft(x) * rfft(ir)) * scale;  workspace: at_fftconv_workspace_bytes.
+ */
+int64_t at_fftconv_workspace_bytes(int64_t B, int64_t C, int64_t Cir, int64_t T);
+int at_fftconv_circ_f32(const float* x, const float* ir, const float* scale, int64_t B, int64_t C, int64_t Cir,
+                        int64_t T, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,89 @@
+"""The N > 1 path on CPU: world_size-2 gloo process group, batch sharding, table broadcast from
+rank 0, per-item results gathered back in batch order (audiotools_amd/dist.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.dont_write_bytecode = True
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import audiotools_amd as A
+    from audiotools_amd import dist as adist, tables
+    from oracle import restate
+    from tests import synth
+
+    r, w, device = adist.init(backend="gloo")
+    assert (r, w) == (rank, world) and device.type == "cpu"
+    B = 5
+    x = synth.audio_batch(B, 2, 16000, seed=21, gaps=False, sample_rate=16000)
+    lo, hi = adist.shard_range(B, rank, world)
+    # shared table: only rank 0 builds it (other ranks would produce garbage on purpose)
+    key = ("window", "hann", 512)
+    built = []
+
+    def builder():
+        built.append(rank)
+        return tables.window_np("hann", 512) if rank == 0 else np.full(512, np.nan, dtype=np.float32)
+
+    win = adist.broadcast_table(key, builder, device)
+    assert built == ([0] if rank == 0 else [])
+    assert torch.equal(win, torch.from_numpy(tables.window_np("hann", 512)))
+    # a tuple-valued table
+    tup = adist.broadcast_table(("t", 1), lambda: (np.arange(6, dtype=np.int32).reshape(3, 2), np.ones(4, np.float32)), device)
+    assert tup[0].shape == (3, 2) and tup[0].dtype == torch.int32 and float(tup[1].sum()) == 4.0
+    # the data path: each rank processes its slab, no collective
+    sig = A.AudioSignal(x[lo:hi].clone(), 16000)
+    lufs_local = sig.loudness()
+    mel_local = sig.mel_spectrogram(40)
+    full = adist.gather_items(lufs_local, B)
+    adist.barrier()
+    if rank == 0:
+        ref = restate.loudness(x, 16000)
+        q.put(("lufs", float((full - ref).abs().max())))
+        q.put(("mel_shape", tuple(mel_local.shape)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shard_and_broadcast():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = dict(q.get(timeout=5) for _ in range(2))
+    assert got["lufs"] < 1e-4
+    assert got["mel_shape"] == (3, 2, 40, 126)
+
+
+def test_shard_range_partitions_batch():
+    from audiotools_amd import dist as adist
+
+    for B in (1, 5, 8, 512, 513):
+        for W in (1, 2, 3, 8):
+            spans = [adist.shard_range(B, r, W) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -187,3 +187,92 @@ def test_loudness_segmentation_invariance():
     ref = restate.loudness(x, 44100)
     assert float((one - ref).abs().max()) < LU
     assert float((many - one).abs().max()) < 1e-4
+
+
+# ------------------------------------------------------- FIR / resample / convolve rows
+def test_effects_golden_cfg4():
+    d = np.load(os.path.join(G, "effects_cfg4.npz"))
+    x = torch.from_numpy(d["x"])
+    s = lambda: A.AudioSignal(x.clone(), 48000).to("cuda")
+    assert rel_err(s().low_pass(torch.from_numpy(d["lp_cut"])).audio_data, torch.from_numpy(d["low_pass"])) < REL
+    assert rel_err(s().high_pass(torch.tensor([500.0, 1000.0, 2000.0])).audio_data, torch.from_numpy(d["high_pass"])) < REL
+    assert rel_err(s().equalizer(torch.from_numpy(d["eq_db"])).audio_data, torch.from_numpy(d["equalizer"])) < REL
+    ir = A.AudioSignal(torch.from_numpy(d["ir"]).clone(), 48000).to("cuda")
+    assert rel_err(s().convolve(ir).audio_data, torch.from_numpy(d["convolve"])) < REL
+    assert rel_err(s().resample(16000).audio_data, torch.from_numpy(d["resample_48k_16k"])) < REL
+    xr = torch.from_numpy(d["xr"])
+    assert rel_err(A.AudioSignal(xr, 44100).to("cuda").resample(16000).audio_data, torch.from_numpy(d["resample_441_16k"])) < REL
+
+
+@pytest.mark.parametrize("highpass", [False, True])
+def test_sinc_filters_vs_oracle(highpass):
+    """Per-item cutoffs incl. a very long filter (50 Hz -> 44 983 taps) and odd lengths."""
+    x = synth.audio_batch(4, 2, 30001, seed=31, gaps=False)
+    cut = torch.tensor([4000.0, 16000.0, 300.0, 50.0])
+    s = A.AudioSignal(x.clone(), 44100).to("cuda")
+    got = (s.high_pass(cut) if highpass else s.low_pass(cut)).audio_data
+    ref = restate.high_pass(x, cut, 44100) if highpass else restate.low_pass(x, cut, 44100)
+    assert rel_err(got, ref) < REL
+    assert s.stft_data is None
+
+
+def test_reference_dsp_properties_gpu():
+    """tests/core/test_dsp.py:76-109 on the HIP path."""
+    sr, f = 44100, 440
+    t = torch.arange(0, 1, 1 / sr)
+    sw = (torch.sin(2 * np.pi * f * t) * restate.get_window("hann", t.shape[-1]))[None, None]
+    sig = A.AudioSignal(sw.repeat(3, 1, 1), sr).to("cuda")
+    out = sig.clone().low_pass(torch.tensor([220.0, 880.0, 220.0])).audio_data
+    assert out[0].abs().max() < 1e-4 and out[2].abs().max() < 1e-4
+    assert (out[1] - sig.audio_data[1]).abs().max() < 1e-3
+    assert (sig.clone().high_pass(220).audio_data - sig.audio_data).abs().max() < 1e-4
+    with pytest.raises(ValueError):
+        sig.clone().low_pass(30000.0)
+
+
+@pytest.mark.parametrize("old,new", [(44100, 16000), (16000, 44100), (48000, 44100), (44100, 22050), (16000, 8000), (44100, 48000)])
+def test_resample_vs_oracle(old, new):
+    x = synth.audio_batch(3, 2, old // 2 + 13, seed=old % 97, gaps=False)
+    got = A.AudioSignal(x.clone(), old).to("cuda").resample(new)
+    ref = restate.resample(x, old, new)
+    assert got.sample_rate == new and got.audio_data.shape == ref.shape
+    assert rel_err(got.audio_data, ref) < REL
+
+
+def test_equalizer_and_filterbank_properties():
+    """tests/core/test_effects.py:184-231: zero-dB EQ is the identity; per-item curves match the oracle."""
+    x = synth.audio_batch(3, 2, 24000, seed=41, gaps=False)
+    s = A.AudioSignal(x.clone(), 44100).to("cuda")
+    assert float((s.clone().equalizer(torch.zeros(3, 6)).audio_data.cpu() - x).abs().max()) < 1e-5
+    db = -torch.rand(3, 8, generator=torch.Generator().manual_seed(2))
+    assert rel_err(s.clone().equalizer(db).audio_data, restate.equalizer(x, 44100, db)) < REL
+    fb = s.clone().mel_filterbank(8)
+    assert float((fb.sum(-1).cpu() - x).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("T,Lir", [(24000, 9600), (16000, 16000), (10007, 20000)])
+def test_convolve_vs_oracle(T, Lir):
+    """Circular FFT convolution incl. a prime length (Bluestein in rocFFT) and IR longer than the signal."""
+    x = synth.audio_batch(3, 2, T, seed=T % 89, gaps=False)
+    g = torch.Generator().manual_seed(7)
+    ir = torch.randn(3, 1, Lir, generator=g) * torch.exp(-torch.arange(Lir) / (0.1 * Lir))
+    got = A.AudioSignal(x.clone(), 16000).to("cuda").convolve(A.AudioSignal(ir.clone(), 16000).to("cuda"))
+    assert rel_err(got.audio_data, restate.convolve(x, ir)) < REL
+    # identity: (delayed) unit impulse returns the input (tests/core/test_effects.py:86-121)
+    imp = torch.zeros(3, 1, T)
+    imp[..., 777] = 1
+    back = A.AudioSignal(x.clone(), 16000).to("cuda").convolve(A.AudioSignal(imp, 16000).to("cuda"))
+    assert float((back.audio_data.cpu() - x).abs().max()) < 1e-5
+
+
+def test_apply_ir_and_normalize():
+    x = synth.audio_batch(3, 1, 32000, seed=51, gaps=False, sample_rate=16000)
+    g = torch.Generator().manual_seed(8)
+    ir = torch.randn(3, 1, 8000, generator=g) * torch.exp(-torch.arange(8000) / 1500.0)
+    s = A.AudioSignal(x.clone(), 16000).to("cuda")
+    y = s.clone().apply_ir(A.AudioSignal(ir.clone(), 16000).to("cuda"), drr=torch.tensor([5.0, 10.0, 15.0]),
+                           ir_eq=-torch.rand(3, 6, generator=g))
+    # apply_ir restores the input peak (effects.py:175-177)
+    assert torch.allclose(y.audio_data.abs().amax(-1), s.audio_data.abs().amax(-1), rtol=1e-4)
+    n = s.clone().normalize(-30.0)
+    assert float((n.loudness().cpu() + 30.0).abs().max()) < 0.1
