@@ -1,0 +1,2 @@
+"""Import-path compatibility with the reference (``audiotools.data.transforms``)."""
+from .. import transforms  # noqa: F401

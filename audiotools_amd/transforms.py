@@ -1,0 +1,609 @@
+"""Batched, seeded audio transforms with the reference's two-phase protocol
+(``audiotools/data/transforms.py:21-265``):
+
+1. ``kwargs = tfm.instantiate(state, signal)`` draws this transform's parameters from a
+   seeded ``RandomState`` (cheap, CPU, one item) -- ``batch_instantiate`` collates a list of
+   them into batched tensors;
+2. ``signal = tfm(signal, **kwargs)`` applies them to a (device) batch, only to the items
+   whose ``mask`` is set.
+
+Parameters live under ``kwargs[tfm.name]``; ``Compose`` prefixes child names with their
+position so nested dictionaries never collide.  Every hot transform bottoms out in an
+``AudioSignal`` method that runs on the HIP kernels (``low_pass`` / ``high_pass`` /
+``equalizer`` -> ``at_fir_per_item_f32``; ``apply_ir`` / ``convolve`` -> ``at_fftconv_circ_f32``;
+``normalize`` / ``mix`` -> ``at_lufs_f32``; the spectral family -> ``at_stft_mel_f32``).
+
+Most concrete transforms are pure "draw parameters, call one method" recipes; they are built
+from the declarative :class:`_Recipe` base instead of one hand-written class each.  File-backed
+sources (``AudioLoader``) are outside the accelerated path: transforms that need other audio
+(``BackgroundNoise``, ``CrossTalk``, ``RoomImpulseResponse``) take any ``loader`` callable with
+the ``AudioLoader.__call__`` signature; :class:`TensorLoader` serves items from an in-memory
+(device-resident, broadcastable) bank.
+"""
+import copy
+from contextlib import contextmanager
+from inspect import signature
+from typing import List
+
+import numpy as np
+import torch
+
+from . import util
+from .signal import AudioSignal
+
+tt = torch.tensor
+
+
+def _flatten(d, prefix=()):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict) and v:
+            out.update(_flatten(v, prefix + (k,)))
+        else:
+            out[prefix + (k,)] = v
+    return out
+
+
+def _unflatten(d):
+    out = {}
+    for ks, v in d.items():
+        cur = out
+        for k in ks[:-1]:
+            cur = cur.setdefault(k, {})
+        cur[ks[-1]] = v
+    return out
+
+
+class BaseTransform:
+    """Base of all transforms.  Subclasses implement ``_instantiate(state[, signal]) -> dict``
+    and ``_transform(signal, **params) -> signal``; the parameter names of ``_transform`` (plus
+    ``mask``) are the keys the transform expects in its kwargs."""
+
+    def __init__(self, keys: list = [], name: str = None, prob: float = 1.0):
+        own = [k for k in signature(self._transform).parameters.keys() if k not in ("signal", "kwargs")]
+        self.keys = list(keys) + own + ["mask"]
+        self.prob = prob
+        self.name = self.__class__.__name__ if name is None else name
+
+    def _prepare(self, batch: dict):
+        sub = batch[self.name]
+        for k in self.keys:
+            assert k in sub.keys(), f"{k} not in batch"
+        return sub
+
+    def _transform(self, signal):
+        return signal
+
+    def _instantiate(self, state, signal: AudioSignal = None):
+        return {}
+
+    @staticmethod
+    def apply_mask(batch: dict, mask: torch.Tensor):
+        return _unflatten({k: v[mask] for k, v in _flatten(batch).items()})
+
+    def transform(self, signal: AudioSignal, **kwargs):
+        params = self._prepare(kwargs)
+        mask = params["mask"]
+        if torch.any(mask):
+            params = self.apply_mask(params, mask)
+            params = {k: v for k, v in params.items() if k != "mask"}
+            if bool(torch.all(mask)) and mask.ndim == 1 and mask.numel() == signal.batch_size:
+                # Every item selected: transform in place instead of the reference's gather ->
+                # transform -> scatter copy of the whole batch (transforms.py:159-164).  The cache
+                # semantics of that round trip are reproduced: AudioSignal.__setitem__ only writes
+                # _loudness / stft_data back when BOTH sides have them (audio_signal.py:1672-1679).
+                loud0, stft0 = signal._loudness, signal.stft_data
+                out = self._transform(signal, **params)
+                loud1, stft1 = out._loudness, out.stft_data
+                if out is not signal:
+                    signal.audio_data[...] = out.audio_data
+                signal._loudness = None if loud0 is None else (loud0 if loud1 is None else loud1)
+                signal._stft_data = None if stft0 is None else (stft0 if stft1 is None else stft1)
+            else:
+                signal[mask] = self._transform(signal[mask], **params)
+        return signal
+
+    def __call__(self, *args, **kwargs):
+        return self.transform(*args, **kwargs)
+
+    def instantiate(self, state=None, signal: AudioSignal = None):
+        state = util.random_state(state)
+        needs_signal = "signal" in set(signature(self._instantiate).parameters.keys())
+        params = self._instantiate(state, **({"signal": signal} if needs_signal else {}))
+        for k, v in list(params.items()):
+            if not isinstance(v, (AudioSignal, torch.Tensor, dict)):
+                params[k] = tt(v)
+        params["mask"] = tt(state.rand() <= self.prob)
+        return {self.name: params}
+
+    def batch_instantiate(self, states: list = None, signal: AudioSignal = None):
+        return util.collate([self.instantiate(s, signal) for s in states])
+
+
+class Identity(BaseTransform):
+    """Does nothing (audiotools/data/transforms.py:268-271)."""
+
+
+class SpectralTransform(BaseTransform):
+    """STFT before, inverse STFT after (transforms.py:274-286)."""
+
+    def transform(self, signal, **kwargs):
+        signal.stft()
+        super().transform(signal, **kwargs)
+        signal.istft()
+        return signal
+
+
+class Compose(BaseTransform):
+    """Apply child transforms in sequence; children are renamed ``"{position}.{name}"``
+    (transforms.py:289-424)."""
+
+    def __init__(self, *transforms: list, name: str = None, prob: float = 1.0):
+        if isinstance(transforms[0], list):
+            transforms = transforms[0]
+        for i, t in enumerate(transforms):
+            t.name = f"{i}.{t.name}"
+        keys = [t.name for t in transforms]
+        super().__init__(keys=keys, name=name, prob=prob)
+        self.transforms = transforms
+        self.transforms_to_apply = keys
+
+    @contextmanager
+    def filter(self, *names: list):
+        """Temporarily restrict which children run (matched by substring of their name)."""
+        old = self.transforms_to_apply
+        self.transforms_to_apply = names
+        yield
+        self.transforms_to_apply = old
+
+    def _transform(self, signal, **kwargs):
+        for t in self.transforms:
+            if any(x in t.name for x in self.transforms_to_apply):
+                signal = t(signal, **kwargs)
+        return signal
+
+    def _instantiate(self, state, signal: AudioSignal = None):
+        params = {}
+        for t in self.transforms:
+            params.update(t.instantiate(state, signal=signal))
+        return params
+
+    def __getitem__(self, idx):
+        return self.transforms[idx]
+
+    def __len__(self):
+        return len(self.transforms)
+
+    def __iter__(self):
+        return iter(self.transforms)
+
+
+class Choose(Compose):
+    """Exactly one child (drawn per item with ``weights``) is applied (transforms.py:427-475)."""
+
+    def __init__(self, *transforms: list, weights: list = None, name: str = None, prob: float = 1.0):
+        super().__init__(*transforms, name=name, prob=prob)
+        n = len(self.transforms)
+        self.weights = np.array([1 / n] * n if weights is None else weights)
+
+    def _instantiate(self, state, signal: AudioSignal = None):
+        kwargs = super()._instantiate(state, signal)
+        pick = state.choice(list(range(len(self.transforms))), p=self.weights)
+        one_hot = []
+        for i, t in enumerate(self.transforms):
+            if kwargs[t.name]["mask"].item():
+                kwargs[t.name]["mask"] = tt(i == pick)
+            one_hot.append(kwargs[t.name]["mask"])
+        kwargs["one_hot"] = one_hot
+        return kwargs
+
+
+class Repeat(Compose):
+    """The same transform ``n_repeat`` times (transforms.py:478-500)."""
+
+    def __init__(self, transform, n_repeat: int = 1, name: str = None, prob: float = 1.0):
+        super().__init__([copy.copy(transform) for _ in range(n_repeat)], name=name, prob=prob)
+        self.n_repeat = n_repeat
+
+
+class RepeatUpTo(Choose):
+    """The transform repeated 1 .. max_repeat-1 times, count drawn per item (transforms.py:503-528)."""
+
+    def __init__(self, transform, max_repeat: int = 5, weights: list = None, name: str = None, prob: float = 1.0):
+        super().__init__([Repeat(transform, n_repeat=n) for n in range(1, max_repeat)], name=name, prob=prob,
+                         weights=weights)
+        self.max_repeat = max_repeat
+
+
+# -------------------------------------------------------------------- recipes
+class _Recipe(BaseTransform):
+    """Declarative transform: ``DISTS`` maps parameter name -> default distribution tuple
+    (overridable through same-named constructor kwargs), ``METHOD`` is the AudioSignal method
+    called with the drawn parameters, ``FIXED`` are extra constructor kwargs forwarded to the
+    method as-is."""
+
+    DISTS = {}
+    FIXED = {}
+    METHOD = None
+    RENAME = {}     # transform parameter name -> method keyword
+    PROB = 1.0
+    BASE = BaseTransform
+
+    def __init__(self, *args, name: str = None, prob: float = None, **kwargs):
+        names = list(self.DISTS) + list(self.FIXED)
+        given = dict(zip(names, args))
+        given.update(kwargs)
+        unknown = set(given) - set(names)
+        if unknown:
+            raise TypeError(f"{type(self).__name__}: unexpected arguments {sorted(unknown)}")
+        for k, v in {**self.DISTS, **self.FIXED}.items():
+            setattr(self, k, given.get(k, v))
+        BaseTransform.__init__(self, keys=list(self.DISTS), name=name, prob=self.PROB if prob is None else prob)
+
+    def _instantiate(self, state):
+        return {k: util.sample_from_dist(getattr(self, k), state) for k in self.DISTS}
+
+    def _transform(self, signal, **kwargs):
+        kw = {self.RENAME.get(k, k): v for k, v in kwargs.items()}
+        kw.update({k: getattr(self, k) for k in self.FIXED})
+        return getattr(signal, self.METHOD)(**kw)
+
+
+class ClippingDistortion(_Recipe):
+    """Clip to the ``perc`` quantiles (transforms.py:531-561)."""
+    DISTS = {"perc": ("uniform", 0.0, 0.1)}
+    METHOD = "clip_distortion"
+    RENAME = {"perc": "clip_percentile"}
+
+
+class Quantization(_Recipe):
+    """Linear quantisation to ``channels`` levels (transforms.py:603-633)."""
+    DISTS = {"channels": ("choice", [8, 32, 128, 256, 1024])}
+    METHOD = "quantization"
+    RENAME = {"channels": "quantization_channels"}
+
+
+class MuLawQuantization(_Recipe):
+    """Mu-law quantisation (transforms.py:636-666)."""
+    DISTS = {"channels": ("choice", [8, 32, 128, 256, 1024])}
+    METHOD = "mulaw_quantization"
+    RENAME = {"channels": "quantization_channels"}
+
+
+class VolumeChange(_Recipe):
+    """Gain in dB (transforms.py:941-970)."""
+    DISTS = {"db": ("uniform", -12.0, 0.0)}
+    METHOD = "volume_change"
+
+
+class VolumeNorm(_Recipe):
+    """Normalise every item to ``db`` LUFS (transforms.py:973-1003)."""
+    DISTS = {"db": ("const", -24)}
+    METHOD = "normalize"
+
+
+class LowPass(_Recipe):
+    """Per-item windowed-sinc low-pass (transforms.py:1095-1131)."""
+    DISTS = {"cutoff": ("choice", [4000, 8000, 16000])}
+    FIXED = {"zeros": 51}
+    METHOD = "low_pass"
+    RENAME = {"cutoff": "cutoffs"}
+
+
+class HighPass(_Recipe):
+    """Per-item windowed-sinc high-pass (transforms.py:1134-1170)."""
+    DISTS = {"cutoff": ("choice", [50, 100, 250, 500, 1000])}
+    FIXED = {"zeros": 51}
+    METHOD = "high_pass"
+    RENAME = {"cutoff": "cutoffs"}
+
+
+class _SpectralRecipe(_Recipe):
+    """A recipe wrapped in stft() ... istft() like SpectralTransform."""
+
+    def transform(self, signal, **kwargs):
+        signal.stft()
+        BaseTransform.transform(self, signal, **kwargs)
+        signal.istft()
+        return signal
+
+
+class ShiftPhase(_SpectralRecipe):
+    """Add a constant to the STFT phase (transforms.py:1200-1229)."""
+    DISTS = {"shift": ("uniform", -np.pi, np.pi)}
+    METHOD = "shift_phase"
+
+
+class InvertPhase(ShiftPhase):
+    """Phase shift of pi (transforms.py:1232-1247)."""
+    DISTS = {"shift": ("const", np.pi)}
+
+
+class MaskLowMagnitudes(_SpectralRecipe):
+    """Zero bins below ``db_cutoff`` (transforms.py:1372-1402)."""
+    DISTS = {"db_cutoff": ("uniform", -10, 10)}
+    METHOD = "mask_low_magnitudes"
+
+
+class RescaleAudio(BaseTransform):
+    """Scale down items that peak above ``val`` (transforms.py:1173-1197)."""
+
+    def __init__(self, val: float = 1.0, name: str = None, prob: float = 1):
+        super().__init__(name=name, prob=prob)
+        self.val = val
+
+    def _transform(self, signal):
+        return signal.ensure_max_of_audio(self.val)
+
+
+class Silence(BaseTransform):
+    """Replace the item by digital silence, keeping its cached loudness (transforms.py:1066-1092)."""
+
+    def __init__(self, name: str = None, prob: float = 0.1):
+        super().__init__(name=name, prob=prob)
+
+    def _transform(self, signal):
+        loud = signal._loudness
+        signal = AudioSignal(torch.zeros_like(signal.audio_data), sample_rate=signal.sample_rate,
+                             stft_params=signal.stft_params)
+        signal._loudness = loud
+        return signal
+
+
+class Equalizer(BaseTransform):
+    """Random mel-band attenuation curve ``-eq_amount * U(0,1)^n_bands`` (transforms.py:564-600)."""
+
+    def __init__(self, eq_amount: tuple = ("const", 1.0), n_bands: int = 6, name: str = None, prob: float = 1.0):
+        super().__init__(name=name, prob=prob)
+        self.eq_amount = eq_amount
+        self.n_bands = n_bands
+
+    def _instantiate(self, state):
+        return {"eq": -util.sample_from_dist(self.eq_amount, state) * state.rand(self.n_bands)}
+
+    def _transform(self, signal, eq):
+        return signal.equalizer(eq)
+
+
+class NoiseFloor(BaseTransform):
+    """Add white noise normalised to ``db`` LUFS (transforms.py:669-704)."""
+
+    def __init__(self, db: tuple = ("const", -50.0), name: str = None, prob: float = 1.0):
+        super().__init__(name=name, prob=prob)
+        self.db = db
+
+    def _instantiate(self, state, signal: AudioSignal):
+        db = util.sample_from_dist(self.db, state)
+        nz = AudioSignal(state.randn(signal.num_channels, signal.signal_length), signal.sample_rate)
+        nz.normalize(db)
+        return {"nz_signal": nz}
+
+    def _transform(self, signal, nz_signal):
+        return signal + nz_signal
+
+
+class GlobalVolumeNorm(BaseTransform):
+    """Bring the FILE-level loudness in ``signal.metadata["loudness"]`` to ``db`` (transforms.py:1006-1063)."""
+
+    def __init__(self, db: tuple = ("const", -24), name: str = None, prob: float = 1.0):
+        super().__init__(name=name, prob=prob)
+        self.db = db
+
+    def _instantiate(self, state, signal: AudioSignal):
+        loud = signal.metadata.get("loudness")
+        if loud is None or float(loud) == float("-inf"):
+            return {"db": 0.0}
+        return {"db": util.sample_from_dist(self.db, state) - float(loud)}
+
+    def _transform(self, signal, db):
+        return signal.volume_change(db)
+
+
+# ------------------------------------------------------- sources of other audio
+class TensorLoader:
+    """In-memory replacement for ``AudioLoader`` (audiotools/data/datasets.py:71-136) on the
+    accelerated path: serves excerpts from a bank of signals that already sit in memory (e.g.
+    an impulse-response bank broadcast to every GPU).  ``bank`` is an AudioSignal (items along
+    the batch axis) or a (N, C, T) tensor with ``sample_rate``."""
+
+    def __init__(self, bank, sample_rate: int = None, weights: List[float] = None):
+        self.bank = bank if isinstance(bank, AudioSignal) else AudioSignal(bank, sample_rate)
+        self.weights = None if weights is None else np.asarray(weights, dtype=np.float64) / np.sum(weights)
+
+    def __call__(self, state, sample_rate: int, duration: float, loudness_cutoff: float = -40,
+                 num_channels: int = 1, offset: float = None, **kwargs):
+        idx = int(state.choice(self.bank.batch_size, p=self.weights))
+        sig = self.bank[idx: idx + 1].clone()
+        n = int(duration * sig.sample_rate)
+        if offset is None:
+            hi = max(sig.signal_length - n, 0)
+            start = int(state.randint(0, hi + 1)) if hi > 0 else 0
+        else:
+            start = int(offset * sig.sample_rate)
+        sig.audio_data = sig.audio_data[..., start: start + n]
+        if num_channels == 1:
+            sig = sig.to_mono()
+        sig = sig.resample(sample_rate)
+        if duration is not None:
+            sig = sig.zero_pad_to(int(duration * sample_rate))
+        return {"signal": sig, "source_idx": 0, "item_idx": idx, "source": "tensor", "path": ""}
+
+
+def _resolve_loader(sources, weights, loader, who):
+    if loader is not None:
+        return loader
+    if sources is None:
+        return None
+    raise NotImplementedError(
+        f"{who}: file-backed `sources` need the reference's AudioLoader (file I/O is outside the "
+        f"accelerated path, SURVEY.md 2.1); pass loader=TensorLoader(bank, sample_rate) or any callable "
+        f"with the AudioLoader.__call__ signature")
+
+
+class BackgroundNoise(BaseTransform):
+    """Mix in another signal at ``snr`` dB with a random EQ (transforms.py:707-792)."""
+
+    def __init__(self, snr: tuple = ("uniform", 10.0, 30.0), sources: List[str] = None, weights: List[float] = None,
+                 eq_amount: tuple = ("const", 1.0), n_bands: int = 3, name: str = None, prob: float = 1.0,
+                 loudness_cutoff: float = None, loader=None):
+        super().__init__(name=name, prob=prob)
+        self.snr, self.eq_amount, self.n_bands = snr, eq_amount, n_bands
+        self.loader = _resolve_loader(sources, weights, loader, "BackgroundNoise")
+        self.loudness_cutoff = loudness_cutoff
+
+    def _instantiate(self, state, signal: AudioSignal):
+        eq = -util.sample_from_dist(self.eq_amount, state) * state.rand(self.n_bands)
+        snr = util.sample_from_dist(self.snr, state)
+        bg = self.loader(state, signal.sample_rate, duration=signal.signal_duration,
+                         loudness_cutoff=self.loudness_cutoff, num_channels=signal.num_channels)["signal"]
+        return {"eq": eq, "bg_signal": bg, "snr": snr}
+
+    def _transform(self, signal, bg_signal, snr, eq):
+        return signal.mix(bg_signal.clone(), snr, eq)
+
+
+class CrossTalk(BaseTransform):
+    """Mix in another talker and restore the original loudness (transforms.py:795-854)."""
+
+    def __init__(self, snr: tuple = ("uniform", 0.0, 10.0), sources: List[str] = None, weights: List[float] = None,
+                 name: str = None, prob: float = 1.0, loudness_cutoff: float = -40, loader=None):
+        super().__init__(name=name, prob=prob)
+        self.snr = snr
+        self.loader = _resolve_loader(sources, weights, loader, "CrossTalk")
+        self.loudness_cutoff = loudness_cutoff
+
+    def _instantiate(self, state, signal: AudioSignal):
+        snr = util.sample_from_dist(self.snr, state)
+        other = self.loader(state, signal.sample_rate, duration=signal.signal_duration,
+                            loudness_cutoff=self.loudness_cutoff, num_channels=signal.num_channels)["signal"]
+        return {"crosstalk_signal": other, "snr": snr}
+
+    def _transform(self, signal, crosstalk_signal, snr):
+        loudness = signal.loudness()
+        mix = signal.mix(crosstalk_signal.clone(), snr)
+        mix.normalize(loudness)
+        return mix
+
+
+class RoomImpulseResponse(BaseTransform):
+    """Convolve with a room impulse response with random EQ and direct-to-reverberant ratio
+    (transforms.py:857-938)."""
+
+    def __init__(self, drr: tuple = ("uniform", 0.0, 30.0), sources: List[str] = None, weights: List[float] = None,
+                 eq_amount: tuple = ("const", 1.0), n_bands: int = 6, name: str = None, prob: float = 1.0,
+                 use_original_phase: bool = False, offset: float = 0.0, duration: float = 1.0, loader=None):
+        super().__init__(name=name, prob=prob)
+        self.drr, self.eq_amount, self.n_bands = drr, eq_amount, n_bands
+        self.use_original_phase = use_original_phase
+        self.loader = _resolve_loader(sources, weights, loader, "RoomImpulseResponse")
+        self.offset, self.duration = offset, duration
+
+    def _instantiate(self, state, signal: AudioSignal = None):
+        eq = -util.sample_from_dist(self.eq_amount, state) * state.rand(self.n_bands)
+        drr = util.sample_from_dist(self.drr, state)
+        ir = self.loader(state, signal.sample_rate, offset=self.offset, duration=self.duration,
+                         loudness_cutoff=None, num_channels=signal.num_channels)["signal"]
+        ir.zero_pad_to(signal.sample_rate)
+        return {"eq": eq, "ir_signal": ir, "drr": drr}
+
+    def _transform(self, signal, ir_signal, drr, eq):
+        return signal.apply_ir(ir_signal.clone(), drr, eq, use_original_phase=self.use_original_phase)
+
+
+class Smoothing(BaseTransform):
+    """Convolve with a short window, keep the input peak (transforms.py:1405-1453)."""
+
+    def __init__(self, window_type: tuple = ("const", "average"),
+                 window_length: tuple = ("choice", [8, 16, 32, 64, 128, 256, 512]), name: str = None, prob: float = 1):
+        super().__init__(name=name, prob=prob)
+        self.window_type, self.window_length = window_type, window_length
+
+    def _instantiate(self, state, signal: AudioSignal = None):
+        wt = util.sample_from_dist(self.window_type, state)
+        wl = util.sample_from_dist(self.window_length, state)
+        window = signal.get_window(window_type=wt, window_length=wl, device="cpu")
+        return {"window": AudioSignal(window, signal.sample_rate)}
+
+    def _transform(self, signal, window):
+        sscale = signal.audio_data.abs().max(dim=-1, keepdim=True).values
+        sscale = torch.where(sscale == 0.0, torch.ones_like(sscale), sscale)
+        out = signal.convolve(window)
+        oscale = out.audio_data.abs().max(dim=-1, keepdim=True).values
+        oscale = torch.where(oscale == 0.0, torch.ones_like(oscale), oscale)
+        return out * (sscale / oscale)
+
+
+class CorruptPhase(SpectralTransform):
+    """Add Gaussian noise to the STFT phase (transforms.py:1250-1278)."""
+
+    def __init__(self, scale: tuple = ("uniform", 0, np.pi), name: str = None, prob: float = 1):
+        super().__init__(name=name, prob=prob)
+        self.scale = scale
+
+    def _instantiate(self, state, signal: AudioSignal = None):
+        scale = util.sample_from_dist(self.scale, state)
+        corruption = state.normal(scale=scale, size=signal.phase.shape[1:])
+        return {"corruption": corruption.astype("float32")}
+
+    def _transform(self, signal, corruption):
+        return signal.shift_phase(shift=corruption)
+
+
+class FrequencyMask(SpectralTransform):
+    """Zero a band of relative width ``f_width`` around ``f_center`` (transforms.py:1281-1324)."""
+
+    def __init__(self, f_center: tuple = ("uniform", 0.0, 1.0), f_width: tuple = ("const", 0.1), name: str = None,
+                 prob: float = 1):
+        super().__init__(name=name, prob=prob)
+        self.f_center, self.f_width = f_center, f_width
+
+    def _instantiate(self, state, signal: AudioSignal):
+        c = util.sample_from_dist(self.f_center, state)
+        w = util.sample_from_dist(self.f_width, state)
+        nyq = signal.sample_rate / 2
+        return {"fmin_hz": nyq * max(c - (w / 2), 0.0), "fmax_hz": nyq * min(c + (w / 2), 1.0)}
+
+    def _transform(self, signal, fmin_hz: float, fmax_hz: float):
+        return signal.mask_frequencies(fmin_hz=fmin_hz, fmax_hz=fmax_hz)
+
+
+class TimeMask(SpectralTransform):
+    """Zero a time span of relative width ``t_width`` around ``t_center`` (transforms.py:1327-1369)."""
+
+    def __init__(self, t_center: tuple = ("uniform", 0.0, 1.0), t_width: tuple = ("const", 0.025), name: str = None,
+                 prob: float = 1):
+        super().__init__(name=name, prob=prob)
+        self.t_center, self.t_width = t_center, t_width
+
+    def _instantiate(self, state, signal: AudioSignal):
+        c = util.sample_from_dist(self.t_center, state)
+        w = util.sample_from_dist(self.t_width, state)
+        dur = signal.signal_duration
+        return {"tmin_s": dur * max(c - (w / 2), 0.0), "tmax_s": dur * min(c + (w / 2), 1.0)}
+
+    def _transform(self, signal, tmin_s: float, tmax_s: float):
+        return signal.mask_timesteps(tmin_s=tmin_s, tmax_s=tmax_s)
+
+
+def _fill_masked_with_noise(signal):
+    mag, phase = signal.magnitude, signal.phase
+    hole = (mag == 0.0) * (phase == 0.0)
+    mag = torch.where(hole, torch.randn_like(mag), mag)
+    phase = torch.where(hole, torch.randn_like(phase), phase)
+    signal.magnitude = mag
+    signal.phase = phase
+    return signal
+
+
+class TimeNoise(TimeMask):
+    """Like TimeMask, but the hole is filled with noise (transforms.py:1456-1495)."""
+
+    def _transform(self, signal, tmin_s: float, tmax_s: float):
+        return _fill_masked_with_noise(signal.mask_timesteps(tmin_s=tmin_s, tmax_s=tmax_s, val=0.0))
+
+
+class FrequencyNoise(FrequencyMask):
+    """Like FrequencyMask, but the hole is filled with noise (transforms.py:1498-1536)."""
+
+    def _transform(self, signal, fmin_hz: float, fmax_hz: float):
+        return _fill_masked_with_noise(signal.mask_frequencies(fmin_hz=fmin_hz, fmax_hz=fmax_hz))

@@ -1,0 +1,85 @@
+"""The transform protocol (instantiate -> collate -> transform under a mask) on CPU tensors:
+seed-for-seed equality with the UNMODIFIED reference where it can be imported, plus the
+reference's own property checks (tests/data/test_transforms.py:34-85)."""
+import numpy as np
+import pytest
+import torch
+
+import audiotools_amd as A
+from audiotools_amd import transforms as tfm
+from tests import synth
+
+NO_LOADER = ["ClippingDistortion", "Equalizer", "Quantization", "MuLawQuantization", "NoiseFloor", "VolumeChange",
+             "VolumeNorm", "Silence", "LowPass", "HighPass", "RescaleAudio", "ShiftPhase", "InvertPhase",
+             "CorruptPhase", "FrequencyMask", "TimeMask", "MaskLowMagnitudes", "Smoothing", "Identity"]
+
+
+def _signal(mod, B=1, seed=5):
+    x = synth.audio_batch(B, 1, 22050, seed=seed, gaps=False)
+    return mod.AudioSignal(x.clone(), 44100)
+
+
+@pytest.mark.parametrize("name", NO_LOADER)
+def test_seeded_equality_with_reference(reference, name):
+    ours = getattr(tfm, name)()
+    theirs = getattr(reference.transforms if hasattr(reference, "transforms") else reference.data.transforms, name)()
+    sa, sr = _signal(A), _signal(reference)
+    ka = ours.instantiate(7, sa)
+    kr = theirs.instantiate(7, sr)
+    assert sorted(ka[ours.name]) == sorted(kr[theirs.name])
+    oa = ours(sa.clone(), **ka).audio_data
+    orr = theirs(sr.clone(), **kr).audio_data
+    assert oa.shape == orr.shape
+    assert torch.allclose(oa, orr, atol=2e-5), float((oa - orr).abs().max())
+
+
+def test_compose_batch_equality_with_reference(reference):
+    rt = reference.data.transforms
+    mk = lambda m: m.Compose(m.LowPass(cutoff=("choice", [4000, 8000])), m.Equalizer(), m.VolumeNorm(("uniform", -30, -20)),
+                             m.Choose(m.HighPass(), m.ClippingDistortion()), m.RescaleAudio(), name="chain")
+    ours, theirs = mk(tfm), mk(rt)
+    B = 4
+    sa, sr = _signal(A, B), _signal(reference, B)
+    ka = ours.batch_instantiate(list(range(B)), sa)
+    kr = theirs.batch_instantiate(list(range(B)), sr)
+    oa, orr = ours(sa.clone(), **ka), theirs(sr.clone(), **kr)
+    assert torch.allclose(oa.audio_data, orr.audio_data, atol=2e-5)
+    # batch item 0 equals the single-item application (test_transforms.py:64-76)
+    k0 = ours.instantiate(0, sa[0])
+    single = ours(sa[0].clone(), **k0)
+    assert torch.allclose(single.audio_data, oa.audio_data[:1], atol=2e-5)
+    with ours.filter("LowPass"):
+        only_lp = ours(sa.clone(), **ka)
+    lp = tfm.LowPass()
+    assert not torch.allclose(only_lp.audio_data, oa.audio_data)
+
+
+def test_mask_and_prob():
+    s = _signal(A, 6)
+    t = tfm.VolumeChange(db=("const", -6.0), prob=0.5)
+    kw = t.batch_instantiate(list(range(6)), s)
+    mask = kw["VolumeChange"]["mask"]
+    assert mask.dtype == torch.bool and 0 < int(mask.sum()) < 6
+    out = t(s.clone(), **kw)
+    ratio = out.audio_data.abs().amax(-1)[:, 0] / s.audio_data.abs().amax(-1)[:, 0]
+    assert torch.allclose(ratio[mask], torch.full_like(ratio[mask], 10 ** (-6 / 20)), atol=1e-5)
+    assert torch.allclose(ratio[~mask], torch.ones_like(ratio[~mask]))
+    with pytest.raises(AssertionError):
+        t(s.clone(), **{"VolumeChange": {"mask": mask}})
+
+
+def test_room_impulse_response_with_tensor_loader():
+    g = torch.Generator().manual_seed(3)
+    bank = torch.randn(5, 1, 44100, generator=g) * torch.exp(-torch.arange(44100) / 8000.0)
+    t = tfm.RoomImpulseResponse(loader=tfm.TensorLoader(bank, 44100))
+    s = _signal(A, 3)
+    kw = t.batch_instantiate([1, 2, 3], s)
+    assert kw["RoomImpulseResponse"]["ir_signal"].shape == (3, 1, 44100)
+    out = t(s.clone(), **kw)
+    assert torch.allclose(out.audio_data.abs().amax(-1), s.audio_data.abs().amax(-1), rtol=1e-4)
+    with pytest.raises(NotImplementedError):
+        tfm.RoomImpulseResponse(sources=["irs.csv"])
+    bn = tfm.BackgroundNoise(loader=tfm.TensorLoader(torch.randn(4, 1, 44100, generator=g), 44100))
+    kb = bn.batch_instantiate([4, 5, 6], s)
+    noisy = bn(s.clone(), **kb)
+    assert not torch.allclose(noisy.audio_data, s.audio_data)
