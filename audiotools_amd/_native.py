@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libaudiotools_amd.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["stft.hip", "loudness.hip", "fir.hip", "fftconv.hip"]
+SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "fftconv.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into ``lib/libaudiotools_amd.so``
     (hipcc cross-compiles without a GPU)."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES] + [os.path.join(CSRC_DIR, "at_common.h")]
+    srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES] + [os.path.join(CSRC_DIR, h) for h in ("at_common.h", "fft_wave.h")]
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
             return LIB_PATH
@@ -58,6 +58,8 @@ SIGNATURES = {
     "at_mel_units_host": (_i32, [_p, _i32, _i32, _p, _p]),
     "at_stft_mel_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
+    "at_istft_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "at_istft_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p, _i64, _p]),
     "at_fir_per_item_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "at_resample_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "at_fftconv_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),

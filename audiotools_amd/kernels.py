@@ -83,6 +83,46 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
     return stft, mel_spec
 
 
+_nola_cache = {}
+
+
+def _nola_ok(window: torch.Tensor, n_fft: int, hop: int) -> bool:
+    key = (window.data_ptr(), n_fft, hop)
+    if key not in _nola_cache:
+        w2 = window.detach().float().cpu().numpy().astype("float64") ** 2
+        reps = -(-n_fft // hop)
+        import numpy as np
+        env = np.zeros(hop)
+        for j in range(reps):
+            seg = w2[j * hop: (j + 1) * hop]
+            env[: len(seg)] += seg
+        _nola_cache[key] = bool(env.min() > 1e-11)
+    return _nola_cache[key]
+
+
+def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, length: int) -> torch.Tensor:
+    """Inverse STFT of a (B, C, F, N) complex64 HIP tensor -> (B, C, length) float32
+    (torch.istft(center=True) semantics)."""
+    _require_native_ok(stft_bcfn)
+    B, C, F, N = stft_bcfn.shape
+    assert F == n_fft // 2 + 1
+    # physical (B, C, N, F) bin-contiguous layout; a no-op for tensors produced by stft_mel()
+    X = stft_bcfn.transpose(2, 3).contiguous()
+    dev = X.device
+    # torch.istft refuses windows whose overlap-add envelope vanishes (NOLA)
+    if not _nola_ok(window, n_fft, hop):
+        raise RuntimeError("istft: window overlap add min is (nearly) zero -- the STFT is not invertible")
+    lib = _native.lib()
+    need = int(lib.at_istft_workspace_bytes(B * C, N, n_fft))
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    tw = tables.stft_twiddles(n_fft, dev)
+    out = torch.empty((B, C, length), dtype=torch.float32, device=dev)
+    code = lib.at_istft_f32(_native.ptr(torch.view_as_real(X)), B * C, N, _native.ptr(window), _native.ptr(tw), n_fft, hop,
+                            length, _native.ptr(out), _native.ptr(ws), need, _native.current_stream(dev))
+    _native.check(code, "at_istft_f32")
+    return out
+
+
 def lufs_block_params(rate: int, block_size: float):
     """(K, S) exactly as loudness.py:165-170 computes them (Python floats)."""
     overlap = 0.75

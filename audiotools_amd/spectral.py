@@ -108,7 +108,10 @@ class SpectralMixin:
             length = self.original_signal_length + 2 * pad + right_pad
         if match_stride:
             X = torch.nn.functional.pad(X, (2, 2))
-        x = torch.istft(X, n_fft=n_fft, hop_length=hop, window=window, length=length, center=True)
+        if kernels.is_native(torch.view_as_real(self.stft_data)) and kernels.stft_native_supported(n_fft):
+            x = kernels.istft(X.reshape(nb, nch, nf, X.shape[-1]), window, n_fft, hop, int(length))
+        else:
+            x = torch.istft(X, n_fft=n_fft, hop_length=hop, window=window, length=length, center=True)
         x = x.reshape(nb, nch, -1)
         if match_stride:
             x = x[..., pad: -(pad + right_pad)]

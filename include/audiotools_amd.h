@@ -69,6 +69,18 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
                     float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,
                     float* mel_out, void* stream);
 
+/* ---- inverse STFT --------------------------------------------------------------------------
+ * Replaces  audiotools/core/audio_signal.py:1283-1290  torch.istft(X, n_fft, hop, window, length,
+ *           center=True).  Power-of-two n_fft in [32, 2048]; any hop.
+ *   X        (rows, n_frames, n_fft/2+1) complex64 interleaved, bin-contiguous (the layout
+ *            at_stft_mel_f32 writes / torch.stft returns)
+ *   out      (rows, length) f32; samples with no frame overlap are 0 (torch pads to `length`)
+ *   workspace at_istft_workspace_bytes(rows, n_frames, n_fft) bytes (windowed frames)
+ */
+int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft);
+int at_istft_f32(const float* X, int64_t rows, int64_t n_frames, const float* window, const float* twiddles, int n_fft,
+                 int hop, int64_t length, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- BS.1770 integrated loudness ---------------------------------------------------
  * Replaces  audiotools/core/loudness.py:102-126  (2x torchaudio.functional.lfilter, the
  *           CPU/IIR branch), :164-174 (julius.core.unfold), :176-247 (gated integration).

@@ -276,3 +276,40 @@ def test_apply_ir_and_normalize():
     assert torch.allclose(y.audio_data.abs().amax(-1), s.audio_data.abs().amax(-1), rtol=1e-4)
     n = s.clone().normalize(-30.0)
     assert float((n.loudness().cpu() + 30.0).abs().max()) < 0.1
+
+
+# ----------------------------------------------------------------------------- istft
+@pytest.mark.parametrize("win,hop,wt,ms", [(2048, 512, "hann", False), (2048, 512, "sqrt_hann", True),
+                                           (512, 128, "sqrt_hann", False), (512, 128, "hann", True),
+                                           (1024, 256, "hann", False), (256, 64, "sqrt_hann", True),
+                                           (512, 100, "hann", False), (64, 16, "hann", False)])
+def test_istft_vs_oracle_and_roundtrip(win, hop, wt, ms):
+    """tests/core/test_audio_signal.py:400-456: istft(stft(x)) == x; plus values vs torch.istft on CPU."""
+    x = synth.audio_batch(3, 2, 22050 + 7, seed=win + hop, gaps=False)
+    s = A.AudioSignal(x.clone(), 44100).to("cuda")
+    X = s.stft(win, hop, wt, ms)
+    ref = restate.istft(X.cpu(), win, hop, wt, ms, x.shape[-1])
+    y = s.istft(win, hop, wt, ms).audio_data
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < REL
+    if hop * 4 == win:
+        # match_stride drops the two edge frames on each side: only the interior reconstructs
+        # (tests/core/test_audio_signal.py:447-456)
+        sl = slice(win, -win) if ms else slice(None)
+        assert float((y.cpu() - x)[..., sl].abs().max()) < 1e-5
+
+
+def test_istft_golden_and_modified_spectrum():
+    d = np.load(os.path.join(G, "stft_cfg1.npz"))
+    s = A.AudioSignal(torch.from_numpy(d["x"]), 16000).to("cuda")
+    s.stft(512, 128, "hann")
+    assert rel_err(s.clone().istft(512, 128, "hann").audio_data, torch.from_numpy(d["istft"])) < REL
+    # a spectrum that is NOT the STFT of a signal (time mask + phase shift) still inverts like torch.istft
+    x = synth.audio_batch(2, 1, 16000, seed=9, gaps=False)
+    g = A.AudioSignal(x.clone(), 16000).to("cuda")
+    g.stft()
+    g.mask_timesteps(0.2, 0.4).shift_phase(0.3)
+    ref = restate.istft(g.stft_data.cpu(), 512, 128, "hann", False, 16000)
+    assert rel_err(g.istft().audio_data, ref) < REL
+    with pytest.raises(RuntimeError):
+        A.AudioSignal(x.clone(), 16000).to("cuda").istft()
