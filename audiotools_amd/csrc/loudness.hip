@@ -23,6 +23,7 @@
 // Kernel 2  lufs_gate: one wave per item; float64 gating exactly as the reference
 //   (z in f32, l/Gamma in f64).
 #include "at_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -52,6 +53,7 @@ struct LufsArgs {
   int warm;            // warm-up samples for segments that start after sample 0
   int nstage;
   int vec4;
+  int debug;
   Stage st[MAX_STAGE];
   // P^(2^i), i = 0..6, per stage, row-major 2x2: wave-uniform, read through s_load
   double Pp[MAX_STAGE][7][4];   // float64: used once per wave to build the per-lane matrices
@@ -79,6 +81,19 @@ __device__ __forceinline__ float row_bcast31(float v) { return dpp0<0x143, 0xc>(
 __device__ __forceinline__ float wave_shr1(float v, float lane0) {                     // lane i <- i-1, lane 0 <- lane0
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane0), __builtin_bit_cast(int, v),
                                                                 0x138, 0xf, 0xf, false));
+}
+// wave64 sum with DPP only (quad_perm xor 1/2, row_half_mirror, row_mirror, row_bcast15/31);
+// the total ends up in lane 63 and is broadcast with v_readlane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float x, int ctrl_dummy) { return x; };
+  (void)dpp;
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false)); // row_bcast15 -> rows 1,3
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false)); // row_bcast31 -> rows 2,3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float lane63(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
@@ -209,21 +224,16 @@ __global__ __launch_bounds__(256, AT_LUFS_WPS) void kweight_hop_energy(const Luf
   // raw tile of one super-block in registers: 8 x float4 (VEC4) or 32 x float (scalar path)
   float4 R[8];
   auto load_tile = [&](int64_t sb) __attribute__((always_inline)) {
-    if constexpr (VEC4) {
+    // Branch-free: a conditional load makes the compiler drain vmcnt before every load of the
+    // tile (WAW on the destination registers) and serialises the 8 loads.  Addresses past the
+    // row end are clamped into the row and the result is replaced by 0 with a select.
+    if constexpr (VEC4) {  // T % 4 == 0 and sb % 4 == 0: a float4 is entirely inside or outside the row
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int p = i * 64 + lane;
-        const int64_t g = sb + 4 * (int64_t)p;
-        float4 val;
-        if (g + 3 < A.T) {
-          val = *reinterpret_cast<const float4*>(xr + g);
-        } else {
-          val.x = g + 0 < A.T ? xr[g + 0] : 0.f;
-          val.y = g + 1 < A.T ? xr[g + 1] : 0.f;
-          val.z = g + 2 < A.T ? xr[g + 2] : 0.f;
-          val.w = 0.f;
-        }
-        R[i] = val;
+        const int64_t g = sb + 4 * (int64_t)(i * 64 + lane);
+        const int64_t gc = g < A.T ? g : A.T - 4;
+        const float4 val = *reinterpret_cast<const float4*>(xr + gc);
+        R[i] = g < A.T ? val : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
 #pragma unroll
@@ -232,7 +242,8 @@ __global__ __launch_bounds__(256, AT_LUFS_WPS) void kweight_hop_energy(const Luf
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t g = sb + (4 * i + j) * 64 + lane;
-          e[j] = g < A.T ? xr[g] : 0.f;
+          const float val = xr[g < A.T ? g : A.T - 1];
+          e[j] = g < A.T ? val : 0.f;
         }
         R[i] = make_float4(e[0], e[1], e[2], e[3]);
       }
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(256, AT_LUFS_WPS) void kweight_hop_energy(const Luf
 
     // ---- biquad cascade
 #define AT_STAGE(SI)                                                     \
-    if constexpr (SI < NS) {                                             \
+    if constexpr (SI < NS) if (!A.debug) {                                             \
       const float hx1 = wave_shr1(v[CHUNK - 1], kx1[SI]);                \
       const float hx2 = wave_shr1(v[CHUNK - 2], kx2[SI]);                \
       kx1[SI] = lane63(v[CHUNK - 1]);                                    \
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(256, AT_LUFS_WPS) void kweight_hop_energy(const Luf
               e = fmaf(m, m, e);
             }
           }
-          const double tot = at::wave_sum((double)e);
+          const double tot = (double)wave_sum_dpp(e);
           if (h != h_cur) {
             if (h_cur >= 0 && lane == 0) A.E[row * A.H + h_cur] = acc;
             h_cur = h;
@@ -484,6 +495,7 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
       for (int e = 0; e < 4; ++e) P[e] = n[e];
     }
   }
+  { const char* e = getenv("AT_LUFS_DEBUG"); A.debug = e ? atoi(e) : 0; }
   A.vec4 = ((T % 4) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0) ? 1 : 0;
   double* E = reinterpret_cast<double*>(workspace);
   int H;
@@ -499,7 +511,9 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
   const int64_t H_data = (T + S - 1) / S;
   A.H_data = (int)H_data;
   // aim for >= 8192 waves, but keep segments >= 4x the warm-up unless the batch is tiny
-  int64_t seg = (rows * H_data + 8191) / 8192;
+  int64_t want_waves = 8192;
+  { const char* e = getenv("AT_LUFS_WAVES"); if (e && atoi(e) > 0) want_waves = atoi(e); }
+  int64_t seg = (rows * H_data + want_waves - 1) / want_waves;
   const int64_t min_seg = (4 * (int64_t)warm + S - 1) / S;
   if (seg < min_seg && rows * ((H_data + min_seg - 1) / min_seg) >= 1024) seg = min_seg;
   if (seg < 1) seg = 1;
