@@ -330,6 +330,12 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
       if (STORE_OK(xh.x)) orow[M / 2] = xh;
       if constexpr (MEL) magbuf[M / 2 + 4 * ((M / 2) >> 4)] = cabs_fast(xh);
     }
+    if constexpr (MEL) {
+      // The last row holds only the Nyquist bin; a unit on it multiplies its other 15 columns by
+      // zero weights, and those columns alias FFT-slab slots that may never have been written
+      // (0 * garbage = NaN).  Zero them.
+      for (int c = 1 + t; c < 16; c += L) magbuf[(M / 16) * MAG_ROW + c] = 0.f;
+    }
 
     if constexpr (MEL) {
       wave_sync();

@@ -313,3 +313,53 @@ def test_istft_golden_and_modified_spectrum():
     assert rel_err(g.istft().audio_data, ref) < REL
     with pytest.raises(RuntimeError):
         A.AudioSignal(x.clone(), 16000).to("cuda").istft()
+
+
+# ------------------------------------------------------ BASELINE.json full-size configurations
+def _device_batch(B, C, T, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = (0.1 * torch.randn(B, C, T, device="cuda", generator=g)).clamp_(-1, 1)
+    x *= (10 ** (-30 * torch.rand(B, device="cuda", generator=g) / 20))[:, None, None]
+    return x
+
+
+def test_cfg2_full_size_stft_mel():
+    """configs[1]: batch 256 x 2ch x 10s @44.1k, STFT(2048/512) + 80-bin mel.  Oracle on a
+    subset of the items (rows are independent), linearity and finiteness on all of them."""
+    B, C, T = 256, 2, 441000
+    x = _device_batch(B, C, T, 11)
+    s = A.AudioSignal(x, 44100)
+    mel = s.mel_spectrogram(80)
+    assert mel.shape == (B, C, 80, 862) and s.stft_data.shape == (B, C, 1025, 862)
+    assert torch.isfinite(mel).all()
+    idx = [0, 37, 255]
+    xs = x[idx].cpu()
+    Xr = restate.stft(xs, 2048, 512)
+    assert rel_err(s.stft_data[idx], Xr) < REL
+    assert rel_err(mel[idx], restate.mel_spectrogram(Xr, 44100, 80)) < REL
+    # mel is linear in |X| and |X| is homogeneous: scaling the audio scales the mel
+    mel2 = A.AudioSignal(0.5 * x, 44100).mel_spectrogram(80)
+    assert rel_err(mel2, 0.5 * mel) < REL
+    # every frame of every row was written: a checksum over frames matches a second run
+    mel3 = A.AudioSignal(x, 44100).mel_spectrogram(80)
+    assert torch.equal(mel3, mel)
+
+
+def test_cfg3_full_size_loudness():
+    """configs[2]: batch 512 x 2ch x 10s @44.1k LUFS.  Oracle on a subset, gain property on all,
+    permutation invariance (items are independent), silence clamp."""
+    B, C, T = 512, 2, 441000
+    x = _device_batch(B, C, T, 12)
+    x[5] = 0.0
+    x[9, :, : 6 * 44100] = 0.0            # long digital-silence gap: absolute gate
+    l = A.AudioSignal(x, 44100).loudness()
+    assert l.shape == (B,) and float(l[5]) == -70.0
+    idx = [0, 9, 200, 511]
+    ref = restate.loudness(x[idx].cpu(), 44100)
+    assert float((l[idx].cpu() - ref).abs().max()) < LU
+    l6 = A.AudioSignal(0.5 * x, 44100).loudness()
+    keep = l > -60
+    assert float(((l6 - l)[keep] + 6.0206).abs().max()) < 1e-2
+    perm = torch.randperm(B, device="cuda")
+    lp = A.AudioSignal(x[perm], 44100).loudness()
+    assert float((lp - l[perm]).abs().max()) < 1e-4
