@@ -61,7 +61,7 @@ SIGNATURES = {
     "at_istft_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "at_istft_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p, _i64, _p]),
     "at_fir_per_item_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p, _p]),
-    "at_resample_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "at_resample_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "at_fftconv_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "at_fftconv_circ_f32": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _p]),
     "at_lufs_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32]),

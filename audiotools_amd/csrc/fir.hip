@@ -11,9 +11,7 @@
 // (with replicate padding applied while staging) and the item's taps sit in LDS; every thread
 // owns 8 consecutive outputs and slides a 16-sample register window over the taps, 64 FMAs per
 // 4 ds_read_b128 -- the kernel is bound by the FP32 vector rate, not by LDS or HBM.
-// Resampler: the julius bank is stored sparse (per output phase only the taps with |t| < zeros,
-// transposed to [tap][phase]) in LDS next to the input tile; a thread owns one phase of a group
-// of frames.
+// Resampler: see the comment above resample_kernel.
 #include "at_common.h"
 
 namespace {
@@ -84,64 +82,75 @@ __global__ __launch_bounds__(256) void fir_per_item_kernel(const float* __restri
 }
 
 // ---- polyphase resampler ------------------------------------------------------------------
+// y[f*new + i] = sum_m wg[G][m][p] * xp[f*old + base[G] + m],   i = 4 G + p
+// The julius bank is banded: phase i only has taps in a window of ~2*zeros*old/sr that slides with
+// i.  Phases are grouped by 4; a group stores its taps densely over the union window (LG taps,
+// zero filled) as float4 = 4 phases per tap.  A thread owns one group x RS_FB consecutive frames:
+// 16 FMAs per 4 LDS reads of x + one float4 of weights (L2 resident, ~100 KB per ratio).
 struct ResampleArgs {
   const float* x;        // (rows, T)
-  const float* ws;       // (Wd, new_sr): sparse taps, [tap j][phase i]
-  const int* k0;         // (new_sr): first dense tap index of phase i
+  const float4* wg;      // (NG, LG): 4 phases per tap
+  const int* base;       // (NG): first dense tap index of the group
   float* out;            // (rows, out_len)
   int64_t T, out_len, rows;
-  int old_sr, new_sr, width, Wd;
-  int frames_per_tile;   // FT
+  int old_sr, new_sr, width, NG, LG;
+  int frames_per_tile;   // FT (multiple of RS_FB)
   int tiles_per_row;
-  int bank_in_lds;
+  int xs_len;
 };
 
 constexpr int RS_FB = 4;  // frames per thread
 
 __global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(16))) float xs[];
   const int FT = A.frames_per_tile;
-  const int xs_len = FT * A.old_sr + A.width * 2 + A.old_sr;  // covers k < 2*width + old for every frame of the tile
-  float* xs = smem;
-  float* bank = smem + ((xs_len + 3) & ~3);
   const int64_t row = blockIdx.x / A.tiles_per_row;
   const int tile = blockIdx.x % A.tiles_per_row;
   const float* __restrict__ xr = A.x + row * A.T;
   const int64_t f0 = (int64_t)tile * FT;
   const int t = threadIdx.x;
   // padded input: xp[m] = x[clamp(m - width)], frame f reads xp[f*old + k]
-  for (int m = t; m < xs_len; m += 256) {
+  for (int m = t; m < A.xs_len; m += 256) {
     int64_t g = f0 * A.old_sr + m - A.width;
     g = g < 0 ? 0 : (g >= A.T ? A.T - 1 : g);
     xs[m] = xr[g];
   }
-  if (A.bank_in_lds)
-    for (int m = t; m < A.Wd * A.new_sr; m += 256) bank[m] = A.ws[m];
   __syncthreads();
-  const float* __restrict__ w = A.bank_in_lds ? bank : A.ws;
-  const int groups = (FT + RS_FB - 1) / RS_FB;
+  const int fgroups = FT / RS_FB;
   float* __restrict__ orow = A.out + row * A.out_len;
-  for (int item = t; item < A.new_sr * groups; item += 256) {
-    const int i = item % A.new_sr;
-    const int fg = item / A.new_sr;
-    const int kk = A.k0[i];
-    float acc[RS_FB];
+  for (int item = t; item < A.NG * fgroups; item += 256) {
+    const int G = item % A.NG;
+    const int fg = item / A.NG;
+    float acc[4][RS_FB];
 #pragma unroll
-    for (int r = 0; r < RS_FB; ++r) acc[r] = 0.f;
-    const float* xb = xs + (fg * RS_FB) * A.old_sr + kk;
-    for (int j = 0; j < A.Wd; ++j) {
-      const float wj = w[j * A.new_sr + i];
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < RS_FB; ++r) acc[p][r] = 0.f;
+    const float* xb = xs + (fg * RS_FB) * A.old_sr + A.base[G];
+    const float4* __restrict__ w = A.wg + (int64_t)G * A.LG;
+#pragma unroll 4
+    for (int m = 0; m < A.LG; ++m) {
+      const float4 wv = w[m];
+      float xv[RS_FB];
+#pragma unroll
+      for (int r = 0; r < RS_FB; ++r) xv[r] = xb[r * A.old_sr + m];
 #pragma unroll
       for (int r = 0; r < RS_FB; ++r) {
-        const int fr = fg * RS_FB + r;
-        if (fr < FT) acc[r] = fmaf(wj, xb[r * A.old_sr + j], acc[r]);
+        acc[0][r] = fmaf(wv.x, xv[r], acc[0][r]);
+        acc[1][r] = fmaf(wv.y, xv[r], acc[1][r]);
+        acc[2][r] = fmaf(wv.z, xv[r], acc[2][r]);
+        acc[3][r] = fmaf(wv.w, xv[r], acc[3][r]);
       }
     }
 #pragma unroll
     for (int r = 0; r < RS_FB; ++r) {
       const int64_t f = f0 + fg * RS_FB + r;
-      const int64_t o = f * A.new_sr + i;
-      if (fg * RS_FB + r < FT && o < A.out_len) orow[o] = acc[r];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int i = 4 * G + p;
+        const int64_t o = f * A.new_sr + i;
+        if (i < A.new_sr && o < A.out_len) orow[o] = acc[p][r];
+      }
     }
   }
 }
@@ -169,28 +178,26 @@ int at_fir_per_item_f32(const float* x, int64_t B, int64_t C, int64_t T, const f
 }
 
 // x (rows,T) -> out (rows,out_len), out_len = floor(new_sr*T/old_sr) for the REDUCED ratio.
-// ws (Wd,new_sr), k0 (new_sr): sparse transposed bank (tables.resample_sparse_bank).
-int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* ws, const int* k0, int old_sr, int new_sr,
-                    int width, int Wd, float* out, int64_t out_len, void* stream) {
-  if (!x || !ws || !k0 || !out || rows < 0 || T <= 0 || old_sr <= 0 || new_sr <= 0 || width <= 0 || Wd <= 0 ||
-      out_len < 0)
+// wg (NG, LG, 4) f32, base (NG) i32: the bank grouped 4 phases per tap (tables.resample_grouped_bank).
+int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* wg, const int* base, int old_sr, int new_sr,
+                    int width, int NG, int LG, float* out, int64_t out_len, void* stream) {
+  if (!x || !wg || !base || !out || rows < 0 || T <= 0 || old_sr <= 0 || new_sr <= 0 || width <= 0 || NG <= 0 ||
+      LG <= 0 || out_len < 0 || 4 * NG < new_sr)
     return AT_ERR_INVALID;
   if (rows == 0 || out_len == 0) return AT_OK;
   ResampleArgs A;
-  A.x = x; A.ws = ws; A.k0 = k0; A.out = out; A.T = T; A.out_len = out_len; A.rows = rows;
-  A.old_sr = old_sr; A.new_sr = new_sr; A.width = width; A.Wd = Wd;
+  A.x = x; A.wg = reinterpret_cast<const float4*>(wg); A.base = base; A.out = out; A.T = T; A.out_len = out_len;
+  A.rows = rows; A.old_sr = old_sr; A.new_sr = new_sr; A.width = width; A.NG = NG; A.LG = LG;
   const int64_t frames = (out_len + new_sr - 1) / new_sr;
-  // tile: ~8k input samples of LDS, at least RS_FB frames
-  int FT = 8192 / old_sr;
+  // tile: ~14k input samples of LDS (56 KB -> 2 workgroups per CU), a multiple of RS_FB frames
+  int FT = 14000 / old_sr / RS_FB * RS_FB;
   if (FT < RS_FB) FT = RS_FB;
   if (FT > 64) FT = 64;
   A.frames_per_tile = FT;
   A.tiles_per_row = (int)((frames + FT - 1) / FT);
-  const int xs_len = FT * old_sr + 2 * width + old_sr;
-  size_t lds = (size_t)((xs_len + 3) & ~3) * 4;
-  const size_t bank_bytes = (size_t)Wd * new_sr * 4;
-  A.bank_in_lds = (lds + bank_bytes <= 150 * 1024) ? 1 : 0;
-  if (A.bank_in_lds) lds += bank_bytes;
+  // last frame of the tile reads up to (FT-1)*old + max(base)+LG-1 <= (FT-1)*old + 2*width + old
+  A.xs_len = FT * old_sr + 2 * width + LG;
+  const size_t lds = (size_t)A.xs_len * 4;
   if (lds > 160 * 1024) return AT_ERR_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {

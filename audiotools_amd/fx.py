@@ -237,10 +237,11 @@ class ImpulseResponseMixin:
         early_idx = (idx >= td - t0) * (idx <= td + t0)
         early = torch.where(early_idx, x, torch.zeros_like(x))
         late = torch.where(early_idx, torch.zeros_like(x), x)
-        window = torch.zeros_like(x)
-        for b in range(self.batch_size):
-            w_idx = early_idx[b, 0].nonzero()
-            window[b, ..., w_idx] = self.get_window("hann", w_idx.shape[-1], str(self.device))
+        # "Hann window over the early span" -- as written in the reference (effects.py:569-573) it is
+        # get_window("hann", window_idx.shape[-1]) with window_idx = nonzero() of shape (n, 1), i.e. a
+        # length-1 Hann = [1.0] broadcast over the span: the window is 1 on the early span of
+        # channel 0 (for every channel) and 0 elsewhere.  Reproduced, without the per-item loop.
+        window = early_idx[:, :1, :].expand_as(x).to(x.dtype)
         return early, late, window
 
     def measure_drr(self):

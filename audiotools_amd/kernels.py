@@ -237,18 +237,18 @@ def sinc_filter(audio: torch.Tensor, cutoffs_norm: torch.Tensor, zeros: float, h
 
 def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
     _require_native_ok(audio)
-    plan = tables.resample_sparse_bank(int(old_sr), int(new_sr))
+    plan = tables.resample_grouped_bank(int(old_sr), int(new_sr))
     if plan is None:
         return audio
-    ws_np, k0_np, old, new, width, Wd = plan
+    wg_np, base_np, old, new, width, NG, LG = plan
     dev = audio.device
-    ws, k0 = tables.device_table(("resample_sparse", old, new), dev, lambda: (ws_np, k0_np))
+    wg, base = tables.device_table(("resample_grouped", old, new), dev, lambda: (wg_np, base_np))
     B, C, T = audio.shape
     audio = audio.contiguous()
     out_len = int(math.floor(new * T / old))
     out = torch.empty((B, C, out_len), dtype=torch.float32, device=dev)
-    code = _native.lib().at_resample_f32(_native.ptr(audio), B * C, T, _native.ptr(ws), _native.ptr(k0), old, new, width,
-                                         Wd, _native.ptr(out), out_len, _native.current_stream(dev))
+    code = _native.lib().at_resample_f32(_native.ptr(audio), B * C, T, _native.ptr(wg), _native.ptr(base), old, new, width,
+                                         NG, LG, _native.ptr(out), out_len, _native.current_stream(dev))
     _native.check(code, "at_resample_f32")
     return out
 

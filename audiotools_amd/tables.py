@@ -329,3 +329,37 @@ def resample_sparse_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: flo
     for i in range(new):
         ws[:, i] = b[i, k0[i]: k0[i] + Wd]
     return ws, k0, old, new, width, Wd
+
+
+@functools.lru_cache(None)
+def resample_grouped_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
+    """Bank layout of ``at_resample_f32``: output phases grouped by 4; group G stores, for every
+    tap of the union of its phases' support windows, one float4 (4 phases), zero filled.
+    Returns ``(wg float32 (NG, LG, 4), base int32 (NG,), old, new, width, NG, LG)`` or None."""
+    sp = resample_sparse_bank(old_sr, new_sr, zeros, rolloff)
+    if sp is None:
+        return None
+    ws, k0, old, new, width, Wd = sp
+    dense = resample_bank(old_sr, new_sr, zeros, rolloff)[0].numpy()
+    K = dense.shape[1]
+    NG = (new + 3) // 4
+    base = np.zeros(NG, dtype=np.int32)
+    spans = []
+    for G in range(NG):
+        ph = list(range(4 * G, min(4 * G + 4, new)))
+        lo = int(min(k0[i] for i in ph))
+        hi = int(max(k0[i] + Wd for i in ph))
+        base[G] = lo
+        spans.append(hi - lo)
+    LG = int(max(spans))
+    base = np.minimum(base, K - LG).astype(np.int32)
+    wg = np.zeros((NG, LG, 4), dtype=np.float32)
+    thr = 1e-12 * np.abs(dense).max()
+    for G in range(NG):
+        for p in range(4):
+            i = 4 * G + p
+            if i < new:
+                seg = dense[i, base[G]: base[G] + LG].copy()
+                seg[np.abs(seg) <= thr] = 0.0
+                wg[G, :, p] = seg
+    return wg, base, old, new, width, NG, LG

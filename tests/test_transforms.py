@@ -83,3 +83,22 @@ def test_room_impulse_response_with_tensor_loader():
     kb = bn.batch_instantiate([4, 5, 6], s)
     noisy = bn(s.clone(), **kb)
     assert not torch.allclose(noisy.audio_data, s.audio_data)
+
+
+def test_ir_tools_match_reference(reference):
+    """decompose_ir / alter_drr / measure_drr / apply_ir vs the unmodified reference (CPU), incl.
+    its quirk that the 'Hann' window over the early span is a length-1 Hann, i.e. all ones."""
+    g = torch.Generator().manual_seed(1)
+    ir = torch.randn(5, 1, 24000, generator=g) * torch.exp(-torch.arange(24000) / 3000.0)
+    ir[2] = torch.roll(ir[2], 30, -1)
+    ir[3, :, :5] *= 50
+    a, r = A.AudioSignal(ir.clone(), 48000), reference.AudioSignal(ir.clone(), 48000)
+    for got, ref in zip(a.decompose_ir(), r.decompose_ir()):
+        assert torch.equal(got, ref)
+    assert torch.allclose(a.measure_drr(), r.measure_drr())
+    assert torch.allclose(a.clone().alter_drr(10.0).audio_data, r.clone().alter_drr(10.0).audio_data, atol=1e-6)
+    x = 0.1 * torch.randn(5, 1, 48000, generator=g)
+    mk = lambda M: M.AudioSignal(x.clone(), 48000).apply_ir(
+        M.AudioSignal(ir.clone(), 48000), drr=torch.tensor([5.0, 10, 15, 20, 0]),
+        ir_eq=-torch.rand(5, 6, generator=torch.Generator().manual_seed(2)))
+    assert torch.allclose(mk(A).audio_data, mk(reference).audio_data, atol=1e-6)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Timing of the non-headline BASELINE.json configurations on one GPU (development aid).
+cfg4: batch=1024 mono 5s@48kHz  Compose(LowPass, Equalizer, RoomImpulseResponse(2 s RIR))
+cfg5: batch=2048 2ch 30s@44.1kHz resample 44.1k->16k + STFT + mel  (per-GPU share = 256 items)"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import audiotools_amd as A
+from audiotools_amd import transforms as tfm
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--b4", type=int, default=1024)
+ap.add_argument("--b5", type=int, default=256)
+args = ap.parse_args()
+dev = "cuda"
+
+
+def timed(fn, label, n=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    print(f"{label:34s} {ms:9.2f} ms", flush=True)
+    return ms
+
+
+# ---- cfg4
+B, T, SR = args.b4, 240000, 48000
+g = torch.Generator(device=dev).manual_seed(1)
+x = (0.1 * torch.randn(B, 1, T, device=dev, generator=g)).clamp_(-1, 1)
+bank = torch.randn(64, 1, 96000, device=dev, generator=g) * torch.exp(-torch.arange(96000, device=dev) / (0.3 * SR))
+chain = tfm.Compose(tfm.LowPass(cutoff=("choice", [4000, 8000, 16000])), tfm.Equalizer(n_bands=6),
+                    tfm.RoomImpulseResponse(loader=tfm.TensorLoader(bank, SR), duration=2.0))
+sig = A.AudioSignal(x, SR)
+t0 = time.perf_counter()
+kw = chain.batch_instantiate(list(range(B)), A.AudioSignal(x[:1], SR))
+print(f"cfg4 batch_instantiate (host)       {(time.perf_counter() - t0) * 1e3:9.1f} ms")
+kw = A.util.prepare_batch(kw, dev)
+kc = kw["Compose"]
+timed(lambda: A.AudioSignal(x.clone(), SR).low_pass(kc["0.LowPass"]["cutoff"]), "cfg4 low_pass (B per-item cutoffs)")
+timed(lambda: A.AudioSignal(x.clone(), SR).equalizer(kc["1.Equalizer"]["eq"]), "cfg4 equalizer (6 bands)")
+ir = kc["2.RoomImpulseResponse"]["ir_signal"]
+timed(lambda: A.AudioSignal(x.clone(), SR).apply_ir(ir.clone(), kc["2.RoomImpulseResponse"]["drr"], kc["2.RoomImpulseResponse"]["eq"]), "cfg4 apply_ir (2 s RIR)")
+ms = timed(lambda: chain(A.AudioSignal(x.clone(), SR), **kw), "cfg4 full chain")
+print(f"cfg4 throughput: {B * 5.0 / (ms * 1e-3):.0f} audio-seconds/sec")
+
+# ---- cfg5 (per-GPU share)
+del x, sig, kw, kc, ir
+torch.cuda.empty_cache()
+B, T, SR = args.b5, 1323000, 44100
+x = (0.1 * torch.randn(B, 2, T, device=dev, generator=g)).clamp_(-1, 1)
+
+
+def cfg5():
+    s = A.AudioSignal(x, SR).resample(16000)
+    return s.mel_spectrogram(80)
+
+
+timed(lambda: A.AudioSignal(x, SR).resample(16000), "cfg5 resample 44.1k->16k")
+ms = timed(cfg5, "cfg5 resample + stft + mel")
+print(f"cfg5 throughput: {B * 30.0 / (ms * 1e-3):.0f} audio-seconds/sec per GPU")
