@@ -16,9 +16,13 @@
 
 namespace {
 
-constexpr int FIR_TILE = 2048;   // outputs per workgroup
+constexpr int FIR_R = 16;        // consecutive outputs per thread
+constexpr int FIR_TILE = 256 * FIR_R;   // outputs per workgroup
 constexpr int FIR_CHUNK = 512;   // taps staged per pass
-constexpr int FIR_XS = FIR_TILE + FIR_CHUNK + 16;
+constexpr int FIR_XS = (FIR_TILE + FIR_CHUNK + 32) / 16 * 20;
+// LDS window is stored in rows of 16 samples padded to 20 floats (80 B): the per-lane stride of the
+// ds_read_b128 window reads becomes 80 B instead of 64 B -> conflict-free
+__device__ __forceinline__ int fir_pad(int n) { return n + 4 * (n >> 4); }
 
 __global__ __launch_bounds__(256) void fir_per_item_kernel(const float* __restrict__ x, const float* __restrict__ taps,
                                                            float* __restrict__ out, int64_t T, int C, int taps_rows,
@@ -34,49 +38,49 @@ __global__ __launch_bounds__(256) void fir_per_item_kernel(const float* __restri
   const int64_t n0 = (int64_t)tile * FIR_TILE;
   const int t = threadIdx.x;
 
-  float acc[8];
+  float acc[FIR_R];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int i = 0; i < FIR_R; ++i) acc[i] = 0.f;
 
   for (int j0 = 0; j0 < Lp; j0 += FIR_CHUNK) {
     const int nj = min(FIR_CHUNK, Lp - j0);  // multiple of 8
     __syncthreads();
     // stage x[n0 + j0 - half + m], m in [0, FIR_TILE + nj + 8), replicate padding at both ends
-    for (int m = t; m < FIR_TILE + nj + 8; m += 256) {
+    for (int m = t; m < FIR_TILE + nj + 16; m += 256) {
       int64_t g = n0 + j0 - half + m;
       g = g < 0 ? 0 : (g >= T ? T - 1 : g);
-      xs[m] = xr[g];
+      xs[fir_pad(m)] = xr[g];
     }
     for (int m = t; m < nj; m += 256) hs[m] = h[j0 + m];
     __syncthreads();
 
-    float xw[16];
-    {
-      const float4 a = *reinterpret_cast<const float4*>(xs + 8 * t);
-      const float4 b = *reinterpret_cast<const float4*>(xs + 8 * t + 4);
-      xw[8] = a.x; xw[9] = a.y; xw[10] = a.z; xw[11] = a.w;
-      xw[12] = b.x; xw[13] = b.y; xw[14] = b.z; xw[15] = b.w;
+    // register window: xw[i] = xs[R t + j + i], i < R + 8; slides by 8 taps per step
+    float xw[FIR_R + 8];
+#pragma unroll
+    for (int i4 = 0; i4 < FIR_R / 4; ++i4) {
+      const float4 a = *reinterpret_cast<const float4*>(xs + fir_pad(FIR_R * t + 4 * i4));
+      xw[8 + 4 * i4 + 0] = a.x; xw[8 + 4 * i4 + 1] = a.y; xw[8 + 4 * i4 + 2] = a.z; xw[8 + 4 * i4 + 3] = a.w;
     }
     for (int j = 0; j < nj; j += 8) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) xw[i] = xw[i + 8];
-      const float4 a = *reinterpret_cast<const float4*>(xs + 8 * t + j + 8);
-      const float4 b = *reinterpret_cast<const float4*>(xs + 8 * t + j + 12);
-      xw[8] = a.x; xw[9] = a.y; xw[10] = a.z; xw[11] = a.w;
-      xw[12] = b.x; xw[13] = b.y; xw[14] = b.z; xw[15] = b.w;
+      for (int i = 0; i < FIR_R; ++i) xw[i] = xw[i + 8];
+      const float4 a = *reinterpret_cast<const float4*>(xs + fir_pad(FIR_R * t + j + FIR_R));
+      const float4 b = *reinterpret_cast<const float4*>(xs + fir_pad(FIR_R * t + j + FIR_R + 4));
+      xw[FIR_R + 0] = a.x; xw[FIR_R + 1] = a.y; xw[FIR_R + 2] = a.z; xw[FIR_R + 3] = a.w;
+      xw[FIR_R + 4] = b.x; xw[FIR_R + 5] = b.y; xw[FIR_R + 6] = b.z; xw[FIR_R + 7] = b.w;
       const float4 h0 = *reinterpret_cast<const float4*>(hs + j);
       const float4 h1 = *reinterpret_cast<const float4*>(hs + j + 4);
       const float hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = fmaf(hh[u], xw[i + u], acc[i]);
+        for (int i = 0; i < FIR_R; ++i) acc[i] = fmaf(hh[u], xw[i + u], acc[i]);
     }
   }
   float* __restrict__ orow = out + row * T;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t n = n0 + 8 * t + i;
+  for (int i = 0; i < FIR_R; ++i) {
+    const int64_t n = n0 + FIR_R * t + i;
     if (n < T) orow[n] = highpass ? xr[n] - acc[i] : acc[i];
   }
 }
