@@ -1,7 +1,7 @@
 // Wave-level FFT building blocks shared by stft.hip and istft.hip (gfx950).
 // Every thread owns 16 complex points; L = M/16 threads form one M-point transform, a wave64
 // runs 64/L transforms at once.  Stockham autosort passes of radix 16 / R2 / R3 in registers,
-// exchanges through a per-wave LDS slab with index i stored at i + i/16.
+// exchanges through a per-wave LDS slab, bank-swizzled by phys<L>().
 #pragma once
 #include "at_common.h"
 
@@ -122,7 +122,22 @@ struct Plan {
 };
 constexpr int WAVE_LDS_SLOTS = 1088;  // 64*16*(17/16) complex = 8704 B, same for every M
 
-__device__ __forceinline__ int phys(int i) { return i + (i >> 4); }
+// LDS slot of logical point i of an M = 16 L point frame.
+//  L <= 16 (several frames per wave): i + i/16 -- with the odd frame stride M + M/16 the stride-16
+//           stores of pass 1 and the contiguous reads are conflict-free.
+//  L >= 32: XOR swizzle of the low 4 bits with the 16-row index.  A permutation inside every
+//           16-row, so 32 contiguous lanes of a ds_read_b64 still cover all 64 banks (the +i/16
+//           padding made those reads wrap onto banks 0,1: 2-way conflict on EVERY exchange read,
+//           23 % of all LDS cycles in the r01 profile), and the 16 lanes of a pass-1
+//           ds_write_b64 (index 16 t + r) land on 16 distinct bank pairs.
+#ifndef AT_FFT_SWIZZLE
+#define AT_FFT_SWIZZLE 1
+#endif
+template <int L>
+__device__ __forceinline__ int phys(int i) {
+  if constexpr (L >= 32 && AT_FFT_SWIZZLE) return i ^ ((i >> 4) & 15);
+  else return i + (i >> 4);
+}
 
 // |z| with the hardware v_sqrt_f32 (1 ulp): the IEEE sqrtf() expansion costs ~10x more VALU
 __device__ __forceinline__ float cabs_fast(float2 z) { return __builtin_amdgcn_sqrtf(fmaf(z.x, z.x, z.y * z.y)); }
@@ -152,14 +167,14 @@ __device__ __forceinline__ void pass_compute_store(float2 (&a)[16], float2* __re
     const int j = t + b * L;
     const int o0 = (j / NS) * (NS * R) + (j % NS);
 #pragma unroll
-    for (int r = 0; r < R; ++r) buf[phys(o0 + r * NS)] = v[r];
+    for (int r = 0; r < R; ++r) buf[phys<L>(o0 + r * NS)] = v[r];
   }
 }
 
 template <int L>
 __device__ __forceinline__ void load_points(float2 (&a)[16], const float2* __restrict__ buf, int t) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) a[q] = buf[phys(t + L * q)];
+  for (int q = 0; q < 16; ++q) a[q] = buf[phys<L>(t + L * q)];
 }
 
 

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const IstftArgs A) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int n = t + L * q;
-      const float2 y = fbuf[phys(n)];
+      const float2 y = fbuf[phys<L>(n)];
       const float2 w = w2[n];
       if (live) out[n] = make_float2(y.x * inv_n * w.x, -y.y * inv_n * w.y);
     }

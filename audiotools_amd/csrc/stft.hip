@@ -15,7 +15,7 @@
 //    wave64 transforms 64/L frames at once (1 frame of n_fft=2048, 4 of 512);
 //  * Stockham autosort passes of radix 16,16,{2,4} in registers; the exchange
 //    between passes goes through a per-wave LDS slab of 8704 B (index i stored
-//    at i + i/16 so the stride-16 writes of pass 1 spread over all banks).
+//    bank-swizzled, see phys<L>() in fft_wave.h).
 //    Waves never synchronise with each other (no s_barrier in the kernel);
 //  * a wave walks a chunk of consecutive frames of one row, so the 4x overlap
 //    of the input between frames is served by L1/L2, HBM sees each sample once;
@@ -262,11 +262,11 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = t + L * q;
-      zk[q] = fbuf[phys(k)];
-      zm[q] = fbuf[phys((M - k) & (M - 1))];
+      zk[q] = fbuf[phys<L>(k)];
+      zm[q] = fbuf[phys<L>((M - k) & (M - 1))];
     }
     float2 zh = make_float2(0.f, 0.f);
-    if (t == 0) zh = fbuf[phys(M / 2)];
+    if (t == 0) zh = fbuf[phys<L>(M / 2)];
     wave_sync();  // all reads of Z done before the slab is reused for |X|
 
     // Issue the next frame's new loads BEFORE this frame's stores: vmcnt retires in order, so a

@@ -6,6 +6,7 @@ SURVEY.md 8(b) "Ownership"), and launches on torch's current stream.  No
 function here computes anything on the host beyond shapes.
 """
 import math
+import os
 
 import torch
 
@@ -182,8 +183,13 @@ def _pad8(n: int) -> int:
     return (n + 7) // 8 * 8
 
 
-def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False, replicate: bool = True):
-    """Per-item FIR with replicate padding.  ``taps`` (B or 1, L) odd-length, centred."""
+FIR_FFT_MIN_TAPS = 96   # below this the direct register-window kernel is cheaper than two block FFTs
+
+
+def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False, replicate: bool = True,
+                 method: str = "auto"):
+    """Per-item FIR with replicate padding.  ``taps`` (B or 1, L) odd-length, centred.
+    ``method``: "direct" (at_fir_per_item_f32), "fft" (overlap-save, at_fir_fft_f32) or "auto"."""
     _require_native_ok(audio)
     assert replicate
     B, C, T = audio.shape
@@ -195,6 +201,15 @@ def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False
     tp = torch.zeros((rows, Lp), dtype=torch.float32, device=audio.device)
     tp[:, :L] = taps.to(audio.device, torch.float32)
     out = torch.empty_like(audio)
+    if method == "auto":
+        method = os.environ.get("AT_FIR_METHOD") or ("fft" if L >= FIR_FFT_MIN_TAPS else "direct")
+    if method == "fft":
+        tw = tables.stft_twiddles(2048, audio.device)
+        code = _native.lib().at_fir_fft_f32(_native.ptr(audio), B, C, T, _native.ptr(tp), rows, Lp, half,
+                                            1 if highpass else 0, _native.ptr(tw), _native.ptr(out),
+                                            _native.current_stream(audio.device))
+        _native.check(code, "at_fir_fft_f32")
+        return out
     code = _native.lib().at_fir_per_item_f32(_native.ptr(audio), B, C, T, _native.ptr(tp), rows, Lp, half,
                                              1 if highpass else 0, _native.ptr(out), _native.current_stream(audio.device))
     _native.check(code, "at_fir_per_item_f32")

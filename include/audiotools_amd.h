@@ -112,6 +112,16 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
 int at_fir_per_item_f32(const float* x, int64_t B, int64_t C, int64_t T, const float* taps, int taps_rows,
                         int L_padded, int half, int highpass, float* out, void* stream);
 
+/* Same filter evaluated by overlap-save block FFTs (2048-sample blocks, wave-level FFT shared with
+ * the STFT kernel): the cost per output does not grow with the tap count (the direct form above
+ * spends 2*taps flop per sample).  Identical arguments and semantics; additionally
+ *   twiddles2048  (2048, 2) f32 device copy of at_stft_twiddles_host(2048, .)
+ * L_padded need not be a multiple of 8 here.  Filters longer than 1536 taps run as partitions of
+ * 1024 taps (one launch each, accumulating into out).  x and out must not alias.
+ */
+int at_fir_fft_f32(const float* x, int64_t B, int64_t C, int64_t T, const float* taps, int taps_rows, int L_padded,
+                   int half, int highpass, const float* twiddles2048, float* out, void* stream);
+
 /* ---- polyphase resampling ---------------------------------------------------------------
  * Replaces  audiotools/core/audio_signal.py:732  julius.resample_frac(x, old, new) (zeros 24,
  *           rolloff 0.945): replicate pad (width, width+old), conv1d with the (new, 2*width+old)

@@ -216,6 +216,29 @@ def test_sinc_filters_vs_oracle(highpass):
     assert s.stft_data is None
 
 
+@pytest.mark.parametrize("L", [9, 97, 613, 1047, 1535, 1537, 3001])
+@pytest.mark.parametrize("highpass", [False, True])
+def test_fir_direct_and_fft_forms(L, highpass):
+    """Both native FIR forms (register-window direct, overlap-save block FFT incl. the partitioned
+    case L > 1536) against float64 conv1d with replicate padding; asymmetric per-item taps, odd T."""
+    from audiotools_amd import kernels
+    B, C, T = 3, 2, 10007
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(B, C, T, generator=g)
+    taps = torch.randn(B, L, generator=g) / L ** 0.5
+    half = (L - 1) // 2
+    xp = torch.nn.functional.pad(x.double(), (half, half), mode="replicate")
+    ref = torch.stack([torch.nn.functional.conv1d(xp[b][:, None], taps[b].double()[None, None])[:, 0] for b in range(B)])
+    if highpass:
+        ref = x.double() - ref
+    for method in ("direct", "fft"):
+        got = kernels.fir_per_item(x.cuda(), taps.cuda(), highpass=highpass, method=method)
+        assert rel_err(got, ref.float()) < REL, method
+    shared = kernels.fir_per_item(x.cuda(), taps[:1].cuda(), highpass=highpass, method="fft")
+    ref0 = torch.nn.functional.conv1d(xp.reshape(-1, 1, xp.shape[-1]), taps[0].double()[None, None]).reshape(B, C, T)
+    assert rel_err(shared, ((x.double() - ref0) if highpass else ref0).float()) < REL
+
+
 def test_reference_dsp_properties_gpu():
     """tests/core/test_dsp.py:76-109 on the HIP path."""
     sr, f = 44100, 440

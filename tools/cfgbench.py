@@ -11,7 +11,9 @@ from audiotools_amd import transforms as tfm
 ap = argparse.ArgumentParser()
 ap.add_argument("--b4", type=int, default=1024)
 ap.add_argument("--b5", type=int, default=256)
+ap.add_argument("--only", default="lowpass,eq,applyir,chain,cfg5", help="comma list: lowpass,eq,applyir,chain,cfg5")
 args = ap.parse_args()
+only = set(args.only.split(","))
 dev = "cuda"
 
 
@@ -39,12 +41,18 @@ kw = chain.batch_instantiate(list(range(B)), A.AudioSignal(x[:1], SR))
 print(f"cfg4 batch_instantiate (host)       {(time.perf_counter() - t0) * 1e3:9.1f} ms")
 kw = A.util.prepare_batch(kw, dev)
 kc = kw["Compose"]
-timed(lambda: A.AudioSignal(x.clone(), SR).low_pass(kc["0.LowPass"]["cutoff"]), "cfg4 low_pass (B per-item cutoffs)")
-timed(lambda: A.AudioSignal(x.clone(), SR).equalizer(kc["1.Equalizer"]["eq"]), "cfg4 equalizer (6 bands)")
+if "lowpass" in only:
+    timed(lambda: A.AudioSignal(x.clone(), SR).low_pass(kc["0.LowPass"]["cutoff"]), "cfg4 low_pass (B per-item cutoffs)")
+if "eq" in only:
+    timed(lambda: A.AudioSignal(x.clone(), SR).equalizer(kc["1.Equalizer"]["eq"]), "cfg4 equalizer (6 bands)")
 ir = kc["2.RoomImpulseResponse"]["ir_signal"]
-timed(lambda: A.AudioSignal(x.clone(), SR).apply_ir(ir.clone(), kc["2.RoomImpulseResponse"]["drr"], kc["2.RoomImpulseResponse"]["eq"]), "cfg4 apply_ir (2 s RIR)")
-ms = timed(lambda: chain(A.AudioSignal(x.clone(), SR), **kw), "cfg4 full chain")
-print(f"cfg4 throughput: {B * 5.0 / (ms * 1e-3):.0f} audio-seconds/sec")
+if "applyir" in only:
+    timed(lambda: A.AudioSignal(x.clone(), SR).apply_ir(ir.clone(), kc["2.RoomImpulseResponse"]["drr"], kc["2.RoomImpulseResponse"]["eq"]), "cfg4 apply_ir (2 s RIR)")
+if "chain" in only:
+    ms = timed(lambda: chain(A.AudioSignal(x.clone(), SR), **kw), "cfg4 full chain")
+    print(f"cfg4 throughput: {B * 5.0 / (ms * 1e-3):.0f} audio-seconds/sec")
+if "cfg5" not in only:
+    sys.exit(0)
 
 # ---- cfg5 (per-GPU share)
 del x, sig, kw, kc, ir

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel micro-benchmark on the north-star shapes (development aid).
-usage: python tools/kbench.py [--batch 512] [--iters 10] [--what stft,stftmel,mel,lufs]"""
+usage: python tools/kbench.py [--batch 512] [--iters 10] [--what stft,stftmel,melonly,lufs,istft,copy]"""
 import argparse
 import os
 import sys
@@ -54,6 +54,10 @@ for what in args.what.split(","):
                rows * T * 4 + rows * N * 80 * 4, "mel-only")
     elif what == "lufs":
         timeit(lambda: kernels.integrated_loudness(x, SR), rows * T * 4, "lufs")
+    elif what == "istft":
+        X, _ = kernels.stft_mel(x, win, n_fft, hop)
+        timeit(lambda: kernels.istft(X, win, n_fft, hop, T), rows * T * 4 + rows * N * F * 8, "istft")
+        del X
     elif what == "copy":
         y = torch.empty(rows * N * F * 2, device=dev)
         timeit(lambda: y.fill_(1.0), y.numel() * 4, "fill")
