@@ -58,8 +58,8 @@ SIGNATURES = {
     "at_mel_units_host": (_i32, [_p, _i32, _i32, _p, _p]),
     "at_stft_mel_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
-    "at_istft_workspace_bytes": (_i64, [_i64, _i64, _i32]),
-    "at_istft_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i64, _p, _p, _i64, _p]),
+    "at_istft_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
+    "at_istft_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i64, _i64, _p, _p, _i64, _p]),
     "at_fir_per_item_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "at_fir_fft_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "at_resample_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),

@@ -4,6 +4,15 @@
 // window, length, center=True): per frame a C2R FFT, multiplication by the window, overlap-add,
 // division by the overlap-added squared window, removal of the n_fft/2 centre padding.
 //
+// Two code paths:
+//  * hop = n_fft / {2,4,8,16}: FUSED kernel (istft_fused_kernel).  A frame slot (L lanes) walks a
+//    run of consecutive frames of one row; the windowed frames are overlap-added in a register
+//    window of n_fft samples that shifts by one hop per frame (the mirror image of the register
+//    reuse in the forward kernel), finished hops are scaled by the reciprocal envelope and stored.
+//    HBM sees X once (+ (n_fft/hop - 1)/run of re-read at run boundaries) and the signal once:
+//    no frame buffer, no second pass.
+//  * any other hop: kernel A + kernel B below through a (rows, frames, n_fft) frame buffer.
+//
 // Kernel A (istft_frames_kernel): one wave per 64/L frames.  The Hermitian half spectrum of a
 // frame is folded into the M-point complex spectrum of z[n] = x[2n] + i x[2n+1]
 //     Z[k] = (X[k] + conj X[M-k]) + i e^{+2 pi i k/N} (X[k] - conj X[M-k])
@@ -134,6 +143,212 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
   }
 }
 
+// ---- fused inverse: FFT + window + overlap-add in registers ---------------------------------
+struct IstftFusedArgs {
+  const float2* X;        // (rows, n_x, M+1) bin-contiguous
+  const float* window;    // (N)
+  const float2* tw;       // (N)
+  const float* inv_env;   // ((n_frames-1)*hop + N): 1 / sum_f w^2, 0 where the envelope vanishes
+  float* out;             // (rows, length)
+  int64_t rows;
+  int64_t length;
+  int n_x;                // frames stored in X
+  int lead;               // virtual all-zero frames in front of X's first frame (match_stride: 2)
+  int n_frames;           // virtual frames in total (lead + n_x + trailing zero frames)
+  int n_seg;              // hop-sized output segments per row = n_frames - 1 + N/hop
+  int run;                // segments per unit
+  int runs_per_row;
+  int64_t total_units;    // rows * runs_per_row
+};
+
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };  // dword-aligned pair
+
+// envelope: every padded position gathers w^2 of the <= N/hop frames that cover it
+__global__ __launch_bounds__(256) void istft_env_kernel(const float* __restrict__ window, float* __restrict__ inv_env,
+                                                        int n_frames, int N, int hop, int64_t total) {
+  for (int64_t pp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pp < total; pp += (int64_t)gridDim.x * blockDim.x) {
+    int64_t f_hi = pp / hop;
+    if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+    int64_t f_lo = (pp - N + hop) / hop;
+    if (pp - N + 1 <= 0) f_lo = 0;
+    if (f_lo < 0) f_lo = 0;
+    float env = 0.f;
+    for (int64_t f = f_lo; f <= f_hi; ++f) {
+      const int n = (int)(pp - f * hop);
+      if (n < 0 || n >= N) continue;
+      const float w = window[n];
+      env = fmaf(w, w, env);
+    }
+    inv_env[pp] = env > 1e-11f ? 1.0f / env : 0.f;
+  }
+}
+
+#ifndef AT_ISTFT_WPS
+#define AT_ISTFT_WPS 2
+#endif
+
+template <int M, int SH /* hop = 2 L SH */>
+__global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const IstftFusedArgs A) {
+  using P = Plan<M>;
+  constexpr int L = P::L, FW = P::FW, N = 2 * M, HOP = 2 * L * SH, R = N / HOP;
+  __shared__ float2 lds[4 * WAVE_LDS_SLOTS];
+  __shared__ float2 s_win2[M];
+  __shared__ float2 s_twf[M];                                     // fold twiddles (cos, -sin)(2 pi k / N), k < M
+  __shared__ __attribute__((aligned(16))) float s_tw2[16 * 36];   // pass-2 twiddles, row = j mod 16
+  for (int i = threadIdx.x; i < M; i += 256) {
+    s_win2[i] = reinterpret_cast<const float2*>(A.window)[i];
+    s_twf[i] = A.tw[i];
+  }
+  if constexpr (P::R2 > 1) {
+    for (int i = threadIdx.x; i < 16 * P::R2; i += 256) {
+      const int jj = i / P::R2, r = i % P::R2;
+      reinterpret_cast<float2*>(s_tw2 + jj * 36)[r] = A.tw[r * jj * (N / (16 * P::R2))];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fs = lane / L, t = lane % L;
+  float2* fbuf = lds + wave * WAVE_LDS_SLOTS + fs * P::SLOTS;
+  constexpr int NB2 = 16 / P::R2;
+  constexpr int NB3 = 16 / P::R3;
+
+  // this frame slot's unit: (row, run of segments [h0, h1))
+  int64_t unit = ((int64_t)blockIdx.x * 4 + wave) * FW + fs;
+  const bool unit_ok = unit < A.total_units;
+  if (!unit_ok) unit = A.total_units - 1;   // keep the lanes converged; nothing is stored
+  const int64_t row = unit / A.runs_per_row;
+  const int h0 = (int)(unit - row * A.runs_per_row) * A.run;
+  const int h1 = min(h0 + A.run, A.n_seg);
+  const float2* __restrict__ Xrow = A.X + row * (int64_t)A.n_x * (M + 1);
+  float* __restrict__ orow = A.out + row * A.length;
+  const int len = (int)A.length;
+
+  float2 tw3b[P::R3 > 1 ? NB3 : 1];
+  if constexpr (P::R3 > 1) {
+    constexpr int NS = 16 * P::R2;
+#pragma unroll
+    for (int b = 0; b < NB3; ++b) tw3b[b] = A.tw[((t + b * L) % NS) * (N / (NS * P::R3))];
+  }
+
+  float2 acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = make_float2(0.f, 0.f);
+
+  const float inv_n = 1.0f / (float)N;
+  // every slot runs the same trip count; frames outside [lead, lead + n_x) are all-zero
+  for (int i = 0; i < A.run + R - 1; ++i) {
+    const int f = h0 - (R - 1) + i;          // virtual frame added in this step = segment finished
+    const int fx = f - A.lead;
+    const bool live = fx >= 0 && fx < A.n_x && f < h1;
+    const float2* __restrict__ Xf = Xrow + (int64_t)(live ? fx : 0) * (M + 1);
+    float2 a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = t + L * q;
+      float2 xa = Xf[k];
+      float2 xm = Xf[M - k];
+      if (!live) { xa = make_float2(0.f, 0.f); xm = xa; }
+      if (k == 0) { xa.y = 0.f; xm.y = 0.f; }  // c2r ignores the imaginary part of DC and Nyquist
+      const float2 w = s_twf[k];
+      const float c = w.x, s = -w.y;
+      const float sr = xa.x + xm.x, si = xa.y - xm.y;
+      const float dr = xa.x - xm.x, di = xa.y + xm.y;
+      a[q] = make_float2(sr - s * dr - c * di, -(si + c * dr - s * di));
+    }
+    pass_compute_store<16, 1, L>(a, fbuf, t, nullptr);
+    wave_sync();
+    if constexpr (P::R2 > 1) {
+      load_points<L>(a, fbuf, t);
+      wave_sync();
+      float2 tw2[NB2 * P::R2];
+#pragma unroll
+      for (int b = 0; b < NB2; ++b) {
+        const float2* rowp = reinterpret_cast<const float2*>(s_tw2 + ((t + b * L) & 15) * 36);
+#pragma unroll
+        for (int r = 1; r < P::R2; ++r) tw2[b * P::R2 + r] = rowp[r];
+      }
+      pass_compute_store<P::R2, 16, L>(a, fbuf, t, tw2);
+      wave_sync();
+    }
+    if constexpr (P::R3 > 1) {
+      load_points<L>(a, fbuf, t);
+      wave_sync();
+      float2 tw3[NB3 * P::R3];
+#pragma unroll
+      for (int b = 0; b < NB3; ++b) {
+        tw3[b * P::R3 + 1] = tw3b[b];
+#pragma unroll
+        for (int r = 2; r < P::R3; ++r) tw3[b * P::R3 + r] = cmul(tw3[b * P::R3 + r - 1], tw3b[b]);
+      }
+      pass_compute_store<P::R3, 16 * P::R2, L>(a, fbuf, t, tw3);
+      wave_sync();
+    }
+    // windowed frame into the register window: acc[q] covers samples 2(t + L q), +1 of frame f
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int n = t + L * q;
+      const float2 y = fbuf[phys<L>(n)];
+      const float2 w = s_win2[n];
+      acc[q].x = fmaf(y.x * inv_n, w.x, acc[q].x);
+      acc[q].y = fmaf(-y.y * inv_n, w.y, acc[q].y);
+    }
+    wave_sync();
+    // segment f is complete: scale by 1/envelope, store, shift the window by one hop
+    if (unit_ok && f >= h0 && f < h1) {
+#pragma unroll
+      for (int q = 0; q < SH; ++q) {
+        const int64_t pp = (int64_t)f * HOP + 2 * (t + L * q);
+        const int p = (int)(pp - N / 2);
+        if (p >= -1 && p < len) {
+          const float e0 = A.inv_env[pp], e1 = A.inv_env[pp + 1];
+          if (p >= 0 && p + 1 < len) {
+            f2u o; o.x = acc[q].x * e0; o.y = acc[q].y * e1;
+            *reinterpret_cast<f2u*>(orow + p) = o;
+          } else if (p >= 0) {
+            orow[p] = acc[q].x * e0;
+          } else {
+            orow[p + 1] = acc[q].y * e1;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 16 - SH; ++q) acc[q] = acc[q + SH];
+#pragma unroll
+    for (int q = 16 - SH; q < 16; ++q) acc[q] = make_float2(0.f, 0.f);
+  }
+}
+
+template <int M, int SH>
+int launch_fused(const IstftFusedArgs& A, hipStream_t stream) {
+  constexpr int FW = Plan<M>::FW;
+  const int64_t waves = (A.total_units + FW - 1) / FW;
+  const int64_t blocks = (waves + 3) / 4;
+  if (blocks > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((istft_fused_kernel<M, SH>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+template <int M>
+int launch_fused_sh(int sh, const IstftFusedArgs& A, hipStream_t stream) {
+  switch (sh) {
+    case 1: return launch_fused<M, 1>(A, stream);
+    case 2: return launch_fused<M, 2>(A, stream);
+    case 4: return launch_fused<M, 4>(A, stream);
+    case 8: return launch_fused<M, 8>(A, stream);
+  }
+  return AT_ERR_UNSUPPORTED;
+}
+
+// hop = n_fft / {2,4,8,16}  <=>  hop = 2 L SH with SH in {8,4,2,1}
+int fused_shift(int n_fft, int hop) {
+  for (int r = 2; r <= 16; r *= 2)
+    if (hop * r == n_fft) return 16 / r;
+  return 0;
+}
+
 template <int M>
 int launch_frames(const IstftArgs& A, hipStream_t stream) {
   int64_t blocks = (A.total_groups + 3) / 4;
@@ -147,24 +362,68 @@ int launch_frames(const IstftArgs& A, hipStream_t stream) {
 
 extern "C" {
 
-// bytes of the (rows, n_frames, n_fft) float frame buffer
-int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft) {
-  if (rows < 0 || n_frames < 0 || n_fft <= 0) return AT_ERR_INVALID;
+// bytes of workspace: the reciprocal envelope ((n_frames-1)*hop + n_fft floats) for the fused path,
+// plus the (rows, n_frames, n_fft) float frame buffer when hop is not n_fft / {2,4,8,16}
+int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft, int hop) {
+  if (rows < 0 || n_frames <= 0 || n_fft <= 0 || hop <= 0) return AT_ERR_INVALID;
+  if (fused_shift(n_fft, hop)) return ((n_frames - 1) * hop + n_fft) * 4;
   return rows * n_frames * (int64_t)n_fft * 4;
 }
 
-// X (rows, n_frames, n_fft/2+1) complex64 interleaved, bin-contiguous (as at_stft_mel_f32 writes it);
+// X (rows, n_x, n_fft/2+1) complex64 interleaved, bin-contiguous (as at_stft_mel_f32 writes it).
+// The transform is taken over n_frames = lead + n_x + trail VIRTUAL frames of which the first
+// `lead` and the last n_frames - lead - n_x are all-zero (match_stride re-inserts the two edge
+// frames the forward transform dropped, audio_signal.py:1278-1281, without copying X).
 // out (rows, length): sample p comes from centre-padded position p + n_fft/2.
-int at_istft_f32(const float* X, int64_t rows, int64_t n_frames, const float* window, const float* twiddles, int n_fft,
-                 int hop, int64_t length, float* out, void* workspace, int64_t workspace_bytes, void* stream) {
-  if (!X || !window || !twiddles || !out || rows < 0 || n_frames <= 0 || hop <= 0 || length < 0) return AT_ERR_INVALID;
+int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft,
+                 int hop, int lead, int64_t n_frames, int64_t length, float* out, void* workspace,
+                 int64_t workspace_bytes, void* stream) {
+  if (!X || !window || !twiddles || !out || rows < 0 || n_x <= 0 || hop <= 0 || length < 0 || lead < 0 ||
+      n_frames < lead + n_x)
+    return AT_ERR_INVALID;
   if (!(n_fft >= 32 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0)) return AT_ERR_UNSUPPORTED;
-  if (n_frames >= (1LL << 31)) return AT_ERR_UNSUPPORTED;
+  if (n_frames >= (1LL << 31) / (hop > n_fft ? hop : n_fft) || length >= (1LL << 31) - n_fft) return AT_ERR_UNSUPPORTED;
   if (rows == 0 || length == 0) return AT_OK;
-  if (!workspace || workspace_bytes < at_istft_workspace_bytes(rows, n_frames, n_fft)) return AT_ERR_INVALID;
+  if (!workspace || workspace_bytes < at_istft_workspace_bytes(rows, n_frames, n_fft, hop)) return AT_ERR_INVALID;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int M = n_fft / 2;
   const int FW = 64 / (M / 16);
+  const int sh = fused_shift(n_fft, hop);
+  if (sh) {
+    IstftFusedArgs F;
+    F.X = reinterpret_cast<const float2*>(X); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
+    F.inv_env = reinterpret_cast<const float*>(workspace); F.out = out; F.rows = rows; F.length = length;
+    F.n_x = (int)n_x; F.lead = lead; F.n_frames = (int)n_frames;
+    const int R = n_fft / hop;
+    F.n_seg = (int)n_frames - 1 + R;
+    // runs: >= ~16k frame-slot units so the chip is filled a few times over, but long enough that
+    // the R-1 warm-up frames of a run stay a small fraction
+    int64_t want = (16384 + rows - 1) / rows;
+    int run = (int)((F.n_seg + want - 1) / want);
+    if (run < 8 * R) run = 8 * R;
+    if (run > F.n_seg) run = F.n_seg;
+    F.run = run;
+    F.runs_per_row = (F.n_seg + run - 1) / run;
+    F.total_units = rows * F.runs_per_row;
+    const int64_t env_n = (n_frames - 1) * hop + n_fft;
+    int64_t eb = (env_n + 255) / 256;
+    if (eb > 4096) eb = 4096;
+    hipLaunchKernelGGL(istft_env_kernel, dim3((unsigned)eb), dim3(256), 0, st, window, reinterpret_cast<float*>(workspace),
+                       (int)n_frames, n_fft, hop, env_n);
+    AT_LAUNCH_CHECK();
+    switch (M) {
+      case 16: return launch_fused_sh<16>(sh, F, st);
+      case 32: return launch_fused_sh<32>(sh, F, st);
+      case 64: return launch_fused_sh<64>(sh, F, st);
+      case 128: return launch_fused_sh<128>(sh, F, st);
+      case 256: return launch_fused_sh<256>(sh, F, st);
+      case 512: return launch_fused_sh<512>(sh, F, st);
+      case 1024: return launch_fused_sh<1024>(sh, F, st);
+    }
+    return AT_ERR_UNSUPPORTED;
+  }
+  // generic hop: frame buffer + gather.  Virtual zero frames are not supported here.
+  if (lead != 0 || n_frames != n_x) return AT_ERR_UNSUPPORTED;
   IstftArgs A;
   A.X = reinterpret_cast<const float2*>(X); A.window = window; A.tw = reinterpret_cast<const float2*>(twiddles);
   A.frames = reinterpret_cast<float*>(workspace); A.rows = rows; A.n_frames = (int)n_frames;

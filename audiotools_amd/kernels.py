@@ -101,12 +101,22 @@ def _nola_ok(window: torch.Tensor, n_fft: int, hop: int) -> bool:
     return _nola_cache[key]
 
 
-def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, length: int) -> torch.Tensor:
+def istft_fused_supported(n_fft: int, hop: int) -> bool:
+    """True when at_istft_f32 takes its fused single-pass path (hop = n_fft / {2,4,8,16})."""
+    return any(hop * r == n_fft for r in (2, 4, 8, 16))
+
+
+def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, length: int,
+          lead: int = 0, trail: int = 0) -> torch.Tensor:
     """Inverse STFT of a (B, C, F, N) complex64 HIP tensor -> (B, C, length) float32
-    (torch.istft(center=True) semantics)."""
+    (torch.istft(center=True) semantics).  ``lead`` / ``trail`` all-zero frames are added in front
+    of / behind the N frames without copying (match_stride, audio_signal.py:1278-1281)."""
     _require_native_ok(stft_bcfn)
     B, C, F, N = stft_bcfn.shape
     assert F == n_fft // 2 + 1
+    if (lead or trail) and not istft_fused_supported(n_fft, hop):
+        stft_bcfn = torch.nn.functional.pad(stft_bcfn, (lead, trail))
+        N, lead, trail = N + lead + trail, 0, 0
     # physical (B, C, N, F) bin-contiguous layout; a no-op for tensors produced by stft_mel()
     X = stft_bcfn.transpose(2, 3).contiguous()
     dev = X.device
@@ -114,12 +124,13 @@ def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, l
     if not _nola_ok(window, n_fft, hop):
         raise RuntimeError("istft: window overlap add min is (nearly) zero -- the STFT is not invertible")
     lib = _native.lib()
-    need = int(lib.at_istft_workspace_bytes(B * C, N, n_fft))
+    n_frames = lead + N + trail
+    need = int(lib.at_istft_workspace_bytes(B * C, n_frames, n_fft, hop))
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     tw = tables.stft_twiddles(n_fft, dev)
     out = torch.empty((B, C, length), dtype=torch.float32, device=dev)
     code = lib.at_istft_f32(_native.ptr(torch.view_as_real(X)), B * C, N, _native.ptr(window), _native.ptr(tw), n_fft, hop,
-                            length, _native.ptr(out), _native.ptr(ws), need, _native.current_stream(dev))
+                            lead, n_frames, length, _native.ptr(out), _native.ptr(ws), need, _native.current_stream(dev))
     _native.check(code, "at_istft_f32")
     return out
 

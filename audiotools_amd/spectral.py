@@ -106,11 +106,12 @@ class SpectralMixin:
         right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
         if length is None:
             length = self.original_signal_length + 2 * pad + right_pad
-        if match_stride:
-            X = torch.nn.functional.pad(X, (2, 2))
         if kernels.is_native(torch.view_as_real(self.stft_data)) and kernels.stft_native_supported(n_fft):
-            x = kernels.istft(X.reshape(nb, nch, nf, X.shape[-1]), window, n_fft, hop, int(length))
+            edge = 2 if match_stride else 0   # the two frames per side the forward transform dropped
+            x = kernels.istft(self.stft_data, window, n_fft, hop, int(length), lead=edge, trail=edge)
         else:
+            if match_stride:
+                X = torch.nn.functional.pad(X, (2, 2))
             x = torch.istft(X, n_fft=n_fft, hop_length=hop, window=window, length=length, center=True)
         x = x.reshape(nb, nch, -1)
         if match_stride:

@@ -70,16 +70,24 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
                     float* mel_out, void* stream);
 
 /* ---- inverse STFT --------------------------------------------------------------------------
- * Replaces  audiotools/core/audio_signal.py:1283-1290  torch.istft(X, n_fft, hop, window, length,
- *           center=True).  Power-of-two n_fft in [32, 2048]; any hop.
- *   X        (rows, n_frames, n_fft/2+1) complex64 interleaved, bin-contiguous (the layout
+ * Replaces  audiotools/core/audio_signal.py:1278-1290  (F.pad of the two edge frames when
+ *           match_stride) + torch.istft(X, n_fft, hop, window, length, center=True).
+ *           Power-of-two n_fft in [32, 2048]; any hop.
+ *   X        (rows, n_x, n_fft/2+1) complex64 interleaved, bin-contiguous (the layout
  *            at_stft_mel_f32 writes / torch.stft returns)
+ *   lead, n_frames   the transform runs over n_frames >= lead + n_x VIRTUAL frames: `lead` all-zero
+ *            frames, the n_x frames of X, then all-zero frames (match_stride: lead = 2,
+ *            n_frames = n_x + 4; otherwise lead = 0, n_frames = n_x)
  *   out      (rows, length) f32; samples with no frame overlap are 0 (torch pads to `length`)
- *   workspace at_istft_workspace_bytes(rows, n_frames, n_fft) bytes (windowed frames)
+ *   workspace at_istft_workspace_bytes(rows, n_frames, n_fft, hop) bytes
+ * hop = n_fft/{2,4,8,16}: ONE fused kernel (FFT, window, overlap-add in registers, envelope
+ * division) -- X is read once, out written once; the workspace only holds the reciprocal envelope.
+ * Other hops go through a (rows, n_frames, n_fft) frame buffer in the workspace (lead must be 0).
  */
-int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft);
-int at_istft_f32(const float* X, int64_t rows, int64_t n_frames, const float* window, const float* twiddles, int n_fft,
-                 int hop, int64_t length, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft, int hop);
+int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft,
+                 int hop, int lead, int64_t n_frames, int64_t length, float* out, void* workspace,
+                 int64_t workspace_bytes, void* stream);
 
 /* ---- BS.1770 integrated loudness ---------------------------------------------------
  * Replaces  audiotools/core/loudness.py:102-126  (2x torchaudio.functional.lfilter, the

@@ -305,7 +305,9 @@ def test_apply_ir_and_normalize():
 @pytest.mark.parametrize("win,hop,wt,ms", [(2048, 512, "hann", False), (2048, 512, "sqrt_hann", True),
                                            (512, 128, "sqrt_hann", False), (512, 128, "hann", True),
                                            (1024, 256, "hann", False), (256, 64, "sqrt_hann", True),
-                                           (512, 100, "hann", False), (64, 16, "hann", False)])
+                                           (512, 100, "hann", False), (64, 16, "hann", False),
+                                           (1024, 512, "hann", False), (512, 64, "hann", False),
+                                           (128, 8, "sqrt_hann", False), (32, 8, "hann", True)])
 def test_istft_vs_oracle_and_roundtrip(win, hop, wt, ms):
     """tests/core/test_audio_signal.py:400-456: istft(stft(x)) == x; plus values vs torch.istft on CPU."""
     x = synth.audio_batch(3, 2, 22050 + 7, seed=win + hop, gaps=False)
