@@ -236,25 +236,53 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   for (int q = 0; q < 16; ++q) acc[q] = make_float2(0.f, 0.f);
 
   const float inv_n = 1.0f / (float)N;
-  // every slot runs the same trip count; frames outside [lead, lead + n_x) are all-zero
-  for (int i = 0; i < A.run + R - 1; ++i) {
-    const int f = h0 - (R - 1) + i;          // virtual frame added in this step = segment finished
+  // Every lane loads bin k = t + L q of its frame ONCE (ascending, 512 B per wave instruction);
+  // the Hermitian partner X[M-k] of the fold is register 15-q of lane (L - t) mod L and comes
+  // over the LDS crossbar (ds_bpermute).  Lane 0 pairs with itself: register 16-q, and the
+  // Nyquist bin for q = 0.  Loads are branch-free (a dead frame reads frame 0 and is zeroed by
+  // select) and issued one frame AHEAD, right after the fold consumed the registers, so their
+  // latency hides behind the FFT of the current frame.
+  const int src_lane = (lane - t) + ((L - t) & (L - 1));
+  float2 xa[16], xN;
+  auto issue_loads = [&](int f) __attribute__((always_inline)) -> bool {
     const int fx = f - A.lead;
     const bool live = fx >= 0 && fx < A.n_x && f < h1;
     const float2* __restrict__ Xf = Xrow + (int64_t)(live ? fx : 0) * (M + 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xa[q] = Xf[t + L * q];
+    xN = Xf[M];
+    return live;
+  };
+  bool live_nxt = issue_loads(h0 - (R - 1));
+  // every slot runs the same trip count; frames outside [lead, lead + n_x) are all-zero
+  for (int i = 0; i < A.run + R - 1; ++i) {
+    const int f = h0 - (R - 1) + i;          // virtual frame added in this step = segment finished
+    const bool live = live_nxt;
     float2 a[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int k = t + L * q;
-      float2 xa = Xf[k];
-      float2 xm = Xf[M - k];
-      if (!live) { xa = make_float2(0.f, 0.f); xm = xa; }
-      if (k == 0) { xa.y = 0.f; xm.y = 0.f; }  // c2r ignores the imaginary part of DC and Nyquist
+      float2 xk = xa[q];
+      const float2 sv = make_float2(__shfl(xa[15 - q].x, src_lane, 64), __shfl(xa[15 - q].y, src_lane, 64));
+      const float2 own = q == 0 ? xN : xa[q == 0 ? 0 : 16 - q];
+      float2 xm = t == 0 ? own : sv;
+      if (!live) { xk = make_float2(0.f, 0.f); xm = xk; }
+      if (k == 0) { xk.y = 0.f; xm.y = 0.f; }  // c2r ignores the imaginary part of DC and Nyquist
       const float2 w = s_twf[k];
       const float c = w.x, s = -w.y;
-      const float sr = xa.x + xm.x, si = xa.y - xm.y;
-      const float dr = xa.x - xm.x, di = xa.y + xm.y;
+      const float sr = xk.x + xm.x, si = xk.y - xm.y;
+      const float dr = xk.x - xm.x, di = xk.y + xm.y;
       a[q] = make_float2(sr - s * dr - c * di, -(si + c * dr - s * di));
+    }
+    live_nxt = issue_loads(f + 1);
+    // reciprocal envelope of the segment this step finishes (table is L2 resident); loaded here,
+    // far ahead of the stores that use it
+    float2 env[SH];
+    {
+      const int fe = f < 0 ? 0 : (f >= A.n_seg ? A.n_seg - 1 : f);
+      const float2* __restrict__ e2 = reinterpret_cast<const float2*>(A.inv_env) + (int64_t)fe * (HOP / 2);
+#pragma unroll
+      for (int q = 0; q < SH; ++q) env[q] = e2[t + L * q];
     }
     pass_compute_store<16, 1, L>(a, fbuf, t, nullptr);
     wave_sync();
@@ -294,22 +322,25 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
       acc[q].y = fmaf(-y.y * inv_n, w.y, acc[q].y);
     }
     wave_sync();
-    // segment f is complete: scale by 1/envelope, store, shift the window by one hop
-    if (unit_ok && f >= h0 && f < h1) {
+    // segment f is complete: scale by 1/envelope, store, shift the window by one hop.
+    // Interior segments (all lanes of the wave inside [0, length)) take straight-line stores; the
+    // row edges go through the guarded path.
+    {
+      const bool emit = unit_ok && f >= h0 && f < h1;
+      const int p_seg = f * HOP - N / 2;                       // first output sample of the segment
+      const bool inside = emit && p_seg >= 0 && p_seg + HOP <= len;
+      if (__all(inside)) {
 #pragma unroll
-      for (int q = 0; q < SH; ++q) {
-        const int64_t pp = (int64_t)f * HOP + 2 * (t + L * q);
-        const int p = (int)(pp - N / 2);
-        if (p >= -1 && p < len) {
-          const float e0 = A.inv_env[pp], e1 = A.inv_env[pp + 1];
-          if (p >= 0 && p + 1 < len) {
-            f2u o; o.x = acc[q].x * e0; o.y = acc[q].y * e1;
-            *reinterpret_cast<f2u*>(orow + p) = o;
-          } else if (p >= 0) {
-            orow[p] = acc[q].x * e0;
-          } else {
-            orow[p + 1] = acc[q].y * e1;
-          }
+        for (int q = 0; q < SH; ++q) {
+          f2u o; o.x = acc[q].x * env[q].x; o.y = acc[q].y * env[q].y;
+          *reinterpret_cast<f2u*>(orow + p_seg + 2 * (t + L * q)) = o;
+        }
+      } else if (emit) {
+#pragma unroll
+        for (int q = 0; q < SH; ++q) {
+          const int p = p_seg + 2 * (t + L * q);
+          if (p >= 0 && p < len) orow[p] = acc[q].x * env[q].x;
+          if (p + 1 >= 0 && p + 1 < len) orow[p + 1] = acc[q].y * env[q].y;
         }
       }
     }
