@@ -1,0 +1,229 @@
+// Row reductions and impulse-response preparation around the FFT convolution (gfx950).
+//
+// The reference does these as chains of whole-tensor torch ops (abs -> max -> where -> mul ...);
+// on the GPU every link of such a chain is a full HBM pass.  Each entry point here is ONE pass
+// (or one read-twice/write-once pass for alter_drr) with one workgroup per (item, channel) row:
+//   at_absmax_f32      audiotools/core/effects.py:100,118,160,175,213-216  x.abs().max(-1), argmax
+//   at_roll_pad_f32    effects.py:85-100  zero_pad(other) + roll so the |peak| sits at sample 0
+//   at_alter_drr_f32   effects.py:540-647  decompose_ir + solve_alpha + alter_drr + ensure_max_of_audio
+#include "at_common.h"
+
+namespace {
+
+constexpr int RT = 512;  // threads per row workgroup
+
+struct MaxIdx {
+  float v;
+  int64_t i;
+};
+
+// first-occurrence arg-max: larger value wins, ties go to the smaller index (torch semantics)
+__device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+__device__ __forceinline__ MaxIdx block_argmax(MaxIdx m, MaxIdx* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MaxIdx other;
+    other.v = __shfl_xor(m.v, o, 64);
+    other.i = __shfl_xor(m.i, o, 64);
+    m = better(m, other);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[wave] = m;
+  __syncthreads();
+  MaxIdx r = sh[0];
+  for (int w = 1; w < RT / 64; ++w) r = better(r, sh[w]);
+  return r;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = at::wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int w = 0; w < RT / 64; ++w) r += sh[w];
+  return r;
+}
+
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = at::wave_max(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int w = 1; w < RT / 64; ++w) r = fmaxf(r, sh[w]);
+  return r;
+}
+
+// ---- per-row max |x| and its first index ------------------------------------------------------
+__global__ __launch_bounds__(RT) void absmax_kernel(const float* __restrict__ x, int64_t rows, int64_t T,
+                                                    float* __restrict__ vmax, int64_t* __restrict__ imax) {
+  __shared__ MaxIdx sh[RT / 64];
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const float* __restrict__ xr = x + row * T;
+    MaxIdx m{-1.0f, 0};
+    const bool vec = ((reinterpret_cast<uintptr_t>(xr) & 15) == 0);
+    const int64_t T4 = vec ? T / 4 : 0;
+    for (int64_t i = threadIdx.x; i < T4; i += RT) {
+      const float4 v = reinterpret_cast<const float4*>(xr)[i];
+      const float a[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (a[u] > m.v) { m.v = a[u]; m.i = 4 * i + u; }
+    }
+    for (int64_t i = 4 * T4 + threadIdx.x; i < T; i += RT) {
+      const float a = fabsf(xr[i]);
+      if (a > m.v) { m.v = a; m.i = i; }
+    }
+    m = block_argmax(m, sh);
+    if (threadIdx.x == 0) {
+      vmax[row] = m.v;
+      if (imax) imax[row] = m.i;
+    }
+  }
+}
+
+// ---- out[r, n] = xz[(n + shift[r]) mod T],  xz = x zero-padded (or truncated) to length T -------
+__global__ __launch_bounds__(256) void roll_pad_kernel(const float* __restrict__ x, int64_t rows, int64_t L,
+                                                       const int64_t* __restrict__ shift, int64_t T,
+                                                       float* __restrict__ out) {
+  const int64_t row = blockIdx.y;
+  const float* __restrict__ xr = x + row * L;
+  float* __restrict__ orow = out + row * T;
+  int64_t s = shift ? shift[row] % T : 0;
+  if (s < 0) s += T;
+  const int64_t Lc = L < T ? L : T;
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < T; n += (int64_t)gridDim.x * blockDim.x) {
+    int64_t src = n + s;
+    if (src >= T) src -= T;
+    orow[n] = src < Lc ? xr[src] : 0.f;
+  }
+}
+
+// ---- direct-to-reverberant ratio change of an impulse response ---------------------------------
+// One workgroup per (item, channel) row; the row is swept three times (arg-max, energies, output),
+// sweeps two and three hit L2 / Infinity Cache.
+__global__ __launch_bounds__(RT) void alter_drr_kernel(const float* __restrict__ x, int64_t B, int C, int64_t T, int t0,
+                                                       const float* __restrict__ drr /* (B) */,
+                                                       float* __restrict__ out) {
+  __shared__ MaxIdx shm[RT / 64];
+  __shared__ float shf[RT / 64];
+  for (int64_t row = blockIdx.x; row < B * C; row += gridDim.x) {
+    const int64_t b = row / C;
+    const float* __restrict__ xr = x + row * T;
+    const float* __restrict__ x0 = x + b * C * T;  // channel 0 of the item: its early span is the window
+    // sweep 1: signed arg-max of this row (and of channel 0)
+    MaxIdx m{-INFINITY, 0}, m0{-INFINITY, 0};
+    for (int64_t i = threadIdx.x; i < T; i += RT) {
+      const float v = xr[i];
+      if (v > m.v) { m.v = v; m.i = i; }
+    }
+    m = block_argmax(m, shm);
+    if (xr != x0) {
+      for (int64_t i = threadIdx.x; i < T; i += RT) {
+        const float v = x0[i];
+        if (v > m0.v) { m0.v = v; m0.i = i; }
+      }
+      m0 = block_argmax(m0, shm);
+    } else {
+      m0 = m;
+    }
+    const int64_t e_lo = m.i - t0, e_hi = m.i + t0;      // early span of this row
+    const int64_t w_lo = m0.i - t0, w_hi = m0.i + t0;    // window (all-ones Hann of length 1, see fx.py)
+    // sweep 2: energies and peaks
+    float a_sum = 0.f, c_sum = 0.f, late_sq = 0.f, mx_late = 0.f, mx_ew = 0.f, mx_enw = 0.f;
+    for (int64_t i = threadIdx.x; i < T; i += RT) {
+      const float v = xr[i];
+      const bool early = i >= e_lo && i <= e_hi;
+      const bool win = i >= w_lo && i <= w_hi;
+      if (early) {
+        if (win) { a_sum = fmaf(v, v, a_sum); mx_ew = fmaxf(mx_ew, fabsf(v)); }
+        else { c_sum = fmaf(v, v, c_sum); mx_enw = fmaxf(mx_enw, fabsf(v)); }
+      } else {
+        late_sq = fmaf(v, v, late_sq);
+        mx_late = fmaxf(mx_late, fabsf(v));
+      }
+    }
+    a_sum = block_sum(a_sum, shf);
+    c_sum = block_sum(c_sum, shf);
+    late_sq = block_sum(late_sq, shf);
+    mx_late = block_max(mx_late, shf);
+    mx_ew = block_max(mx_ew, shf);
+    mx_enw = block_max(mx_enw, shf);
+    // alpha: larger root of a al^2 + b al + c = 0 with b = 0 (the window is 0/1), floored by
+    // max|late| / max|early|  (effects.py:601-607, 636-640).  NaNs propagate like torch.maximum.
+    const float cc = c_sum - powf(10.f, drr[b] / 10.f) * late_sq;
+    const float disc = sqrtf(0.f * 0.f - 4.f * a_sum * cc);
+    const float r1 = (-0.f - disc) / (2.f * a_sum), r2 = (-0.f + disc) / (2.f * a_sum);
+    float alpha = (r1 != r1 || r2 != r2) ? NAN : fmaxf(r1, r2);
+    const float min_alpha = mx_late / fmaxf(mx_ew, mx_enw);
+    alpha = (alpha != alpha || min_alpha != min_alpha) ? NAN : fmaxf(alpha, min_alpha);
+    // ensure_max_of_audio(1.0): peak of the result, analytically (multiplication is monotonic)
+    const float peak = fmaxf(fmaxf(fabsf(alpha * mx_ew), mx_enw), mx_late);
+    const float gain = (alpha == alpha && peak > 1.0f) ? 1.0f / peak : 1.0f;  // NaN peak: no rescale
+    // sweep 3
+    float* __restrict__ orow = out + row * T;
+    for (int64_t i = threadIdx.x; i < T; i += RT) {
+      const float v = xr[i];
+      const bool early = i >= e_lo && i <= e_hi;
+      const bool win = i >= w_lo && i <= w_hi;
+      // literal alpha*w*early + (1-w)*early + late: a non-finite alpha poisons the row as in torch
+      const float e = early ? v : 0.f, l = early ? 0.f : v, w = win ? 1.f : 0.f;
+      const float y = alpha * w * e + (1.f - w) * e + l;
+      orow[i] = y * gain;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// x (rows, T) -> vmax[rows] = max_n |x[r, n]|, imax[rows] = first n attaining it (imax may be NULL)
+int at_absmax_f32(const float* x, int64_t rows, int64_t T, float* vmax, int64_t* imax, void* stream) {
+  if (!x || !vmax || rows < 0 || T <= 0) return AT_ERR_INVALID;
+  if (rows == 0) return AT_OK;
+  const int64_t blocks = rows < 65536 ? rows : 65536;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(RT), 0, reinterpret_cast<hipStream_t>(stream), x, rows,
+                     T, vmax, imax);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+// x (rows, L) -> out (rows, T): the row zero-padded / truncated to T, then rotated left by
+// shift[r] (NULL = no rotation):  out[r, n] = xz[r, (n + shift[r]) mod T]
+int at_roll_pad_f32(const float* x, int64_t rows, int64_t L, const int64_t* shift, int64_t T, float* out, void* stream) {
+  if (!x || !out || rows < 0 || L <= 0 || T <= 0 || rows > 65535LL * 1024) return AT_ERR_INVALID;
+  if (rows == 0) return AT_OK;
+  if (rows > 65535) return AT_ERR_UNSUPPORTED;
+  int64_t bx = (T + 256 * 8 - 1) / (256 * 8);
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(roll_pad_kernel, dim3((unsigned)bx, (unsigned)rows), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, rows, L, shift, T, out);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+// x (B, C, T) impulse responses, drr (B) target direct-to-reverberant ratios in dB, t0 = early
+// half-span in samples (int(sample_rate * 0.0025)).  out (B, C, T) = alter_drr(x) followed by
+// ensure_max_of_audio(1.0).  out may alias x.
+int at_alter_drr_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, const float* drr, float* out,
+                     void* stream) {
+  if (!x || !drr || !out || B < 0 || C <= 0 || T <= 0 || t0 < 0) return AT_ERR_INVALID;
+  if (B == 0) return AT_OK;
+  if (C > 1 && x == out) return AT_ERR_INVALID;  // channel 0 is re-read by the other channels
+  const int64_t rows = B * C;
+  const int64_t blocks = rows < 65536 ? rows : 65536;
+  hipLaunchKernelGGL(alter_drr_kernel, dim3((unsigned)blocks), dim3(RT), 0, reinterpret_cast<hipStream_t>(stream), x, B,
+                     (int)C, T, t0, drr, out);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+}  // extern "C"

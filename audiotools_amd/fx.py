@@ -33,6 +33,13 @@ def _roll_to_peak(ir: torch.Tensor) -> torch.Tensor:
     return torch.gather(ir, -1, src)
 
 
+def _peak(x: torch.Tensor) -> torch.Tensor:
+    """max |x| over time, keepdim -- one fused pass on the HIP path."""
+    if kernels.is_native(x) and kernels.have("at_absmax_f32"):
+        return kernels.absmax(x)[..., None]
+    return x.abs().max(dim=-1, keepdim=True).values
+
+
 def fftconv_torch(x: torch.Tensor, ir: torch.Tensor) -> torch.Tensor:
     """Circular convolution at length T via rFFT (effects.py:102-111)."""
     T = x.shape[-1]
@@ -51,15 +58,19 @@ def band_split_torch(audio: torch.Tensor, sample_rate: int, n_bands: int) -> tor
     return torch.stack(bands)
 
 
-def equalizer_taps(sample_rate: int, weights: torch.Tensor):
-    """Composite per-item FIR (B, L) equivalent to sum_k weights[:, k] * band_k."""
+def equalizer_taps(sample_rate: int, weights: torch.Tensor, device=None):
+    """Composite per-item FIR (B, L) equivalent to sum_k weights[:, k] * band_k, designed on
+    ``device`` (default: where ``weights`` lives) without a host round trip."""
     n_bands = weights.shape[-1]
+    device = torch.device(device) if device is not None else weights.device
     bank, half = tables.band_split_bank(int(sample_rate), int(n_bands))
     if bank is None:
-        return weights[:, :1].clone(), 0
-    w = weights.float().cpu()
+        return weights[:, :1].to(device, torch.float32).clone(), 0
+    bank = tables.device_table(("band_split_bank", int(sample_rate), int(n_bands)), device, lambda: (bank.numpy(),))[0]
+    w = weights.to(device, torch.float32)
     diff = w[:, :-1] - w[:, 1:]            # (B, n_bands-1)
-    taps = diff @ bank                     # (B, L)
+    # exact float32 products and sums in band order (no TF32 / split-K reordering surprises)
+    taps = (diff[:, :, None] * bank[None]).sum(1)   # (B, L)
     taps[:, half] += w[:, -1]
     return taps, half
 
@@ -91,13 +102,21 @@ class EffectMixin:
         else:
             other.truncate_samples(self.signal_length)
         ir = other.audio_data
-        if start_at_max:
-            ir = _roll_to_peak(ir)
-        scale = 1 / ir.abs().max(dim=-1, keepdim=True)[0].clamp(1e-5)
         x = self.audio_data
         if kernels.is_native(x) and kernels.is_native(ir) and kernels.have("at_fftconv_circ_f32"):
+            # one pass for the peak value + position, one for the rotation (instead of abs, argmax,
+            # arange, mod, gather, abs, max over (B, C, T) tensors)
+            peak, idx = kernels.absmax(ir, want_index=True)
+            if start_at_max:
+                if ir.shape[1] != 1:
+                    raise RuntimeError("start_at_max requires a single-channel impulse response")
+                ir = kernels.roll_pad(ir, idx, ir.shape[-1])
+            scale = 1 / peak[..., None].clamp(1e-5)
             y = kernels.fftconv(x, ir, scale)
         else:
+            if start_at_max:
+                ir = _roll_to_peak(ir)
+            scale = 1 / ir.abs().max(dim=-1, keepdim=True)[0].clamp(1e-5)
             y = fftconv_torch(x, ir) * scale
         self.audio_data = y
         return self
@@ -112,7 +131,7 @@ class EffectMixin:
             ir = ir.equalizer(ir_eq)
         if drr is not None:
             ir = ir.alter_drr(drr)
-        max_spk = self.audio_data.abs().max(dim=-1, keepdims=True).values
+        max_spk = _peak(self.audio_data)
         # The reference evaluates ``self.phase`` here unconditionally (effects.py:165): a full
         # STFT + angle whose result is unused unless ``use_original_phase``, leaving a STALE
         # ``stft_data`` behind.  Deliberate deviation (DESIGN.md "Deviations"): the phase is only
@@ -123,14 +142,14 @@ class EffectMixin:
             self.stft()
             self.stft_data = self.magnitude * torch.exp(1j * phase)
             self.istft()
-        max_transformed = self.audio_data.abs().max(dim=-1, keepdims=True).values
+        max_transformed = _peak(self.audio_data)
         scale_factor = max_spk.clamp(1e-8) / max_transformed.clamp(1e-8)
         self = self * scale_factor
         return self
 
     # --------------------------------------------------------------- levels
     def ensure_max_of_audio(self, max: float = 1.0):
-        peak = self.audio_data.abs().max(dim=-1, keepdims=True)[0]
+        peak = _peak(self.audio_data)
         gain = torch.where(peak > max, max / peak, torch.ones_like(peak))
         self.audio_data = self.audio_data * gain
         return self
@@ -185,8 +204,8 @@ class EffectMixin:
         weights = (10 ** db).float()
         audio = self.audio_data
         if kernels.is_native(audio) and kernels.have("at_fir_per_item_f32"):
-            taps, half = equalizer_taps(self.sample_rate, weights.expand(self.batch_size, n_bands))
-            self.audio_data = kernels.fir_per_item(audio, taps.to(audio.device), replicate=True)
+            taps, half = equalizer_taps(self.sample_rate, weights.expand(self.batch_size, n_bands), audio.device)
+            self.audio_data = kernels.fir_per_item(audio, taps, replicate=True)
         else:
             fbank = self.mel_filterbank(n_bands)
             self.audio_data = (fbank * weights.to(self.device)[:, None, None, :]).sum(-1)
@@ -260,6 +279,11 @@ class ImpulseResponseMixin:
 
     def alter_drr(self, drr: typing.Union[torch.Tensor, np.ndarray, float]):
         drr = util.ensure_tensor(drr, 2, self.batch_size).to(self.device)
+        x = self.audio_data
+        if kernels.is_native(x) and kernels.have("at_alter_drr_f32") and drr.shape[-1] == 1:
+            # decompose + solve_alpha + recombination + ensure_max_of_audio in one kernel
+            self.audio_data = kernels.alter_drr(x, int(self.sample_rate * 0.0025), drr[:, 0])
+            return self
         early, late, window = self.decompose_ir()
         alpha = self.solve_alpha(early, late, window, drr)
         min_alpha = late.abs().max(dim=-1)[0] / early.abs().max(dim=-1)[0]

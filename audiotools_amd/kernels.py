@@ -227,19 +227,63 @@ def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False
     return out
 
 
+def absmax(x: torch.Tensor, want_index: bool = False):
+    """Per-row peak of a (..., T) HIP tensor in one pass: max |x| over the last axis (and the
+    first index attaining it) -- x.abs().max(-1) / x.abs().argmax(-1) of effects.py:100,118,160."""
+    _require_native_ok(x)
+    x = x.contiguous()
+    T = x.shape[-1]
+    rows = x.numel() // T
+    vmax = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    imax = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device) if want_index else None
+    code = _native.lib().at_absmax_f32(_native.ptr(x), rows, T, _native.ptr(vmax), _native.ptr(imax),
+                                       _native.current_stream(x.device))
+    _native.check(code, "at_absmax_f32")
+    return (vmax, imax) if want_index else vmax
+
+
+def roll_pad(x: torch.Tensor, shift: torch.Tensor, T: int) -> torch.Tensor:
+    """(B, C, L) -> (B, C, T): rows zero-padded / truncated to T and rotated left by ``shift`` (B, C)."""
+    _require_native_ok(x)
+    x = x.contiguous()
+    B, C, L = x.shape
+    out = torch.empty((B, C, T), dtype=torch.float32, device=x.device)
+    sh = None if shift is None else shift.to(torch.int64).contiguous()
+    code = _native.lib().at_roll_pad_f32(_native.ptr(x), B * C, L, _native.ptr(sh), T, _native.ptr(out),
+                                         _native.current_stream(x.device))
+    _native.check(code, "at_roll_pad_f32")
+    return out
+
+
+def alter_drr(x: torch.Tensor, t0: int, drr: torch.Tensor) -> torch.Tensor:
+    """alter_drr + ensure_max_of_audio of a batch of impulse responses (B, C, T); ``drr`` (B,)."""
+    _require_native_ok(x)
+    x = x.contiguous()
+    B, C, T = x.shape
+    d = drr.reshape(-1).to(x.device, torch.float32).contiguous()
+    assert d.numel() == B
+    out = torch.empty_like(x)
+    code = _native.lib().at_alter_drr_f32(_native.ptr(x), B, C, T, int(t0), _native.ptr(d), _native.ptr(out),
+                                          _native.current_stream(x.device))
+    _native.check(code, "at_alter_drr_f32")
+    return out
+
+
 def sinc_taps_batched(cutoffs: torch.Tensor, zeros: float):
     """Vectorised design of the per-item windowed-sinc low-pass taps of ``low_pass`` /
     ``high_pass`` (dsp.py:177-179 -> julius.LowPassFilter): every item has its own length
     2*half_i+1, ``half_i = int(zeros / c_i / 2)`` in float32 exactly as upstream; the rows are
     centred in a common (B, 2*Hmax+1) array.  Runs on ``cutoffs.device``."""
     c = cutoffs.reshape(-1).to(torch.float32)
-    if bool((c < 0).any()):
-        raise ValueError("Minimum cutoff must be larger than zero.")
-    if bool((c > 0.5).any()):
-        raise ValueError("A cutoff above 0.5 does not make sense.")
     pos = c > 0
     half = torch.where(pos, (zeros / torch.where(pos, c, torch.ones_like(c)) / 2).to(torch.int64), torch.zeros_like(c, dtype=torch.int64))
-    H = int(half.max())
+    # one host round trip for the two range checks and the common length
+    cmin, cmax, hmax = torch.stack([c.min().double(), c.max().double(), half.max().double()]).tolist()
+    if cmin < 0:
+        raise ValueError("Minimum cutoff must be larger than zero.")
+    if cmax > 0.5:
+        raise ValueError("A cutoff above 0.5 does not make sense.")
+    H = int(hmax)
     n = torch.arange(-H, H + 1, device=c.device)
     nf = n.to(torch.float32)[None, :]
     hf = half.to(torch.float32)[:, None]

@@ -130,6 +130,21 @@ int at_fir_per_item_f32(const float* x, int64_t B, int64_t C, int64_t T, const f
 int at_fir_fft_f32(const float* x, int64_t B, int64_t C, int64_t T, const float* taps, int taps_rows, int L_padded,
                    int half, int highpass, const float* twiddles2048, float* out, void* stream);
 
+/* ---- row peaks and impulse-response preparation -----------------------------------------------
+ * Replaces whole-tensor torch chains of the reference by single passes:
+ *   at_absmax_f32     audiotools/core/effects.py:100 (ir.abs().argmax), :118 (max|ir| clamp),
+ *                     :160,175 (peak before / after apply_ir), :213-216 (ensure_max_of_audio)
+ *                     vmax[r] = max_n |x[r,n]|, imax[r] = first n attaining it (imax may be NULL)
+ *   at_roll_pad_f32   effects.py:85-100: `other` zero-padded / truncated to T and rotated so that
+ *                     its |peak| sits at sample 0:  out[r,n] = xz[r, (n + shift[r]) mod T]
+ *   at_alter_drr_f32  effects.py:540-647 decompose_ir + solve_alpha + alter_drr followed by
+ *                     ensure_max_of_audio(1.0); x (B,C,T), drr (B) in dB, t0 = int(sr * 0.0025)
+ */
+int at_absmax_f32(const float* x, int64_t rows, int64_t T, float* vmax, int64_t* imax, void* stream);
+int at_roll_pad_f32(const float* x, int64_t rows, int64_t L, const int64_t* shift, int64_t T, float* out, void* stream);
+int at_alter_drr_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, const float* drr, float* out,
+                     void* stream);
+
 /* ---- polyphase resampling ---------------------------------------------------------------
  * Replaces  audiotools/core/audio_signal.py:732  julius.resample_frac(x, old, new) (zeros 24,
  *           rolloff 0.945): replicate pad (width, width+old), conv1d with the (new, 2*width+old)

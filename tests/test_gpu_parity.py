@@ -301,6 +301,40 @@ def test_apply_ir_and_normalize():
     assert float((n.loudness().cpu() + 30.0).abs().max()) < 0.1
 
 
+def test_ir_tools_vs_torch_path():
+    """at_absmax_f32 / at_roll_pad_f32 / at_alter_drr_f32 against the torch formulation of the same
+    methods on CPU (which tests/test_transforms.py pins to the unmodified reference)."""
+    from audiotools_amd import kernels, fx
+    g = torch.Generator().manual_seed(77)
+    for C, T in ((1, 9601), (2, 4099)):
+        ir = torch.randn(4, C, T, generator=g) * torch.exp(-torch.arange(T) / (0.2 * T))
+        ir[1, 0, 500] = ir[1].abs().max() * 1.5       # a clear direct path
+        ir[2, 0, 100] = 3.0
+        ir[2, 0, 200] = -3.0                            # |peak| tie: the first index wins
+        v, i = kernels.absmax(ir.cuda(), want_index=True)
+        assert torch.equal(v.cpu(), ir.abs().max(-1).values)
+        assert torch.equal(i.cpu(), ir.abs().argmax(-1))
+        if C == 1:
+            rolled = kernels.roll_pad(ir.cuda(), i, T + 777)
+            ref = fx._roll_to_peak(torch.nn.functional.pad(ir, (0, 777)))
+            assert torch.equal(rolled.cpu(), ref)
+            assert torch.equal(kernels.roll_pad(ir.cuda(), None, T - 100).cpu(), ir[..., : T - 100])
+        drr = torch.tensor([0.0, 10.0, 20.0, 30.0])
+        ref = A.AudioSignal(ir.clone(), 48000).alter_drr(drr).audio_data
+        got = A.AudioSignal(ir.clone(), 48000).to("cuda").alter_drr(drr).audio_data.cpu()
+        # (channels whose early span misses the channel-0 window can have no real root: NaN rows,
+        #  in the reference too)
+        assert torch.equal(torch.isnan(got), torch.isnan(ref))
+        assert rel_err(torch.nan_to_num(got), torch.nan_to_num(ref)) < 1e-5
+    # whole apply_ir chain (ir EQ, DRR change, rotation, FFT convolution, peak restore) vs the CPU path
+    x = synth.audio_batch(3, 1, 24000, seed=5, gaps=False, sample_rate=16000)
+    ir = torch.randn(3, 1, 8000, generator=g) * torch.exp(-torch.arange(8000) / 1500.0)
+    eq = -torch.rand(3, 6, generator=g)
+    mk = lambda dev: A.AudioSignal(x.clone(), 16000).to(dev).apply_ir(
+        A.AudioSignal(ir.clone(), 16000).to(dev), drr=torch.tensor([5.0, 10.0, 15.0]), ir_eq=eq.clone()).audio_data
+    assert rel_err(mk("cuda"), mk("cpu")) < REL
+
+
 # ----------------------------------------------------------------------------- istft
 @pytest.mark.parametrize("win,hop,wt,ms", [(2048, 512, "hann", False), (2048, 512, "sqrt_hann", True),
                                            (512, 128, "sqrt_hann", False), (512, 128, "hann", True),

@@ -19,12 +19,21 @@ dev = "cuda"
 
 def timed(fn, label, n=3):
     fn(); torch.cuda.synchronize()
+    st0 = torch.cuda.memory_stats()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for _ in range(n):
         fn()
+    e1.record()
+    host_ms = (time.perf_counter() - t0) / n * 1e3
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
-    print(f"{label:34s} {ms:9.2f} ms", flush=True)
+    st1 = torch.cuda.memory_stats()
+    dalloc = st1.get("num_device_alloc", 0) - st0.get("num_device_alloc", 0)
+    dfree = st1.get("num_device_free", 0) - st0.get("num_device_free", 0)
+    print(f"{label:34s} {ms:9.2f} ms   (host enqueue {host_ms:7.2f} ms; gpu span {e0.elapsed_time(e1) / n:8.2f} ms; hipMalloc {dalloc}, hipFree {dfree}, "
+          f"reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB)", flush=True)
     return ms
 
 
