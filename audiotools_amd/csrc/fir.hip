@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void fir_per_item_kernel(const float* __restri
     const int nj = min(FIR_CHUNK, Lp - j0);  // multiple of 8
     __syncthreads();
     // stage x[n0 + j0 - half + m], m in [0, FIR_TILE + nj + 8), replicate padding at both ends
+#pragma unroll 4
     for (int m = t; m < FIR_TILE + nj + 16; m += 256) {
       int64_t g = n0 + j0 - half + m;
       g = g < 0 ? 0 : (g >= T ? T - 1 : g);
@@ -91,9 +92,13 @@ __global__ __launch_bounds__(256) void fir_per_item_kernel(const float* __restri
 // i.  Phases are grouped by 4; a group stores its taps densely over the union window (LG taps,
 // zero filled) as float4 = 4 phases per tap.  A thread owns one group x RS_FB consecutive frames:
 // 16 FMAs per 4 LDS reads of x + one float4 of weights (L2 resident, ~100 KB per ratio).
+// The bank is tap-major (LG, NG): the lanes of a wave hold adjacent groups, so a weight load is a
+// few contiguous cache lines per wave instruction (group-major made every lane touch its own
+// line: 64 lines per instruction, the texture-address unit was the bottleneck).  The workgroup
+// size is the work-item count of a tile rounded up to whole waves (one round, no idle tail).
 struct ResampleArgs {
   const float* x;        // (rows, T)
-  const float4* wg;      // (NG, LG): 4 phases per tap
+  const float4* wg;      // (LG, NG): 4 phases per tap, tap-major
   const int* base;       // (NG): first dense tap index of the group
   float* out;            // (rows, out_len)
   int64_t T, out_len, rows;
@@ -103,9 +108,13 @@ struct ResampleArgs {
   int xs_len;
 };
 
-constexpr int RS_FB = 4;  // frames per thread
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };  // dword-aligned quad
 
-__global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs A) {
+constexpr int RS_FB = 4;  // frames per thread
+constexpr int RS_TB = 4;  // taps per pipelined block (LG is padded to a multiple)
+
+__global__ __launch_bounds__(1024) void resample_kernel(const ResampleArgs A) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const int FT = A.frames_per_tile;
   const int64_t row = blockIdx.x / A.tiles_per_row;
@@ -113,38 +122,58 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs A) {
   const float* __restrict__ xr = A.x + row * A.T;
   const int64_t f0 = (int64_t)tile * FT;
   const int t = threadIdx.x;
-  // padded input: xp[m] = x[clamp(m - width)], frame f reads xp[f*old + k]
-  for (int m = t; m < A.xs_len; m += 256) {
-    int64_t g = f0 * A.old_sr + m - A.width;
-    g = g < 0 ? 0 : (g >= A.T ? A.T - 1 : g);
-    xs[m] = xr[g];
+  // padded input: xp[m] = x[clamp(m - width)], frame f reads xp[f*old + k].
+  // Interior tiles: unaligned 16-byte loads, several in flight per thread (a one-load-per-
+  // iteration loop exposes the full HBM latency ~40 times per tile and was 80 % of the kernel).
+  {
+    const int64_t g_lo = f0 * A.old_sr - A.width;
+    const int n4 = (A.xs_len + 3) / 4;  // the LDS allocation is rounded up to whole float4
+    if (g_lo >= 0 && g_lo + 4 * (int64_t)n4 <= A.T) {
+      const f4u* __restrict__ src = reinterpret_cast<const f4u*>(xr + g_lo);
+      float4* __restrict__ dst = reinterpret_cast<float4*>(xs);
+#pragma unroll 4
+      for (int i = t; i < n4; i += blockDim.x) {
+        const f4u v = src[i];
+        dst[i] = make_float4(v.x, v.y, v.z, v.w);
+      }
+    } else {
+#pragma unroll 4
+      for (int m = t; m < A.xs_len; m += blockDim.x) {
+        int64_t g = g_lo + m;
+        g = g < 0 ? 0 : (g >= A.T ? A.T - 1 : g);
+        xs[m] = xr[g];
+      }
+    }
   }
   __syncthreads();
   const int fgroups = FT / RS_FB;
   float* __restrict__ orow = A.out + row * A.out_len;
-  for (int item = t; item < A.NG * fgroups; item += 256) {
+  for (int item = t; item < A.NG * fgroups; item += blockDim.x) {
     const int G = item % A.NG;
     const int fg = item / A.NG;
-    float acc[4][RS_FB];
+    // acc[r] = 4 phases of frame r as one 4-vector: the FMA below becomes two v_pk_fma_f32 whose
+    // A operand is the weight register pair as loaded and whose B operand is x broadcast by
+    // op_sel -- no register shuffling (pairing across frames costs a v_mov per FMA pair).
+    v4f acc[RS_FB];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int r = 0; r < RS_FB; ++r) acc[p][r] = 0.f;
+    for (int r = 0; r < RS_FB; ++r) acc[r] = (v4f)(0.f);
     const float* xb = xs + (fg * RS_FB) * A.old_sr + A.base[G];
-    const float4* __restrict__ w = A.wg + (int64_t)G * A.LG;
-#pragma unroll 4
-    for (int m = 0; m < A.LG; ++m) {
-      const float4 wv = w[m];
-      float xv[RS_FB];
+    const v4f* __restrict__ w = reinterpret_cast<const v4f*>(A.wg) + G;
+    // LG is a multiple of RS_TB (host pads with zero weights)
+#pragma unroll 1
+    for (int m0 = 0; m0 < A.LG; m0 += RS_TB) {
+      v4f wv[RS_TB];
+      float xv[RS_TB][RS_FB];
 #pragma unroll
-      for (int r = 0; r < RS_FB; ++r) xv[r] = xb[r * A.old_sr + m];
+      for (int u = 0; u < RS_TB; ++u) {
+        wv[u] = w[(int64_t)(m0 + u) * A.NG];
 #pragma unroll
-      for (int r = 0; r < RS_FB; ++r) {
-        acc[0][r] = fmaf(wv.x, xv[r], acc[0][r]);
-        acc[1][r] = fmaf(wv.y, xv[r], acc[1][r]);
-        acc[2][r] = fmaf(wv.z, xv[r], acc[2][r]);
-        acc[3][r] = fmaf(wv.w, xv[r], acc[3][r]);
+        for (int r = 0; r < RS_FB; ++r) xv[u][r] = xb[r * A.old_sr + m0 + u];
       }
+#pragma unroll
+      for (int u = 0; u < RS_TB; ++u)
+#pragma unroll
+        for (int r = 0; r < RS_FB; ++r) acc[r] = __builtin_elementwise_fma(wv[u], (v4f)(xv[u][r]), acc[r]);
     }
 #pragma unroll
     for (int r = 0; r < RS_FB; ++r) {
@@ -153,7 +182,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs A) {
       for (int p = 0; p < 4; ++p) {
         const int i = 4 * G + p;
         const int64_t o = f * A.new_sr + i;
-        if (i < A.new_sr && o < A.out_len) orow[o] = acc[p][r];
+        if (i < A.new_sr && o < A.out_len) orow[o] = acc[r][p];
       }
     }
   }
@@ -182,11 +211,11 @@ int at_fir_per_item_f32(const float* x, int64_t B, int64_t C, int64_t T, const f
 }
 
 // x (rows,T) -> out (rows,out_len), out_len = floor(new_sr*T/old_sr) for the REDUCED ratio.
-// wg (NG, LG, 4) f32, base (NG) i32: the bank grouped 4 phases per tap (tables.resample_grouped_bank).
+// wg (LG, NG, 4) f32 tap-major, base (NG) i32: the bank grouped 4 phases per tap (tables.resample_grouped_bank).
 int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* wg, const int* base, int old_sr, int new_sr,
                     int width, int NG, int LG, float* out, int64_t out_len, void* stream) {
   if (!x || !wg || !base || !out || rows < 0 || T <= 0 || old_sr <= 0 || new_sr <= 0 || width <= 0 || NG <= 0 ||
-      LG <= 0 || out_len < 0 || 4 * NG < new_sr)
+      LG <= 0 || (LG % RS_TB) != 0 || out_len < 0 || 4 * NG < new_sr)
     return AT_ERR_INVALID;
   if (rows == 0 || out_len == 0) return AT_OK;
   ResampleArgs A;
@@ -201,7 +230,7 @@ int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* wg, co
   A.tiles_per_row = (int)((frames + FT - 1) / FT);
   // last frame of the tile reads up to (FT-1)*old + max(base)+LG-1 <= (FT-1)*old + 2*width + old
   A.xs_len = FT * old_sr + 2 * width + LG;
-  const size_t lds = (size_t)A.xs_len * 4;
+  const size_t lds = (size_t)((A.xs_len + 3) / 4 * 4) * 4;
   if (lds > 160 * 1024) return AT_ERR_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
@@ -212,7 +241,9 @@ int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* wg, co
   }
   const int64_t blocks = rows * A.tiles_per_row;
   if (blocks > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), A);
+  int threads = (NG * (FT / RS_FB) + 63) / 64 * 64;   // one round of work items, whole waves
+  if (threads > 1024) threads = 1024;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(threads), lds, reinterpret_cast<hipStream_t>(stream), A);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }

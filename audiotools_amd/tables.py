@@ -335,7 +335,9 @@ def resample_sparse_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: flo
 def resample_grouped_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
     """Bank layout of ``at_resample_f32``: output phases grouped by 4; group G stores, for every
     tap of the union of its phases' support windows, one float4 (4 phases), zero filled.
-    Returns ``(wg float32 (NG, LG, 4), base int32 (NG,), old, new, width, NG, LG)`` or None."""
+    Tap-major: adjacent groups are adjacent in memory, so the lanes of a wave (adjacent groups)
+    read one contiguous run per tap.
+    Returns ``(wg float32 (LG, NG, 4), base int32 (NG,), old, new, width, NG, LG)`` or None."""
     sp = resample_sparse_bank(old_sr, new_sr, zeros, rolloff)
     if sp is None:
         return None
@@ -351,7 +353,7 @@ def resample_grouped_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: fl
         hi = int(max(k0[i] + Wd for i in ph))
         base[G] = lo
         spans.append(hi - lo)
-    LG = int(max(spans))
+    LG = (int(max(spans)) + 3) // 4 * 4   # the kernel consumes taps in blocks of 4 (zero padded)
     base = np.minimum(base, K - LG).astype(np.int32)
     wg = np.zeros((NG, LG, 4), dtype=np.float32)
     thr = 1e-12 * np.abs(dense).max()
@@ -362,4 +364,4 @@ def resample_grouped_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: fl
                 seg = dense[i, base[G]: base[G] + LG].copy()
                 seg[np.abs(seg) <= thr] = 0.0
                 wg[G, :, p] = seg
-    return wg, base, old, new, width, NG, LG
+    return np.ascontiguousarray(wg.transpose(1, 0, 2)), base, old, new, width, NG, LG

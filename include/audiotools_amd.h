@@ -149,9 +149,9 @@ int at_alter_drr_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, co
  * Replaces  audiotools/core/audio_signal.py:732  julius.resample_frac(x, old, new) (zeros 24,
  *           rolloff 0.945): replicate pad (width, width+old), conv1d with the (new, 2*width+old)
  *           bank at stride old, interleave phases, cut to floor(new*T/old).
- *   wg (NG, LG, 4) f32, base (NG) i32: the bank grouped 4 output phases per tap -- phases
+ *   wg (LG, NG, 4) f32 tap-major, base (NG) i32: the bank grouped 4 output phases per tap -- phases
  *          4G..4G+3 use dense taps base[G] .. base[G]+LG-1, zero filled outside each phase's own
- *          support (tables.resample_grouped_bank); old_sr/new_sr are the REDUCED ratio.
+ *          support, LG a multiple of 4 (tables.resample_grouped_bank); old_sr/new_sr are the REDUCED ratio.
  */
 int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* wg, const int* base, int old_sr, int new_sr,
                     int width, int NG, int LG, float* out, int64_t out_len, void* stream);

@@ -16,6 +16,7 @@ for f in files:
         k = r["Kernel_Name"][:60]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
-    if "stft" in k or "kweight" in k or "lufs" in k:
+    import os, re
+    if re.search(os.environ.get("PMC_FILTER", "stft|kweight|lufs"), k):
         print(k, {c: round(sum(v) / len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
 PY
