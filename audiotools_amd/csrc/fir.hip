@@ -178,11 +178,14 @@ __global__ __launch_bounds__(1024) void resample_kernel(const ResampleArgs A) {
 #pragma unroll
     for (int r = 0; r < RS_FB; ++r) {
       const int64_t f = f0 + fg * RS_FB + r;
+      const int64_t o = f * A.new_sr + 4 * G;      // the thread's 4 phases are 4 consecutive outputs
+      if (4 * G + 3 < A.new_sr && o + 3 < A.out_len) {
+        f4u v; v.x = acc[r].x; v.y = acc[r].y; v.z = acc[r].z; v.w = acc[r].w;
+        *reinterpret_cast<f4u*>(orow + o) = v;
+      } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int i = 4 * G + p;
-        const int64_t o = f * A.new_sr + i;
-        if (i < A.new_sr && o < A.out_len) orow[o] = acc[r][p];
+        for (int p = 0; p < 4; ++p)
+          if (4 * G + p < A.new_sr && o + p < A.out_len) orow[o + p] = acc[r][p];
       }
     }
   }
