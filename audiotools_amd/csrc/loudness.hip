@@ -510,12 +510,31 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
   // segmentation in units of S samples ("hops") even on the general path
   const int64_t H_data = (T + S - 1) / S;
   A.H_data = (int)H_data;
-  // aim for >= 8192 waves, but keep segments >= 4x the warm-up unless the batch is tiny
-  int64_t want_waves = 8192;
-  { const char* e = getenv("AT_LUFS_WAVES"); if (e && atoi(e) > 0) want_waves = atoi(e); }
-  int64_t seg = (rows * H_data + want_waves - 1) / want_waves;
-  const int64_t min_seg = (4 * (int64_t)warm + S - 1) / S;
-  if (seg < min_seg && rows * ((H_data + min_seg - 1) / min_seg) >= 1024) seg = min_seg;
+  // Segments per row: minimise  rounds x (segment + warm-up)  where a round is one wave on every
+  // resident slot (12 per CU at 3 waves/SIMD).  Wave quantisation matters: 3200 waves on 3072
+  // slots run two rounds for the work of 1.04 (B=64 took 2x its share of the B=512 time).
+  int64_t seg;
+  {
+    static const int n_cu = [] {
+      int dev = 0, cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess) return 256;
+      if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return 256;
+      return cu;
+    }();
+    const int64_t slots = (int64_t)n_cu * 4 * AT_LUFS_WPS;
+    int64_t best_s = 1;
+    double best_cost = 1e300;
+    for (int64_t sp = 1; sp <= H_data && sp <= 4096; ++sp) {
+      const int64_t sh = (H_data + sp - 1) / sp;                  // hops per segment
+      if ((H_data + sh - 1) / sh != sp) continue;                 // not a distinct segmentation
+      const int64_t rounds = (rows * sp + slots - 1) / slots;
+      const double cost = (double)rounds * ((double)sh * S + (sp > 1 ? (double)warm : 0.0));
+      if (cost < best_cost * 0.999) { best_cost = cost; best_s = sp; }
+    }
+    seg = (H_data + best_s - 1) / best_s;
+    const char* e = getenv("AT_LUFS_WAVES");  // development override: target wave count
+    if (e && atoi(e) > 0) seg = (rows * H_data + atoi(e) - 1) / atoi(e);
+  }
   if (seg < 1) seg = 1;
   if (seg > H_data) seg = H_data;
   A.seg_hops = (int)seg;

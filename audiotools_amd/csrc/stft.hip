@@ -69,6 +69,7 @@ struct StftArgs {
   int n_units;             // padded to a multiple of 64
   int n_mels;
   int reuse_shift;         // hop / (2 L) when consecutive frames of a wave can reuse registers, else 0
+  int run;                 // consecutive frame groups a wave handles before jumping ahead (<= AT_STFT_RUN)
   int debug;               // development: 1 = compute but never store, 2 = store only (no FFT)
 };
 
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
   const int nblk_x = ((int)gridDim.x - xcd + n_x - 1) / n_x;       // blocks on this XCD
   const int64_t g_lo = A.total_groups * xcd / n_x;
   const int64_t g_hi = A.total_groups * (xcd + 1) / n_x;
-  constexpr int RUN = AT_STFT_RUN;
+  const int RUN = A.run;
   const int64_t Wtot = (int64_t)nblk_x * NW;                        // waves working on this span
   const int64_t w0 = g_lo + ((int64_t)lblk * NW + wave) * RUN;      // first group of this wave
 
@@ -464,7 +465,22 @@ int launch_one(const StftArgs& A, size_t lds_bytes, int max_blocks, hipStream_t 
   }
   int64_t blocks = (A.total_groups + NW - 1) / NW;
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, stream, A);
+  // Run length: every wave of an XCD span should get the same number of whole runs.  With a fixed
+  // run of 16 a small batch (54 frame groups per wave at B=64) leaves some waves with 4 runs and
+  // others with 3 -- the launch then lasts 64/54 of its balanced time.
+  StftArgs B = A;
+  {
+    const int64_t n_x = blocks < 8 ? blocks : 8;
+    const int64_t waves_x = (blocks / n_x) * NW;                       // waves per XCD span
+    const int64_t span = (A.total_groups + n_x - 1) / n_x;
+    const int64_t per_wave = (span + waves_x - 1) / (waves_x > 0 ? waves_x : 1);
+    const int64_t runs = (per_wave + AT_STFT_RUN - 1) / AT_STFT_RUN;
+    int64_t run = (per_wave + runs - 1) / (runs > 0 ? runs : 1);
+    if (run < 1) run = 1;
+    if (run > AT_STFT_RUN) run = AT_STFT_RUN;
+    B.run = (int)run;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, stream, B);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }

@@ -53,6 +53,19 @@ def resample_torch(audio: torch.Tensor, old_sr: int, new_sr: int) -> torch.Tenso
     return y[..., :out_len]
 
 
+def _per_item_native(X, *params) -> bool:
+    """The in-place stft_data kernels apply: native spectrum and every parameter is a scalar or
+    has one value per item (shape (), (1,), (B,), (B,1,1,1))."""
+    if not (kernels.spec_native(X) and kernels.have("at_spec_mask_f32")):
+        return False
+    B = X.shape[0]
+    for p in params:
+        t = util.ensure_tensor(p)
+        if t.numel() not in (1, B) or (t.numel() == B and t.ndim >= 1 and t.shape[0] != B):
+            return False
+    return True
+
+
 class DSPMixin:
     _original_batch_size = None
     _original_num_channels = None
@@ -142,6 +155,14 @@ class DSPMixin:
     # ----------------------------------------------------------- STFT masks
     def mask_frequencies(self, fmin_hz, fmax_hz, val: float = 0.0):
         """Set magnitude AND phase to ``val`` for fmin <= f < fmax (dsp.py:217-261)."""
+        if self.stft_data is None:
+            self.stft()
+        if _per_item_native(self.stft_data, fmin_hz, fmax_hz):
+            lo, hi = util.ensure_tensor(fmin_hz, ndim=1), util.ensure_tensor(fmax_hz, ndim=1)
+            assert torch.all(lo < hi)
+            grid = torch.linspace(0, self.sample_rate / 2, self.stft_data.shape[-2], device=self.device)
+            self.stft_data = kernels.spec_mask(self.stft_data, 0, lo, hi, grid, val)
+            return self
         mag, phase = self.magnitude, self.phase
         fmin_hz = util.ensure_tensor(fmin_hz, ndim=mag.ndim)
         fmax_hz = util.ensure_tensor(fmax_hz, ndim=mag.ndim)
@@ -157,6 +178,14 @@ class DSPMixin:
 
     def mask_timesteps(self, tmin_s, tmax_s, val: float = 0.0):
         """Set magnitude AND phase to ``val`` for tmin <= t < tmax (dsp.py:263-306)."""
+        if self.stft_data is None:
+            self.stft()
+        if _per_item_native(self.stft_data, tmin_s, tmax_s):
+            lo, hi = util.ensure_tensor(tmin_s, ndim=1), util.ensure_tensor(tmax_s, ndim=1)
+            assert torch.all(lo < hi)
+            grid = torch.linspace(0, self.signal_duration, self.stft_data.shape[-1], device=self.device)
+            self.stft_data = kernels.spec_mask(self.stft_data, 1, lo, hi, grid, val)
+            return self
         mag, phase = self.magnitude, self.phase
         tmin_s = util.ensure_tensor(tmin_s, ndim=mag.ndim)
         tmax_s = util.ensure_tensor(tmax_s, ndim=mag.ndim)
@@ -172,6 +201,11 @@ class DSPMixin:
 
     def mask_low_magnitudes(self, db_cutoff, val: float = 0.0):
         """Mask bins whose log-magnitude is below ``db_cutoff`` (dsp.py:308-334)."""
+        if self.stft_data is None:
+            self.stft()
+        if _per_item_native(self.stft_data, db_cutoff):
+            self.stft_data = kernels.spec_mask_lowmag(self.stft_data, util.ensure_tensor(db_cutoff, ndim=1), val)
+            return self
         mag = self.magnitude
         log_mag = self.log_magnitude()
         db_cutoff = util.ensure_tensor(db_cutoff, ndim=mag.ndim).to(self.device)
@@ -179,6 +213,11 @@ class DSPMixin:
         return self
 
     def shift_phase(self, shift):
+        if self.stft_data is None:
+            self.stft()
+        if _per_item_native(self.stft_data, shift) and util.ensure_tensor(shift).dtype in (torch.float32, torch.int64):
+            self.stft_data = kernels.spec_phase_shift(self.stft_data, util.ensure_tensor(shift, ndim=1))
+            return self
         shift = util.ensure_tensor(shift, ndim=self.phase.ndim).to(self.device)
         self.phase = self.phase + shift
         return self

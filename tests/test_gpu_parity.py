@@ -335,6 +335,47 @@ def test_ir_tools_vs_torch_path():
     assert rel_err(mk("cuda"), mk("cpu")) < REL
 
 
+def test_spectral_edits_vs_torch_path():
+    """at_spec_mask_f32 / at_spec_phase_shift_f32 / at_spec_mask_lowmag_f32 (dsp.py:217-352) against
+    the reference's polar formulation run on CPU by the same methods (pinned to the unmodified
+    reference by tests/test_transforms.py), scalar and per-item parameters."""
+    x = synth.audio_batch(3, 2, 16000 + 3, seed=61, gaps=False, sample_rate=16000)
+
+    def pair():
+        a = A.AudioSignal(x.clone(), 16000, stft_params=A.STFTParams(512, 128)).to("cuda")
+        b = A.AudioSignal(x.clone(), 16000, stft_params=A.STFTParams(512, 128))
+        a.stft(); b.stft()
+        return a, b
+
+    cases = [
+        ("mask_frequencies", dict(fmin_hz=1000.0, fmax_hz=2500.0)),
+        ("mask_frequencies", dict(fmin_hz=torch.tensor([0.0, 500.0, 4000.0]), fmax_hz=torch.tensor([100.0, 7000.0, 8000.0]), val=0.5)),
+        ("mask_timesteps", dict(tmin_s=0.2, tmax_s=0.5)),
+        ("mask_timesteps", dict(tmin_s=torch.tensor([0.0, 0.3, 0.9]), tmax_s=torch.tensor([0.1, 0.6, 1.1]), val=0.25)),
+        ("shift_phase", dict(shift=np.pi)),
+        ("shift_phase", dict(shift=torch.tensor([0.3, -1.2, 2.0]))),
+    ]
+    for name, kw in cases:
+        a, b = pair()
+        before = a.stft_data
+        keep = before.clone()
+        getattr(a, name)(**kw); getattr(b, name)(**kw)
+        assert a.stft_data is not before and torch.equal(before, keep)      # a NEW tensor, like the reference
+        assert rel_err(torch.view_as_real(a.stft_data), torch.view_as_real(b.stft_data)) < 1e-5, name
+        assert rel_err(a.istft().audio_data, b.istft().audio_data) < REL, name
+    # mask_low_magnitudes: the mask is a threshold on a float32 log; allow a vanishing number of
+    # threshold flips from 1-ulp differences in |X| between devices
+    for cut in (-10.0, torch.tensor([-20.0, 0.0, 10.0])):
+        a, b = pair()
+        a.mask_low_magnitudes(cut); b.mask_low_magnitudes(cut)
+        ga, gb = a.stft_data.cpu(), b.stft_data
+        flips = ((ga.abs() == 0) != (gb.abs() == 0)).float().mean()
+        assert float(flips) < 1e-4
+        same = (ga.abs() == 0) == (gb.abs() == 0)
+        assert float((ga - gb)[same].abs().max() / gb.abs().max()) < 1e-5
+        assert 0.01 < float((ga.abs() == 0).float().mean()) < 0.99
+
+
 # ----------------------------------------------------------------------------- istft
 @pytest.mark.parametrize("win,hop,wt,ms", [(2048, 512, "hann", False), (2048, 512, "sqrt_hann", True),
                                            (512, 128, "sqrt_hann", False), (512, 128, "hann", True),
