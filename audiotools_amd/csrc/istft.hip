@@ -187,7 +187,11 @@ __global__ __launch_bounds__(256) void istft_env_kernel(const float* __restrict_
 #define AT_ISTFT_WPS 2
 #endif
 
-template <int M, int SH /* hop = 2 L SH */>
+// ADJ = true turns the kernel into the ADJOINT of the forward transform (backward pass of stft()):
+// x_bar = OLA(window * sum_k Re(G_k e^{+2 pi i k n / N})) -- same data flow, but no 1/N, no factor 2 on
+// the interior bins (i.e. DC and Nyquist count double relative to c2r), no envelope division and no
+// removal of the centre padding (out covers the whole padded signal).
+template <int M, int SH /* hop = 2 L SH */, bool ADJ>
 __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const IstftFusedArgs A) {
   using P = Plan<M>;
   constexpr int L = P::L, FW = P::FW, N = 2 * M, HOP = 2 * L * SH, R = N / HOP;
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = make_float2(0.f, 0.f);
 
-  const float inv_n = 1.0f / (float)N;
+  const float inv_n = ADJ ? 0.5f : 1.0f / (float)N;
   // Every lane loads bin k = t + L q of its frame ONCE (ascending, 512 B per wave instruction);
   // the Hermitian partner X[M-k] of the fold is register 15-q of lane (L - t) mod L and comes
   // over the LDS crossbar (ds_bpermute).  Lane 0 pairs with itself: register 16-q, and the
@@ -267,7 +271,10 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
       const float2 own = q == 0 ? xN : xa[q == 0 ? 0 : 16 - q];
       float2 xm = t == 0 ? own : sv;
       if (!live) { xk = make_float2(0.f, 0.f); xm = xk; }
-      if (k == 0) { xk.y = 0.f; xm.y = 0.f; }  // c2r ignores the imaginary part of DC and Nyquist
+      if (k == 0) {  // c2r ignores the imaginary part of DC and Nyquist
+        xk.y = 0.f; xm.y = 0.f;
+        if (ADJ) { xk.x *= 2.f; xm.x *= 2.f; }
+      }
       const float2 w = s_twf[k];
       const float c = w.x, s = -w.y;
       const float sr = xk.x + xm.x, si = xk.y - xm.y;
@@ -278,7 +285,10 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     // reciprocal envelope of the segment this step finishes (table is L2 resident); loaded here,
     // far ahead of the stores that use it
     float2 env[SH];
-    {
+    if constexpr (ADJ) {
+#pragma unroll
+      for (int q = 0; q < SH; ++q) env[q] = make_float2(1.f, 1.f);
+    } else {
       const int fe = f < 0 ? 0 : (f >= A.n_seg ? A.n_seg - 1 : f);
       const float2* __restrict__ e2 = reinterpret_cast<const float2*>(A.inv_env) + (int64_t)fe * (HOP / 2);
 #pragma unroll
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     // row edges go through the guarded path.
     {
       const bool emit = unit_ok && f >= h0 && f < h1;
-      const int p_seg = f * HOP - N / 2;                       // first output sample of the segment
+      const int p_seg = f * HOP - (ADJ ? 0 : N / 2);           // first output sample of the segment
       const bool inside = emit && p_seg >= 0 && p_seg + HOP <= len;
       if (__all(inside)) {
 #pragma unroll
@@ -351,26 +361,55 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   }
 }
 
-template <int M, int SH>
+template <int M, int SH, bool ADJ>
 int launch_fused(const IstftFusedArgs& A, hipStream_t stream) {
   constexpr int FW = Plan<M>::FW;
   const int64_t waves = (A.total_units + FW - 1) / FW;
   const int64_t blocks = (waves + 3) / 4;
   if (blocks > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((istft_fused_kernel<M, SH>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
+  hipLaunchKernelGGL((istft_fused_kernel<M, SH, ADJ>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }
 
-template <int M>
+template <int M, bool ADJ>
 int launch_fused_sh(int sh, const IstftFusedArgs& A, hipStream_t stream) {
   switch (sh) {
-    case 1: return launch_fused<M, 1>(A, stream);
-    case 2: return launch_fused<M, 2>(A, stream);
-    case 4: return launch_fused<M, 4>(A, stream);
-    case 8: return launch_fused<M, 8>(A, stream);
+    case 1: return launch_fused<M, 1, ADJ>(A, stream);
+    case 2: return launch_fused<M, 2, ADJ>(A, stream);
+    case 4: return launch_fused<M, 4, ADJ>(A, stream);
+    case 8: return launch_fused<M, 8, ADJ>(A, stream);
   }
   return AT_ERR_UNSUPPORTED;
+}
+
+template <bool ADJ>
+int launch_fused_m(int M, int sh, const IstftFusedArgs& F, hipStream_t st) {
+  switch (M) {
+    case 16: return launch_fused_sh<16, ADJ>(sh, F, st);
+    case 32: return launch_fused_sh<32, ADJ>(sh, F, st);
+    case 64: return launch_fused_sh<64, ADJ>(sh, F, st);
+    case 128: return launch_fused_sh<128, ADJ>(sh, F, st);
+    case 256: return launch_fused_sh<256, ADJ>(sh, F, st);
+    case 512: return launch_fused_sh<512, ADJ>(sh, F, st);
+    case 1024: return launch_fused_sh<1024, ADJ>(sh, F, st);
+  }
+  return AT_ERR_UNSUPPORTED;
+}
+
+// run partition shared by the inverse and the adjoint
+void plan_runs(IstftFusedArgs& F, int64_t rows, int n_fft, int hop) {
+  const int R = n_fft / hop;
+  F.n_seg = F.n_frames - 1 + R;
+  // runs: >= ~16k frame-slot units so the chip is filled a few times over, but long enough that
+  // the R-1 warm-up frames of a run stay a small fraction
+  int64_t want = (16384 + rows - 1) / rows;
+  int run = (int)((F.n_seg + want - 1) / want);
+  if (run < 8 * R) run = 8 * R;
+  if (run > F.n_seg) run = F.n_seg;
+  F.run = run;
+  F.runs_per_row = (F.n_seg + run - 1) / run;
+  F.total_units = rows * F.runs_per_row;
 }
 
 // hop = n_fft / {2,4,8,16}  <=>  hop = 2 L SH with SH in {8,4,2,1}
@@ -425,33 +464,14 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
     F.X = reinterpret_cast<const float2*>(X); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
     F.inv_env = reinterpret_cast<const float*>(workspace); F.out = out; F.rows = rows; F.length = length;
     F.n_x = (int)n_x; F.lead = lead; F.n_frames = (int)n_frames;
-    const int R = n_fft / hop;
-    F.n_seg = (int)n_frames - 1 + R;
-    // runs: >= ~16k frame-slot units so the chip is filled a few times over, but long enough that
-    // the R-1 warm-up frames of a run stay a small fraction
-    int64_t want = (16384 + rows - 1) / rows;
-    int run = (int)((F.n_seg + want - 1) / want);
-    if (run < 8 * R) run = 8 * R;
-    if (run > F.n_seg) run = F.n_seg;
-    F.run = run;
-    F.runs_per_row = (F.n_seg + run - 1) / run;
-    F.total_units = rows * F.runs_per_row;
+    plan_runs(F, rows, n_fft, hop);
     const int64_t env_n = (n_frames - 1) * hop + n_fft;
     int64_t eb = (env_n + 255) / 256;
     if (eb > 4096) eb = 4096;
     hipLaunchKernelGGL(istft_env_kernel, dim3((unsigned)eb), dim3(256), 0, st, window, reinterpret_cast<float*>(workspace),
                        (int)n_frames, n_fft, hop, env_n);
     AT_LAUNCH_CHECK();
-    switch (M) {
-      case 16: return launch_fused_sh<16>(sh, F, st);
-      case 32: return launch_fused_sh<32>(sh, F, st);
-      case 64: return launch_fused_sh<64>(sh, F, st);
-      case 128: return launch_fused_sh<128>(sh, F, st);
-      case 256: return launch_fused_sh<256>(sh, F, st);
-      case 512: return launch_fused_sh<512>(sh, F, st);
-      case 1024: return launch_fused_sh<1024>(sh, F, st);
-    }
-    return AT_ERR_UNSUPPORTED;
+    return launch_fused_m<false>(M, sh, F, st);
   }
   // generic hop: frame buffer + gather.  Virtual zero frames are not supported here.
   if (lead != 0 || n_frames != n_x) return AT_ERR_UNSUPPORTED;
@@ -478,6 +498,31 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
                      (int)n_frames, n_fft, hop, length);
   AT_LAUNCH_CHECK();
   return AT_OK;
+}
+
+// Adjoint of the forward STFT (the backward pass of stft() for a real signal):
+//   G (rows, n_frames, n_fft/2+1) complex64 = dL/dX as autograd hands it, bin-contiguous
+//   out (rows, out_len), out_len >= Lp = (n_frames-1)*hop + n_fft:
+//       out[n] = sum_f window[n - f hop] * sum_k Re(G[f,k] e^{+2 pi i k (n - f hop)/n_fft})   for n < Lp
+// (positions >= Lp are not written), i.e. the gradient w.r.t. the CENTRE-PADDED signal; the caller
+// folds the reflected margins back (audio_signal.py:1195 torch.stft(center=True)).
+// hop must be n_fft / {2,4,8,16}.
+int at_stft_adjoint_f32(const float* G, int64_t rows, int64_t n_frames, const float* window, const float* twiddles,
+                        int n_fft, int hop, float* out, int64_t out_len, void* stream) {
+  if (!G || !window || !twiddles || !out || rows < 0 || n_frames <= 0 || hop <= 0 ||
+      out_len < (n_frames - 1) * hop + n_fft || out_len >= (1LL << 31))
+    return AT_ERR_INVALID;
+  if (!(n_fft >= 32 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0)) return AT_ERR_UNSUPPORTED;
+  const int sh = fused_shift(n_fft, hop);
+  if (!sh) return AT_ERR_UNSUPPORTED;
+  if (n_frames >= (1LL << 31) / n_fft) return AT_ERR_UNSUPPORTED;
+  if (rows == 0) return AT_OK;
+  IstftFusedArgs F;
+  F.X = reinterpret_cast<const float2*>(G); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
+  F.inv_env = nullptr; F.out = out; F.rows = rows; F.length = out_len;
+  F.n_x = (int)n_frames; F.lead = 0; F.n_frames = (int)n_frames;
+  plan_runs(F, rows, n_fft, hop);
+  return launch_fused_m<true>(n_fft / 2, sh, F, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -135,6 +135,33 @@ def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, l
     return out
 
 
+def stft_adjoint(grad_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, T: int) -> torch.Tensor:
+    """Backward pass of ``stft_mel(audio (B, C, T), ..., pad=0)``: ``grad_bcfn`` is dL/dX of logical
+    shape (B, C, F, N); returns dL/daudio (B, C, T).  Native OLA of the windowed adjoint DFT over the
+    centre-padded signal, then the two reflected margins are folded back (torch.stft center=True)."""
+    _require_native_ok(grad_bcfn)
+    B, C, F, N = grad_bcfn.shape
+    assert F == n_fft // 2 + 1 and istft_fused_supported(n_fft, hop)
+    G = grad_bcfn.transpose(2, 3).contiguous()   # no copy when the grad has the layout of the forward output
+    dev = G.device
+    half = n_fft // 2
+    Lp = (N - 1) * hop + n_fft
+    full = T + n_fft                      # Lp <= full; the tail no frame covers has zero gradient
+    out = torch.empty((B, C, full), dtype=torch.float32, device=dev)
+    if full > Lp:
+        out[..., Lp:] = 0
+    tw = tables.stft_twiddles(n_fft, dev)
+    code = _native.lib().at_stft_adjoint_f32(_native.ptr(torch.view_as_real(G)), B * C, N, _native.ptr(window),
+                                             _native.ptr(tw), n_fft, hop, _native.ptr(out), full,
+                                             _native.current_stream(dev))
+    _native.check(code, "at_stft_adjoint_f32")
+    g = out[..., half: half + T].clone()
+    # reflect padding: padded position j < half mirrors x[half - j]; position half + T + j mirrors x[T - 2 - j]
+    g[..., 1: half + 1] += out[..., :half].flip(-1)
+    g[..., T - 1 - half: T - 1] += out[..., half + T: half + T + half].flip(-1)
+    return g
+
+
 def lufs_block_params(rate: int, block_size: float):
     """(K, S) exactly as loudness.py:165-170 computes them (Python floats)."""
     overlap = 0.75

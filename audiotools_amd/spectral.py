@@ -28,6 +28,33 @@ padding_type  : str   torch pad mode for the match_stride padding; default "refl
 """
 
 
+class _NativeStft(torch.autograd.Function):
+    """stft() with the HIP kernels in both directions: forward = fused STFT kernel, backward = its
+    adjoint (the fused inverse kernel in adjoint mode).  This is what lets the reference's training
+    losses (metrics/spectral.py: MultiScaleSTFTLoss, MelSpectrogramLoss, PhaseLoss) stay on the
+    native path; everything after the STFT (abs, log, mel matmul) is ordinary differentiable torch."""
+
+    @staticmethod
+    def forward(ctx, audio, window, n_fft, hop):
+        ctx.save_for_backward(window)
+        ctx.cfg = (n_fft, hop, audio.shape[-1])
+        X, _ = kernels.stft_mel(audio.detach(), window, n_fft, hop)
+        return X
+
+    @staticmethod
+    def backward(ctx, grad):
+        (window,) = ctx.saved_tensors
+        n_fft, hop, T = ctx.cfg
+        return kernels.stft_adjoint(grad, window, n_fft, hop, T), None, None, None
+
+
+def _native_autograd_ok(audio: torch.Tensor, n_fft: int, hop: int, match_stride: bool) -> bool:
+    """A HIP float32 tensor that needs gradients can use the native forward + adjoint pair."""
+    return (audio.is_cuda and audio.dtype == torch.float32 and audio.requires_grad and torch.is_grad_enabled()
+            and not match_stride and kernels.stft_native_supported(n_fft) and kernels.istft_fused_supported(n_fft, hop)
+            and audio.shape[-1] > n_fft // 2 and kernels.have("at_stft_adjoint_f32"))
+
+
 class SpectralMixin:
     # ---------------------------------------------------------------- params
     @staticmethod
@@ -89,6 +116,8 @@ class SpectralMixin:
         if kernels.is_native(audio) and kernels.stft_native_supported(n_fft):
             X, _ = kernels.stft_mel(audio, window, n_fft, hop, pad=pad, right_pad=right_pad,
                                     padding_type=padding_type, match_stride=match_stride)
+        elif _native_autograd_ok(audio, n_fft, hop, match_stride):
+            X = _NativeStft.apply(audio, window, n_fft, hop)
         else:
             X = self._torch_stft(n_fft, hop, window, match_stride, padding_type, right_pad, pad)
         self.stft_data = X

@@ -89,6 +89,20 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
                  int hop, int lead, int64_t n_frames, int64_t length, float* out, void* workspace,
                  int64_t workspace_bytes, void* stream);
 
+/* ---- adjoint of the forward STFT (backward pass of stft()) --------------------------------
+ * What torch.autograd computes for  audiotools/core/audio_signal.py:1195  torch.stft(center=True)
+ * (used by the reference's training losses, audiotools/metrics/spectral.py).
+ *   G    (rows, n_frames, n_fft/2+1) complex64 = dL/dX as autograd hands it, bin-contiguous
+ *   out  (rows, out_len) f32, out_len >= Lp = (n_frames-1)*hop + n_fft: gradient w.r.t. the
+ *        CENTRE-PADDED signal (positions >= Lp are not written)
+ *        out[n] = sum_f window[n - f hop] * sum_k Re(G[f,k] e^{+2 pi i k (n - f hop) / n_fft});
+ *        the caller folds the two reflected margins of n_fft/2 samples back onto the signal.
+ * Same fused kernel as at_istft_f32 (no 1/N, DC/Nyquist weighting of the adjoint, no envelope).
+ * hop must be n_fft / {2,4,8,16} (AT_ERR_UNSUPPORTED otherwise).
+ */
+int at_stft_adjoint_f32(const float* G, int64_t rows, int64_t n_frames, const float* window, const float* twiddles,
+                        int n_fft, int hop, float* out, int64_t out_len, void* stream);
+
 /* ---- BS.1770 integrated loudness ---------------------------------------------------
  * Replaces  audiotools/core/loudness.py:102-126  (2x torchaudio.functional.lfilter, the
  *           CPU/IIR branch), :164-174 (julius.core.unfold), :176-247 (gated integration).

@@ -376,6 +376,34 @@ def test_spectral_edits_vs_torch_path():
         assert 0.01 < float((ga.abs() == 0).float().mean()) < 0.99
 
 
+@pytest.mark.parametrize("win,hop,T", [(2048, 512, 22050 + 7), (512, 128, 16000), (1024, 512, 12001), (256, 16, 5000), (64, 8, 1000)])
+def test_stft_autograd_native_adjoint(win, hop, T):
+    """Gradients through the native stft() (forward kernel + at_stft_adjoint_f32) equal those of
+    torch.stft on CPU -- the path of metrics/spectral.py's losses (MultiScaleSTFTLoss,
+    MelSpectrogramLoss) and tests/core/test_grad.py."""
+    x = synth.audio_batch(2, 2, T, seed=win + T, gaps=False)
+    g = torch.Generator().manual_seed(3)
+
+    def loss_and_grad(dev):
+        xa = x.clone().to(dev).requires_grad_(True)
+        s = A.AudioSignal(xa, 44100)
+        X = s.stft(win, hop, "hann")
+        wts = torch.randn(X.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+        # magnitude, log-magnitude and raw complex terms, as the spectral losses use them
+        loss = (X.abs() * wts).sum() + (X.abs().clamp(1e-5).log10() * wts).mean() + (X.real * wts + X.imag * wts.flip(-1)).sum()
+        mel = s.mel_spectrogram(20, window_length=win, hop_length=hop, window_type="hann")
+        loss = loss + mel.clamp(1e-5).log10().mean()
+        (gx,) = torch.autograd.grad(loss, xa)
+        return float(loss), gx
+
+    l_ref, g_ref = loss_and_grad("cpu")
+    l_got, g_got = loss_and_grad("cuda")
+    assert abs(l_got - l_ref) <= 1e-4 * abs(l_ref)
+    assert rel_err(g_got, g_ref) < REL
+    with open("/proc/self/maps") as f:
+        assert "libaudiotools_amd.so" in f.read()
+
+
 # ----------------------------------------------------------------------------- istft
 @pytest.mark.parametrize("win,hop,wt,ms", [(2048, 512, "hann", False), (2048, 512, "sqrt_hann", True),
                                            (512, 128, "sqrt_hann", False), (512, 128, "hann", True),

@@ -1,0 +1,30 @@
+#!/usr/bin/env python
+"""Forward + backward of a magnitude loss through stft(): native kernels vs torch.stft autograd on the GPU."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import audiotools_amd as A
+from audiotools_amd import spectral
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+x = (0.1 * torch.randn(B, 2, 441000, device="cuda")).clamp_(-1, 1)
+
+def run(native):
+    saved = spectral._native_autograd_ok
+    if not native:
+        spectral._native_autograd_ok = lambda *a: False
+    try:
+        def fn():
+            xa = x.clone().requires_grad_(True)
+            X = A.AudioSignal(xa, 44100).stft()
+            X.abs().sum().backward()
+            return xa.grad
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3): g = fn()
+        torch.cuda.synchronize()
+        print(f"stft fwd + |X|.sum() bwd, B={B} ({'native' if native else 'torch.stft'}): {(time.perf_counter() - t0) / 3 * 1e3:8.2f} ms", flush=True)
+        return g
+    finally:
+        spectral._native_autograd_ok = saved
+
+g1 = run(True); g2 = run(False)
+print("grad rel diff", float((g1 - g2).abs().max() / g2.abs().max()))
