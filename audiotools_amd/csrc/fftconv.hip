@@ -116,6 +116,7 @@ int64_t at_fftconv_workspace_bytes(int64_t B, int64_t C, int64_t Cir, int64_t T)
 // NOTE: rocFFT's real inverse overwrites its input, so the product spectrum lives in `workspace`.
 int at_fftconv_circ_f32(const float* x, const float* ir, const float* scale, int64_t B, int64_t C, int64_t Cir,
                         int64_t T, float* out, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!x || !ir || !out || B < 0 || C <= 0 || T <= 0 || (Cir != 1 && Cir != C)) return AT_ERR_INVALID;
   if (B == 0) return AT_OK;
   if (!workspace || workspace_bytes < at_fftconv_workspace_bytes(B, C, Cir, T)) return AT_ERR_INVALID;

@@ -200,6 +200,7 @@ extern "C" {
 // out = FIR(x) or, with highpass != 0, x - FIR(x).
 int at_fir_per_item_f32(const float* x, int64_t B, int64_t C, int64_t T, const float* taps, int taps_rows,
                         int L_padded, int half, int highpass, float* out, void* stream) {
+  if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!x || !taps || !out || B < 0 || C <= 0 || T <= 0 || L_padded <= 0 || (L_padded % 8) != 0 || half < 0 ||
       half >= L_padded || (taps_rows != 1 && taps_rows != B))
     return AT_ERR_INVALID;
@@ -217,6 +218,7 @@ int at_fir_per_item_f32(const float* x, int64_t B, int64_t C, int64_t T, const f
 // wg (LG, NG, 4) f32 tap-major, base (NG) i32: the bank grouped 4 phases per tap (tables.resample_grouped_bank).
 int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* wg, const int* base, int old_sr, int new_sr,
                     int width, int NG, int LG, float* out, int64_t out_len, void* stream) {
+  if (rows == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!x || !wg || !base || !out || rows < 0 || T <= 0 || old_sr <= 0 || new_sr <= 0 || width <= 0 || NG <= 0 ||
       LG <= 0 || (LG % RS_TB) != 0 || out_len < 0 || 4 * NG < new_sr)
     return AT_ERR_INVALID;

@@ -256,6 +256,7 @@ extern "C" {
 // partitions of 1024 taps, one launch each.  x and out must not alias.
 int at_fir_fft_f32(const float* x, int64_t B, int64_t C, int64_t T, const float* taps, int taps_rows, int L_padded,
                    int half, int highpass, const float* twiddles2048, float* out, void* stream) {
+  if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!x || !taps || !out || !twiddles2048 || x == out || B < 0 || C <= 0 || T <= 0 || T >= (1LL << 30) || L_padded <= 0 || half < 0 ||
       half >= L_padded || (taps_rows != 1 && taps_rows != B))
     return AT_ERR_INVALID;

@@ -187,6 +187,7 @@ extern "C" {
 
 // x (rows, T) -> vmax[rows] = max_n |x[r, n]|, imax[rows] = first n attaining it (imax may be NULL)
 int at_absmax_f32(const float* x, int64_t rows, int64_t T, float* vmax, int64_t* imax, void* stream) {
+  if (rows == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!x || !vmax || rows < 0 || T <= 0) return AT_ERR_INVALID;
   if (rows == 0) return AT_OK;
   const int64_t blocks = rows < 65536 ? rows : 65536;
@@ -199,6 +200,7 @@ int at_absmax_f32(const float* x, int64_t rows, int64_t T, float* vmax, int64_t*
 // x (rows, L) -> out (rows, T): the row zero-padded / truncated to T, then rotated left by
 // shift[r] (NULL = no rotation):  out[r, n] = xz[r, (n + shift[r]) mod T]
 int at_roll_pad_f32(const float* x, int64_t rows, int64_t L, const int64_t* shift, int64_t T, float* out, void* stream) {
+  if (rows == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!x || !out || rows < 0 || L <= 0 || T <= 0 || rows > 65535LL * 1024) return AT_ERR_INVALID;
   if (rows == 0) return AT_OK;
   if (rows > 65535) return AT_ERR_UNSUPPORTED;
@@ -215,6 +217,7 @@ int at_roll_pad_f32(const float* x, int64_t rows, int64_t L, const int64_t* shif
 // ensure_max_of_audio(1.0).  out may alias x.
 int at_alter_drr_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, const float* drr, float* out,
                      void* stream) {
+  if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!x || !drr || !out || B < 0 || C <= 0 || T <= 0 || t0 < 0) return AT_ERR_INVALID;
   if (B == 0) return AT_OK;
   if (C > 1 && x == out) return AT_ERR_INVALID;  // channel 0 is re-read by the other channels

@@ -448,6 +448,7 @@ int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft, int 
 int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft,
                  int hop, int lead, int64_t n_frames, int64_t length, float* out, void* workspace,
                  int64_t workspace_bytes, void* stream) {
+  if (rows == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!X || !window || !twiddles || !out || rows < 0 || n_x <= 0 || hop <= 0 || length < 0 || lead < 0 ||
       n_frames < lead + n_x)
     return AT_ERR_INVALID;
@@ -509,6 +510,7 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
 // hop must be n_fft / {2,4,8,16}.
 int at_stft_adjoint_f32(const float* G, int64_t rows, int64_t n_frames, const float* window, const float* twiddles,
                         int n_fft, int hop, float* out, int64_t out_len, void* stream) {
+  if (rows == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!G || !window || !twiddles || !out || rows < 0 || n_frames <= 0 || hop <= 0 ||
       out_len < (n_frames - 1) * hop + n_fft || out_len >= (1LL << 31))
     return AT_ERR_INVALID;

@@ -454,6 +454,7 @@ int64_t at_lufs_workspace_bytes(int64_t B, int64_t C, int64_t T, int K, int S) {
 int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* sos, const double* gains, int nstage,
                 int K, int S, double inv_norm, float floor_db, int warm, float* out, void* workspace,
                 int64_t workspace_bytes, void* stream) {
+  if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!x || !sos || !gains || !out || B < 0 || C <= 0 || C > 5 || T <= 0 || nstage <= 0 || nstage > MAX_STAGE ||
       K <= 0 || S <= 0 || warm < 0)
     return AT_ERR_INVALID;

@@ -98,6 +98,7 @@ extern "C" {
 // (grid = linspace(0, duration, N)).  Masked elements become fill = (re, im) = val * e^{i val}.
 int at_spec_mask_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, int axis, const double* lo, const double* hi,
                      const float* grid, float fill_re, float fill_im, void* stream) {
+  if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!X || !lo || !hi || !grid || B < 0 || C <= 0 || N <= 0 || F <= 0 || (axis != 0 && axis != 1) || N >= (1LL << 31) ||
       F >= (1LL << 31))
     return AT_ERR_INVALID;
@@ -114,6 +115,7 @@ int at_spec_mask_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, int a
 
 // X *= e^{i shift[b]}  (shift_phase with one value per item)
 int at_spec_phase_shift_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, const float* shift, void* stream) {
+  if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!X || !shift || B < 0 || C <= 0 || N <= 0 || F <= 0) return AT_ERR_INVALID;
   if (B == 0) return AT_OK;
   const int64_t rows = B * C, per_row = N * F;
@@ -146,6 +148,7 @@ int at_spec_maxpow_f32(const float* X, int64_t n, float* out, void* stream) {
 // maxpow: device float from at_spec_maxpow_f32 of the same tensor.
 int at_spec_mask_lowmag_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, const double* cutoff_db,
                             const float* maxpow, float top_db, int use_top_db, float val, void* stream) {
+  if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!X || !cutoff_db || !maxpow || B < 0 || C <= 0 || N <= 0 || F <= 0) return AT_ERR_INVALID;
   if (B == 0) return AT_OK;
   const int64_t rows = B * C, per_row = N * F;

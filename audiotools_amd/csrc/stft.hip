@@ -600,6 +600,7 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
                     int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,
                     float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,
                     float* mel_out, void* stream) {
+  if (rows == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!x || !window || !twiddles || rows < 0 || T <= 0 || hop <= 0 || pad < 0 || right_pad < 0 ||
       frame_lo < 0 || n_frames_out < 0)
     return AT_ERR_INVALID;

@@ -404,6 +404,50 @@ def test_stft_autograd_native_adjoint(win, hop, T):
         assert "libaudiotools_amd.so" in f.read()
 
 
+def test_c_abi_error_codes_and_degenerate_inputs():
+    """The C ABI never throws: 0 = ok, -1 = bad argument, -2 = no kernel for the request; empty
+    batches are no-ops; the Python layer turns codes into NativeError / the reference's errors."""
+    import ctypes
+    from audiotools_amd import _native, kernels, tables
+    lib = _native.lib()
+    dev = torch.device("cuda")
+    st = _native.current_stream(dev)
+    x = torch.zeros(2, 1, 4096, device=dev)
+    win = tables.window("hann", 512, dev)
+    tw = tables.stft_twiddles(512, dev)
+    out = torch.empty(2, 1, 33, 257, dtype=torch.complex64, device=dev)
+    p = _native.ptr
+    args = lambda **k: [k.get("x", p(x)), k.get("rows", 2), k.get("T", 4096), p(win), p(tw), k.get("n_fft", 512),
+                        k.get("hop", 128), 0, 0, 0, 0, k.get("n_out", 33), k.get("out", p(out)), None, None, 0, 0, None, st]
+    assert lib.at_stft_mel_f32(*args()) == 0
+    assert lib.at_stft_mel_f32(*args(rows=0)) == 0                      # empty batch
+    assert lib.at_stft_mel_f32(*args(x=None)) == -1
+    assert lib.at_stft_mel_f32(*args(out=None)) == -1                   # stft_data is always produced
+    assert lib.at_stft_mel_f32(*args(hop=0)) == -1
+    assert lib.at_stft_mel_f32(*args(n_out=34)) == -1                   # more frames than the signal has
+    assert lib.at_stft_mel_f32(*args(T=200)) == -1                      # reflect padding needs n_fft/2 < T
+    assert lib.at_stft_mel_f32(*args(n_fft=500)) == -2                  # not a power of two: no kernel
+    assert lib.at_stft_mel_f32(*args(n_fft=4096)) == -2
+    assert lib.at_lufs_f32(None, 1, 1, 100, None, None, 2, 4, 1, 1.0, -70.0, 0, None, None, 0, st) == -1
+    assert lib.at_fir_fft_f32(p(x), 2, 1, 4096, p(win), 1, 512, 255, 0, None, p(x), st) == -1      # x aliases out / no twiddles
+    assert lib.at_istft_workspace_bytes(2, 0, 512, 128) == -1
+    assert lib.at_resample_f32(p(x), 2, 4096, p(win), None, 3, 2, 10, 1, 4, p(x), 10, st) == -1
+    assert lib.at_fftconv_circ_f32(p(x), p(x), None, 2, 1, 3, 4096, p(x), None, 0, st) == -1     # Cir must be 1 or C
+    torch.cuda.synchronize()
+    # Python layer
+    with pytest.raises(_native.NativeError):
+        _native.check(-2, "at_stft_mel_f32")
+    with pytest.raises(_native.NativeError):
+        kernels.stft_mel(torch.zeros(1, 1, 4096), win.cpu(), 512, 128)   # CPU tensor handed to a native launcher
+    e = A.AudioSignal(torch.zeros(0, 1, 4096), 16000).to("cuda")          # empty batch through the object API
+    assert e.stft(512, 128).shape == (0, 1, 257, 33)
+    one = A.AudioSignal(torch.randn(1, 1, 300), 16000, stft_params=A.STFTParams(512, 128)).to("cuda")
+    assert one.stft().shape == (1, 1, 257, 3)                              # shortest legal signal class (T > n_fft/2)
+    assert one.loudness().shape == (1,)                                    # < 0.5 s is zero-padded, not an error
+    with pytest.raises(AssertionError):
+        A.AudioSignal(torch.randn(1, 1, 4096), 16000).to("cuda").stft(512, 100, match_stride=True)
+
+
 # ----------------------------------------------------------------------------- istft
 @pytest.mark.parametrize("win,hop,wt,ms", [(2048, 512, "hann", False), (2048, 512, "sqrt_hann", True),
                                            (512, 128, "sqrt_hann", False), (512, 128, "hann", True),
