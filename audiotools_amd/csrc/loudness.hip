@@ -164,12 +164,22 @@ __device__ __forceinline__ void biquad_stage(float (&v)[CHUNK], const LufsArgs& 
   ky1 = lane63(f1);
   ky2 = lane63(f2);               // carried in the (y1, y1 - y2) basis
   // (c) true recursion from the entering state
+  if (s.g == 1.0f) {  // wave-uniform; every BS.1770 weighting stage has unit pass-band gain (loudness.py:259)
 #pragma unroll
-  for (int i = 0; i < CHUNK; ++i) {
-    const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
-    v[i] = s.g * y;
-    y2 = y1;
-    y1 = y;
+    for (int i = 0; i < CHUNK; ++i) {
+      const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
+      v[i] = y;
+      y2 = y1;
+      y1 = y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < CHUNK; ++i) {
+      const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
+      v[i] = s.g * y;
+      y2 = y1;
+      y1 = y;
+    }
   }
 }
 
