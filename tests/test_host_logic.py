@@ -128,3 +128,55 @@ def test_container_semantics():
     t[m] = t[m] * 0.0
     assert t.audio_data[0].abs().max() == 0 and t.audio_data[1].abs().max() > 0
     assert (A.AudioSignal(x.clone(), 16000) * 2 - A.AudioSignal(x.clone(), 16000)) == A.AudioSignal(x.clone(), 16000)
+
+
+def test_tap_designs_on_host():
+    """The batched tap designs that feed at_fir_fft_f32 / at_fir_per_item_f32 (run here on CPU
+    tensors; the same code runs on the device) against the julius restatement of the oracle."""
+    from audiotools_amd import fx, kernels
+    from oracle.leaves import julius_leaf
+    x = synth.audio_batch(3, 1, 6000, seed=71, gaps=False)
+    # per-item windowed-sinc low-pass (dsp.py:177-179): common centred grid, per-item lengths
+    cut = torch.tensor([4000.0, 900.0, 16000.0]) / 44100
+    taps = kernels.sinc_taps_batched(cut, 51)
+    L = taps.shape[-1]
+    xp = torch.nn.functional.pad(x, ((L - 1) // 2, (L - 1) // 2), mode="replicate")
+    got = torch.stack([torch.nn.functional.conv1d(xp[b][None], taps[b][None, None])[0] for b in range(3)])
+    ref = torch.stack([julius_leaf.LowPassFilter(float(c), zeros=51)(x[b][None])[0] for b, c in enumerate(cut)])
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+    with pytest.raises(ValueError):
+        kernels.sinc_taps_batched(torch.tensor([0.6]), 51)
+    with pytest.raises(ValueError):
+        kernels.sinc_taps_batched(torch.tensor([-0.1]), 51)
+    # equalizer collapsed to ONE composite FIR per item (effects.py:399-433)
+    w = 10 ** (-torch.rand(3, 6, generator=torch.Generator().manual_seed(4)))
+    ctaps, half = fx.equalizer_taps(44100, w)
+    xp = torch.nn.functional.pad(x, (half, half), mode="replicate")
+    got = torch.stack([torch.nn.functional.conv1d(xp[b][None], ctaps[b][None, None])[0] for b in range(3)])
+    bands = fx.band_split_torch(x, 44100, 6)                 # (6, B, C, T), sums to x
+    ref = (bands * w.T[:, :, None, None]).sum(0)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
+    assert kernels.istft_fused_supported(2048, 512) and kernels.istft_fused_supported(512, 32)
+    assert not kernels.istft_fused_supported(512, 100) and not kernels.istft_fused_supported(512, 512)
+
+
+def test_native_dispatch_rules_on_cpu():
+    """CPU tensors never reach the C ABI: the object API runs the torch formulation, the launchers
+    refuse (NativeError), and the spectral-edit / autograd dispatch predicates are False."""
+    from audiotools_amd import _native, filters, kernels, spectral
+    x = synth.audio_batch(2, 1, 4096, seed=72, gaps=False)
+    s = A.AudioSignal(x.clone(), 16000, stft_params=A.STFTParams(512, 128))
+    X = s.stft()
+    assert not kernels.is_native(x) and not kernels.spec_native(X)
+    assert not filters._per_item_native(X, 100.0, 200.0)
+    assert not spectral._native_autograd_ok(x.clone().requires_grad_(True), 512, 128, False)
+    for fn in (lambda: kernels.stft_mel(x, torch.hann_window(512), 512, 128), lambda: kernels.absmax(x),
+               lambda: kernels.fir_per_item(x, torch.ones(1, 9)), lambda: kernels.integrated_loudness(x, 16000)):
+        with pytest.raises(_native.NativeError):
+            fn()
+    # masks / phase shift on CPU = the reference's polar formulation; new tensor each time
+    before = s.stft_data
+    s.mask_frequencies(1000.0, 2000.0)
+    assert s.stft_data is not before
+    y = s.istft().audio_data
+    assert y.shape == x.shape and torch.isfinite(y).all()
