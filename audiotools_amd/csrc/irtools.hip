@@ -12,6 +12,8 @@ namespace {
 
 constexpr int RT = 512;  // threads per row workgroup
 
+struct __attribute__((packed, aligned(4))) q4u { float x, y, z, w; };  // dword-aligned quad
+
 struct MaxIdx {
   float v;
   int64_t i;
@@ -70,16 +72,30 @@ __global__ __launch_bounds__(RT) void absmax_kernel(const float* __restrict__ x,
     MaxIdx m{-1.0f, 0};
     const bool vec = ((reinterpret_cast<uintptr_t>(xr) & 15) == 0);
     const int64_t T4 = vec ? T / 4 : 0;
-    for (int64_t i = threadIdx.x; i < T4; i += RT) {
+    // 4 independent 16-B loads in flight per thread (a load-then-wait loop is latency bound)
+    int64_t i = threadIdx.x;
+    for (; i + 3 * RT < T4; i += 4 * RT) {
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const float4*>(xr)[i + k * RT];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a[4] = {fabsf(v[k].x), fabsf(v[k].y), fabsf(v[k].z), fabsf(v[k].w)};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (a[u] > m.v) { m.v = a[u]; m.i = 4 * (i + k * RT) + u; }
+      }
+    }
+    for (; i < T4; i += RT) {
       const float4 v = reinterpret_cast<const float4*>(xr)[i];
       const float a[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (a[u] > m.v) { m.v = a[u]; m.i = 4 * i + u; }
     }
-    for (int64_t i = 4 * T4 + threadIdx.x; i < T; i += RT) {
-      const float a = fabsf(xr[i]);
-      if (a > m.v) { m.v = a; m.i = i; }
+    for (int64_t j = 4 * T4 + threadIdx.x; j < T; j += RT) {
+      const float a = fabsf(xr[j]);
+      if (a > m.v) { m.v = a; m.i = j; }
     }
     m = block_argmax(m, sh);
     if (threadIdx.x == 0) {
@@ -99,10 +115,35 @@ __global__ __launch_bounds__(256) void roll_pad_kernel(const float* __restrict__
   int64_t s = shift ? shift[row] % T : 0;
   if (s < 0) s += T;
   const int64_t Lc = L < T ? L : T;
-  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < T; n += (int64_t)gridDim.x * blockDim.x) {
-    int64_t src = n + s;
-    if (src >= T) src -= T;
-    orow[n] = src < Lc ? xr[src] : 0.f;
+  const bool vec = (T % 4) == 0 && ((reinterpret_cast<uintptr_t>(orow) & 15) == 0);
+  if (vec) {
+    // 4 consecutive outputs per thread: one dword-aligned 16-B load when the 4 sources are inside
+    // the row (no wrap, no zero tail), element-wise otherwise; aligned 16-B stores
+    for (int64_t n = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); n < T; n += 4 * (int64_t)gridDim.x * blockDim.x) {
+      int64_t src = n + s;
+      if (src >= T) src -= T;
+      float4 o;
+      if (src + 3 < Lc) {
+        const q4u v = *reinterpret_cast<const q4u*>(xr + src);
+        o = make_float4(v.x, v.y, v.z, v.w);
+      } else {
+        float e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int64_t su = src + u;
+          if (su >= T) su -= T;
+          e[u] = su < Lc ? xr[su] : 0.f;
+        }
+        o = make_float4(e[0], e[1], e[2], e[3]);
+      }
+      *reinterpret_cast<float4*>(orow + n) = o;
+    }
+  } else {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < T; n += (int64_t)gridDim.x * blockDim.x) {
+      int64_t src = n + s;
+      if (src >= T) src -= T;
+      orow[n] = src < Lc ? xr[src] : 0.f;
+    }
   }
 }
 
@@ -118,37 +159,71 @@ __global__ __launch_bounds__(RT) void alter_drr_kernel(const float* __restrict__
     const int64_t b = row / C;
     const float* __restrict__ xr = x + row * T;
     const float* __restrict__ x0 = x + b * C * T;  // channel 0 of the item: its early span is the window
-    // sweep 1: signed arg-max of this row (and of channel 0)
-    MaxIdx m{-INFINITY, 0}, m0{-INFINITY, 0};
-    for (int64_t i = threadIdx.x; i < T; i += RT) {
-      const float v = xr[i];
-      if (v > m.v) { m.v = v; m.i = i; }
-    }
-    m = block_argmax(m, shm);
-    if (xr != x0) {
-      for (int64_t i = threadIdx.x; i < T; i += RT) {
-        const float v = x0[i];
-        if (v > m0.v) { m0.v = v; m0.i = i; }
+    // sweep 1: signed arg-max of this row (and of channel 0).  Rows are read 16 B per lane with
+    // two loads in flight when the row is 16-B aligned (T % 4 == 0), element-wise otherwise.
+    const bool vec = (T % 4) == 0 && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+    auto row_argmax = [&](const float* __restrict__ p) {
+      MaxIdx mm{-INFINITY, 0};
+      if (vec) {
+        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+        const int64_t T4 = T / 4;
+        int64_t i = threadIdx.x;
+        for (; i + RT < T4; i += 2 * RT) {
+          const float4 a = p4[i], b = p4[i + RT];
+          const float ea[4] = {a.x, a.y, a.z, a.w}, eb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (ea[u] > mm.v) { mm.v = ea[u]; mm.i = 4 * i + u; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (eb[u] > mm.v) { mm.v = eb[u]; mm.i = 4 * (i + RT) + u; }
+        }
+        for (; i < T4; i += RT) {
+          const float4 a = p4[i];
+          const float ea[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (ea[u] > mm.v) { mm.v = ea[u]; mm.i = 4 * i + u; }
+        }
+      } else {
+        for (int64_t i = threadIdx.x; i < T; i += RT) {
+          const float v = p[i];
+          if (v > mm.v) { mm.v = v; mm.i = i; }
+        }
       }
-      m0 = block_argmax(m0, shm);
-    } else {
-      m0 = m;
-    }
+      return block_argmax(mm, shm);
+    };
+    MaxIdx m = row_argmax(xr);
+    MaxIdx m0 = (xr != x0) ? row_argmax(x0) : m;
     const int64_t e_lo = m.i - t0, e_hi = m.i + t0;      // early span of this row
     const int64_t w_lo = m0.i - t0, w_hi = m0.i + t0;    // window (all-ones Hann of length 1, see fx.py)
     // sweep 2: energies and peaks
     float a_sum = 0.f, c_sum = 0.f, late_sq = 0.f, mx_late = 0.f, mx_ew = 0.f, mx_enw = 0.f;
-    for (int64_t i = threadIdx.x; i < T; i += RT) {
-      const float v = xr[i];
+    auto acc_one = [&](float v, int64_t i) {
       const bool early = i >= e_lo && i <= e_hi;
       const bool win = i >= w_lo && i <= w_hi;
-      if (early) {
-        if (win) { a_sum = fmaf(v, v, a_sum); mx_ew = fmaxf(mx_ew, fabsf(v)); }
-        else { c_sum = fmaf(v, v, c_sum); mx_enw = fmaxf(mx_enw, fabsf(v)); }
-      } else {
-        late_sq = fmaf(v, v, late_sq);
-        mx_late = fmaxf(mx_late, fabsf(v));
+      const float av = fabsf(v), sq = v * v;
+      // branch-free: every element lands in exactly one class
+      a_sum += (early && win) ? sq : 0.f;
+      c_sum += (early && !win) ? sq : 0.f;
+      late_sq += early ? 0.f : sq;
+      mx_ew = fmaxf(mx_ew, (early && win) ? av : 0.f);
+      mx_enw = fmaxf(mx_enw, (early && !win) ? av : 0.f);
+      mx_late = fmaxf(mx_late, early ? 0.f : av);
+    };
+    if (vec) {
+      const float4* __restrict__ p4 = reinterpret_cast<const float4*>(xr);
+      const int64_t T4 = T / 4;
+      int64_t i = threadIdx.x;
+      for (; i + RT < T4; i += 2 * RT) {
+        const float4 a = p4[i], b = p4[i + RT];
+        acc_one(a.x, 4 * i); acc_one(a.y, 4 * i + 1); acc_one(a.z, 4 * i + 2); acc_one(a.w, 4 * i + 3);
+        const int64_t j = i + RT;
+        acc_one(b.x, 4 * j); acc_one(b.y, 4 * j + 1); acc_one(b.z, 4 * j + 2); acc_one(b.w, 4 * j + 3);
       }
+      for (; i < T4; i += RT) {
+        const float4 a = p4[i];
+        acc_one(a.x, 4 * i); acc_one(a.y, 4 * i + 1); acc_one(a.z, 4 * i + 2); acc_one(a.w, 4 * i + 3);
+      }
+    } else {
+      for (int64_t i = threadIdx.x; i < T; i += RT) acc_one(xr[i], i);
     }
     a_sum = block_sum(a_sum, shf);
     c_sum = block_sum(c_sum, shf);
@@ -167,16 +242,31 @@ __global__ __launch_bounds__(RT) void alter_drr_kernel(const float* __restrict__
     // ensure_max_of_audio(1.0): peak of the result, analytically (multiplication is monotonic)
     const float peak = fmaxf(fmaxf(fabsf(alpha * mx_ew), mx_enw), mx_late);
     const float gain = (alpha == alpha && peak > 1.0f) ? 1.0f / peak : 1.0f;  // NaN peak: no rescale
-    // sweep 3
+    // sweep 3: literal alpha*w*early + (1-w)*early + late (a non-finite alpha poisons the row as in torch)
     float* __restrict__ orow = out + row * T;
-    for (int64_t i = threadIdx.x; i < T; i += RT) {
-      const float v = xr[i];
+    auto out_one = [&](float v, int64_t i) {
       const bool early = i >= e_lo && i <= e_hi;
       const bool win = i >= w_lo && i <= w_hi;
-      // literal alpha*w*early + (1-w)*early + late: a non-finite alpha poisons the row as in torch
       const float e = early ? v : 0.f, l = early ? 0.f : v, w = win ? 1.f : 0.f;
-      const float y = alpha * w * e + (1.f - w) * e + l;
-      orow[i] = y * gain;
+      return (alpha * w * e + (1.f - w) * e + l) * gain;
+    };
+    if (vec) {
+      const float4* __restrict__ p4 = reinterpret_cast<const float4*>(xr);
+      float4* __restrict__ o4 = reinterpret_cast<float4*>(orow);
+      const int64_t T4 = T / 4;
+      int64_t i = threadIdx.x;
+      for (; i + RT < T4; i += 2 * RT) {
+        const float4 a = p4[i], b = p4[i + RT];
+        const int64_t j = i + RT;
+        o4[i] = make_float4(out_one(a.x, 4 * i), out_one(a.y, 4 * i + 1), out_one(a.z, 4 * i + 2), out_one(a.w, 4 * i + 3));
+        o4[j] = make_float4(out_one(b.x, 4 * j), out_one(b.y, 4 * j + 1), out_one(b.z, 4 * j + 2), out_one(b.w, 4 * j + 3));
+      }
+      for (; i < T4; i += RT) {
+        const float4 a = p4[i];
+        o4[i] = make_float4(out_one(a.x, 4 * i), out_one(a.y, 4 * i + 1), out_one(a.z, 4 * i + 2), out_one(a.w, 4 * i + 3));
+      }
+    } else {
+      for (int64_t i = threadIdx.x; i < T; i += RT) orow[i] = out_one(xr[i], i);
     }
   }
 }
