@@ -7,10 +7,11 @@
 // at_resample_f32 replaces
 //   audiotools/core/audio_signal.py:732        julius.resample_frac (replicate pad + strided conv1d)
 //
-// FIR: one workgroup = 2048 consecutive outputs of one (item, channel) row.  The input window
-// (with replicate padding applied while staging) and the item's taps sit in LDS; every thread
-// owns 8 consecutive outputs and slides a 16-sample register window over the taps, 64 FMAs per
-// 4 ds_read_b128 -- the kernel is bound by the FP32 vector rate, not by LDS or HBM.
+// FIR (direct form, used for short filters; long ones go to the overlap-save kernel in
+// firfft.hip): one workgroup = 4096 consecutive outputs of one (item, channel) row.  The input
+// window (with replicate padding applied while staging) and the item's taps sit in LDS; every
+// thread owns 16 consecutive outputs and slides a 24-sample register window over the taps,
+// 128 FMAs per 2 ds_read_b128 of x -- bound by the FP32 vector rate, not by LDS or HBM.
 // Resampler: see the comment above resample_kernel.
 #include "at_common.h"
 

@@ -14,12 +14,14 @@
 //  * every thread owns 16 complex points; L = M/16 threads form one frame, so a
 //    wave64 transforms 64/L frames at once (1 frame of n_fft=2048, 4 of 512);
 //  * Stockham autosort passes of radix 16,16,{2,4} in registers; the exchange
-//    between passes goes through a per-wave LDS slab of 8704 B (index i stored
-//    bank-swizzled, see phys<L>() in fft_wave.h).
-//    Waves never synchronise with each other (no s_barrier in the kernel);
-//  * a wave walks a chunk of consecutive frames of one row, so the 4x overlap
-//    of the input between frames is served by L1/L2, HBM sees each sample once;
-//  * twiddles and the window are loaded once per wave and stay in registers;
+//    between passes goes through a per-wave LDS slab of 8704 B (bank-swizzled,
+//    see phys<L>() in fft_wave.h).  Waves never synchronise with each other
+//    (no s_barrier after the table setup);
+//  * a wave walks runs of consecutive frames of one row inside its XCD's span, so
+//    the 4x overlap of the input between frames is served by registers (hop =
+//    n_fft/4: shift by 4) and the XCD's L2; HBM sees each sample once;
+//  * window, split twiddles, pass-2 twiddles and the mel tables live in LDS
+//    (per block), pass-3 twiddles are derived from one base twiddle per butterfly;
 //  * global loads are float2 per lane, 512 B contiguous per wave instruction;
 //    global stores are float2 per lane, 512 B contiguous;
 //  * mel: the Slaney filterbank is banded (each bin feeds <= 2 bands), so it is
