@@ -168,16 +168,30 @@ __global__ __launch_bounds__(FF_NW * 64, FF_WPS) void fir_fft_kernel(const FirFf
   const int Ti = (int)A.T;
   const int b_lo = seg * A.blocks_per_seg;
   const int b_hi = min(b_lo + A.blocks_per_seg, A.blocks_per_row);
+  // Input of a block: interior blocks take 16 dword-aligned 8-B loads per lane, issued one block
+  // AHEAD (right after pass 1 of the current block consumed the registers); row-edge blocks are
+  // staged with replicate clamping through the wave's slab at the top of their own iteration.
+  auto interior = [&](int blk) { const int s0 = blk * V - A.half + A.j0; return s0 >= 0 && s0 + N <= Ti; };
+  float2 nx[16];
+  auto issue_loads = [&](int blk) __attribute__((always_inline)) {
+    const float* __restrict__ p = xr + (blk * V - A.half + A.j0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const f2u v = *reinterpret_cast<const f2u*>(p + 2 * (t + L * q));
+      nx[q] = make_float2(v.x, v.y);
+    }
+  };
+  bool have_nx = false;
+  if (b_lo < b_hi && interior(b_lo)) { issue_loads(b_lo); have_nx = true; }
+  const int src_lane = (64 - t) & 63;
+
   for (int blk = b_lo; blk < b_hi; ++blk) {
     const int o0 = blk * V;                 // first output of the block (T < 2^31 checked by the host)
     const int s0 = o0 - A.half + A.j0;      // first input sample
     float2 a[16];
-    if (s0 >= 0 && s0 + N <= Ti) {
+    if (have_nx) {                          // wave-uniform
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const f2u v = *reinterpret_cast<const f2u*>(xr + s0 + 2 * (t + L * q));
-        a[q] = make_float2(v.x, v.y);
-      }
+      for (int q = 0; q < 16; ++q) a[q] = nx[q];
     } else {
       // row edges: replicate-clamped samples staged through the wave's slab (linear floats)
       float* stage = reinterpret_cast<float*>(fbuf);
@@ -192,14 +206,19 @@ __global__ __launch_bounds__(FF_NW * 64, FF_WPS) void fir_fft_kernel(const FirFf
       for (int q = 0; q < 16; ++q) a[q] = reinterpret_cast<const float2*>(stage)[t + L * q];
       wave_sync();
     }
+    have_nx = blk + 1 < b_hi && interior(blk + 1);
+    if (have_nx) issue_loads(blk + 1);
     fft(a);
-    // ---- spectrum product on the packed form, conj(Z') written back in place
+    // ---- spectrum product on the packed form.  Lane t produces conj(Z') at k = t + 64 q (q < 8),
+    // which IS point t + 64 q of the inverse transform's first pass, and at M - k, which is point
+    // (64 - t) + 64 (15 - q): register 15 - q of lane (64 - t) mod 64 -- handed over with
+    // ds_bpermute instead of a round trip through the slab (lane 0 pairs with itself).
+    float2 cmv[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = t + L * q;
-      const int ik = phys<L>(k), im = phys<L>((M - k) & (M - 1));
-      const float2 zk = fbuf[ik];
-      const float2 zm = fbuf[im];
+      const float2 zk = fbuf[phys<L>(k)];
+      const float2 zm = fbuf[phys<L>((M - k) & (M - 1))];
       const float2 w = s_twp[k];
       const float2 E = make_float2(zk.x + zm.x, zk.y - zm.y);
       const float dr = zk.x - zm.x, di = zk.y + zm.y;
@@ -208,38 +227,46 @@ __global__ __launch_bounds__(FF_NW * 64, FF_WPS) void fir_fft_kernel(const FirFf
       const float2 Qq = cadd(cmul(E, D[q]), cmul(O, S[q]));
       // R = i conj(w) Q
       const float2 R = make_float2(-fmaf(w.x, Qq.y, -w.y * Qq.x), fmaf(w.x, Qq.x, w.y * Qq.y));
-      // conj(Z'[k]) = conj(P + R);  conj(Z'[M-k]) = P - R
-      const float2 ck = make_float2(Pp.x + R.x, -(Pp.y + R.y));
-      const float2 cm = make_float2(Pp.x - R.x, Pp.y - R.y);
-      fbuf[im] = cm;   // for k == 0 both are slot 0 and ck == cm up to rounding; ck wins
-      fbuf[ik] = ck;
+      a[q] = make_float2(Pp.x + R.x, -(Pp.y + R.y));   // conj(Z'[k]) = conj(P + R)
+      cmv[q] = make_float2(Pp.x - R.x, Pp.y - R.y);    // conj(Z'[M-k]) = P - R
     }
-    if (t == 0) {  // k == M/2: conj(Z') = (2/N) conj(Z[M/2]) G[M/2]
-      const float2 z = fbuf[phys<L>(M / 2)];
-      fbuf[phys<L>(M / 2)] = cmul(make_float2(z.x, -z.y), Gh);
-    }
-    wave_sync();
-    load_points<L>(a, fbuf, t);
-    wave_sync();
-    fft(a);
-    // ---- z'[n] = conj(F[n]): outputs o0 + 2n, o0 + 2n + 1 for 2n < V
-    const int lim = min(Ti - o0, V);
+    // k == M/2 (point 512 = register 8 of lane 0): conj(Z') = (2/N) conj(Z[M/2]) G[M/2]
+    const float2 zmid = fbuf[phys<L>(M / 2)];
+    const float2 mid = cmul(make_float2(zmid.x, -zmid.y), Gh);
+    wave_sync();  // all reads of Z done before pass 1 of the inverse overwrites the slab
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int n = t + L * q;
-      const float2 y = fbuf[phys<L>(n)];
-      float y0 = y.x, y1 = -y.y;
-      float* __restrict__ po = orow + o0 + 2 * n;
-      if (2 * n + 1 < lim) {
-        if (A.accumulate) {
-          const f2u v = *reinterpret_cast<const f2u*>(po);
-          y0 += v.x; y1 += v.y;
+    for (int j = 0; j < 8; ++j) {
+      const float2 sv = make_float2(__shfl(cmv[7 - j].x, src_lane, 64), __shfl(cmv[7 - j].y, src_lane, 64));
+      const float2 own = j == 0 ? mid : cmv[j == 0 ? 0 : 8 - j];
+      a[8 + j] = t == 0 ? own : sv;
+    }
+    fft(a);
+    // ---- z'[n] = conj(F[n]): outputs o0 + 2n, o0 + 2n + 1 for 2n < lim
+    const int lim = min(Ti - o0, V);
+    if (!A.accumulate) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int n = t + L * q;
+        const float2 y = fbuf[phys<L>(n)];
+        float* __restrict__ po = orow + o0 + 2 * n;
+        if (2 * L * (q + 1) <= lim) {            // the whole wave is inside: wave-uniform, no exec masking
+          f2u o; o.x = y.x; o.y = -y.y;
+          *reinterpret_cast<f2u*>(po) = o;
+        } else if (2 * L * q < lim) {
+          if (2 * n < lim) po[0] = y.x;
+          if (2 * n + 1 < lim) po[1] = -y.y;
         }
-        f2u o; o.x = y0; o.y = y1;
-        *reinterpret_cast<f2u*>(po) = o;
-      } else if (2 * n < lim) {
-        if (A.accumulate) y0 += *po;
-        *po = y0;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int n = t + L * q;
+        const float2 y = fbuf[phys<L>(n)];
+        float* __restrict__ po = orow + o0 + 2 * n;
+        if (2 * L * q < lim) {
+          if (2 * n < lim) po[0] += y.x;
+          if (2 * n + 1 < lim) po[1] -= y.y;
+        }
       }
     }
     wave_sync();
