@@ -48,6 +48,36 @@ class _NativeStft(torch.autograd.Function):
         return kernels.stft_adjoint(grad, window, n_fft, hop, T), None, None, None
 
 
+class _NativeStftMel(torch.autograd.Function):
+    """mel_spectrogram() under autograd: ONE fused forward kernel (STFT + |X| + banded mel), and a
+    backward that maps dL/dmel to dL/dX with the dense basis (``g_mag = g_mel @ basis``,
+    ``g_X += g_mag * X / |X|``, the derivative torch's abs() uses) before the native adjoint."""
+
+    @staticmethod
+    def forward(ctx, audio, window, n_fft, hop, units, basis):
+        info, w, n_mels = units
+        X, mel = kernels.stft_mel(audio.detach(), window, n_fft, hop, mel=(info, w, n_mels))
+        ctx.save_for_backward(window, X, basis)
+        ctx.cfg = (n_fft, hop, audio.shape[-1])
+        return X, mel
+
+    @staticmethod
+    def backward(ctx, gX, gmel):
+        window, X, basis = ctx.saved_tensors
+        n_fft, hop, T = ctx.cfg
+        g = gX
+        if gmel is not None:
+            # mel[b,c,m,n] = sum_f basis[m,f] |X[b,c,f,n]|
+            g_mag = torch.matmul(gmel.transpose(2, 3), basis).transpose(2, 3)      # (B, C, F, N)
+            mag = X.abs()
+            unit = torch.where(mag > 0, X / mag.clamp_min(torch.finfo(mag.dtype).tiny), torch.zeros_like(X))
+            gm = g_mag * unit
+            g = gm if g is None else g + gm
+        if g is None:
+            return None, None, None, None, None, None
+        return kernels.stft_adjoint(g, window, n_fft, hop, T), None, None, None, None, None
+
+
 def _native_autograd_ok(audio: torch.Tensor, n_fft: int, hop: int, match_stride: bool) -> bool:
     """A HIP float32 tensor that needs gradients can use the native forward + adjoint pair."""
     return (audio.is_cuda and audio.dtype == torch.float32 and audio.requires_grad and torch.is_grad_enabled()
@@ -163,14 +193,24 @@ class SpectralMixin:
             kwargs.get("window_length"), kwargs.get("hop_length"), kwargs.get("window_type"),
             kwargs.get("match_stride"), kwargs.get("padding_type"))
         audio = self.audio_data
-        if kernels.is_native(audio) and kernels.stft_native_supported(n_fft):
+        units = None
+        if kernels.stft_native_supported(n_fft) and audio.is_cuda:
+            units = tables.mel_units_or_none(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, audio.device)
+        if kernels.is_native(audio) and units is not None:
             dev = audio.device
-            info, w = tables.mel_units(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, dev)
+            info, w = units
             window = self.get_window(wtype, n_fft, str(dev))
             right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
             X, mel = kernels.stft_mel(audio, window, n_fft, hop, pad=pad, right_pad=right_pad,
                                       padding_type=padding_type, match_stride=match_stride,
                                       mel=(info, w, n_mels))
+            self.stft_data = X
+            return mel
+        if units is not None and _native_autograd_ok(audio, n_fft, hop, match_stride) and not kwargs.get("padding_type"):
+            dev = audio.device
+            units = tuple(units) + (n_mels,)
+            basis = torch.from_numpy(self.get_mel_filters(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax)).to(dev)
+            X, mel = _NativeStftMel.apply(audio, self.get_window(wtype, n_fft, str(dev)), n_fft, hop, units, basis)
             self.stft_data = X
             return mel
         X = self.stft(**kwargs)

@@ -221,6 +221,27 @@ def mel_units(sr, n_fft, n_mels, fmin, fmax, device):
                         lambda: mel_units_np(mel_filters_np(sr, n_fft, n_mels, fmin, fmax)))
 
 
+_mel_units_unsupported = set()
+
+
+def mel_units_or_none(sr, n_fft, n_mels, fmin, fmax, device):
+    """Unit tables of the fused mel stage, or None when the filterbank does not fit its layout
+    (a band wider than 16 rows of 16 bins, e.g. 5 mels at n_fft 2048, or more than 384 units):
+    the caller then applies the dense basis to |X| of the native STFT instead."""
+    key = (sr, n_fft, n_mels, fmin, fmax)
+    # n_fft = 32: 64 frames per wave, their padded magnitude rows do not fit the wave's LDS slab
+    # (at_stft_mel_f32 answers AT_ERR_UNSUPPORTED for the mel stage)
+    if key in _mel_units_unsupported or n_fft < 64:
+        return None
+    try:
+        return mel_units(sr, n_fft, n_mels, fmin, fmax, device)
+    except _native.NativeError as e:
+        if "unsupported" not in str(e):
+            raise
+        _mel_units_unsupported.add(key)
+        return None
+
+
 def install_table(key, device, tensors):
     """Install an already-on-device table (used by the multi-GPU broadcast)."""
     _device_cache[(key, _dev_key(device))] = tensors

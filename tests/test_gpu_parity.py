@@ -114,6 +114,20 @@ def test_mel_vs_oracle(sr, n_fft, n_mels):
     assert rel_err(s.mfcc(n_mels=n_mels), restate.mfcc(ref)) < 1e-3
 
 
+@pytest.mark.parametrize("win,n_mels", [(32, 5), (64, 10), (128, 20), (256, 40), (512, 80), (1024, 160), (2048, 320), (2048, 5), (512, 5)])
+def test_mel_loss_grid(win, n_mels):
+    """The (window, n_mels) grid of metrics/spectral.py MelSpectrogramLoss.  Banks that do not fit
+    the fused unit layout (very wide or very many bands) take native STFT + dense basis on the
+    device -- never an error."""
+    x = synth.audio_batch(2, 1, 16000, seed=win + n_mels, gaps=False)
+    s = A.AudioSignal(x.clone(), 44100).to("cuda")
+    got = s.mel_spectrogram(n_mels, window_length=win, hop_length=win // 4, window_type="hann")
+    X_ref = restate.stft(x, win, win // 4)
+    ref = restate.mel_spectrogram(X_ref, 44100, n_mels)
+    assert rel_err(got, ref) < REL
+    assert rel_err(torch.view_as_real(s.stft_data), torch.view_as_real(X_ref)) < REL
+
+
 def test_mel_golden_cfg2():
     d = np.load(os.path.join(G, "mel_cfg2.npz"))
     s = A.AudioSignal(torch.from_numpy(d["x"]), 44100).to("cuda")

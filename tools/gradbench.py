@@ -28,3 +28,25 @@ def run(native):
 
 g1 = run(True); g2 = run(False)
 print("grad rel diff", float((g1 - g2).abs().max() / g2.abs().max()))
+
+
+def run_mel(native):
+    saved = spectral._native_autograd_ok
+    if not native:
+        spectral._native_autograd_ok = lambda *a: False
+    try:
+        def fn():
+            xa = x.clone().requires_grad_(True)
+            mel = A.AudioSignal(xa, 44100).mel_spectrogram(80)
+            mel.clamp(1e-5).log10().sum().backward()
+            return xa.grad
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3): g = fn()
+        torch.cuda.synchronize()
+        print(f"log-mel loss fwd + bwd, B={B} ({'native' if native else 'torch.stft'}): {(time.perf_counter() - t0) / 3 * 1e3:8.2f} ms", flush=True)
+        return g
+    finally:
+        spectral._native_autograd_ok = saved
+
+m1 = run_mel(True); m2 = run_mel(False)
+print("mel grad rel diff", float((m1 - m2).abs().max() / m2.abs().max()))
