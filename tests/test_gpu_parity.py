@@ -462,6 +462,45 @@ def test_c_abi_error_codes_and_degenerate_inputs():
         A.AudioSignal(torch.randn(1, 1, 4096), 16000).to("cuda").stft(512, 100, match_stride=True)
 
 
+@pytest.mark.parametrize("name", ["ClippingDistortion", "Equalizer", "Quantization", "MuLawQuantization", "NoiseFloor",
+                                  "VolumeChange", "VolumeNorm", "Silence", "LowPass", "HighPass", "RescaleAudio",
+                                  "ShiftPhase", "InvertPhase", "FrequencyMask", "TimeMask", "MaskLowMagnitudes",
+                                  "Smoothing", "Identity"])
+def test_transforms_gpu_vs_cpu(name):
+    """Every loader-free transform of data/transforms.py with the same instantiated parameters on
+    the HIP path and on the CPU path (which tests/test_transforms.py pins seed-for-seed to the
+    unmodified reference), batch of 4, half of the items masked out (prob 0.5)."""
+    from audiotools_amd import transforms as tfm
+    x = synth.audio_batch(4, 1, 22050, seed=17, gaps=False)
+    t = getattr(tfm, name)(prob=0.5) if name != "Identity" else tfm.Identity()
+    sig = A.AudioSignal(x.clone(), 44100)
+    kw = t.batch_instantiate([3, 4, 5, 6], sig)
+    ref = t(sig.clone(), **kw).audio_data
+    got = t(sig.clone().to("cuda"), **A.util.prepare_batch(kw, "cuda")).audio_data
+    if name == "MaskLowMagnitudes":   # threshold on a float32 log: allow isolated bin flips
+        assert float(((got.cpu() - ref).abs() > 1e-3 * ref.abs().max()).float().mean()) < 1e-3
+    else:
+        assert rel_err(got, ref) < REL, name
+
+
+def test_transform_chain_gpu_vs_cpu():
+    """cfg4-style Compose (per-item LowPass cutoffs, Equalizer, RoomImpulseResponse from a tensor
+    bank with DRR + EQ, VolumeNorm, spectral masks) end to end: HIP path vs CPU path."""
+    from audiotools_amd import transforms as tfm
+    B, T, SR = 6, 24000, 16000
+    x = synth.audio_batch(B, 1, T, seed=23, gaps=False, sample_rate=SR)
+    g = torch.Generator().manual_seed(9)
+    bank = torch.randn(5, 1, 4000, generator=g) * torch.exp(-torch.arange(4000) / 600.0)
+    chain = tfm.Compose(tfm.LowPass(cutoff=("choice", [2000, 4000, 6000])), tfm.Equalizer(n_bands=6),
+                        tfm.RoomImpulseResponse(loader=tfm.TensorLoader(bank, SR), duration=0.25),
+                        tfm.VolumeNorm(("uniform", -30, -20)), tfm.FrequencyMask(), tfm.TimeMask(), tfm.ShiftPhase())
+    sig = A.AudioSignal(x.clone(), SR)
+    kw = chain.batch_instantiate(list(range(B)), sig)
+    ref = chain(sig.clone(), **kw).audio_data
+    got = chain(sig.clone().to("cuda"), **A.util.prepare_batch(kw, "cuda")).audio_data
+    assert rel_err(got, ref) < 5 * REL     # seven stages: the per-stage 1e-4 budget accumulates
+
+
 # ----------------------------------------------------------------------------- istft
 @pytest.mark.parametrize("win,hop,wt,ms", [(2048, 512, "hann", False), (2048, 512, "sqrt_hann", True),
                                            (512, 128, "sqrt_hann", False), (512, 128, "hann", True),
