@@ -501,6 +501,23 @@ def test_transform_chain_gpu_vs_cpu():
     assert rel_err(got, ref) < 5 * REL     # seven stages: the per-stage 1e-4 budget accumulates
 
 
+def test_device_stager_overlapped_copies():
+    """Pinned-host -> device staging on a side stream: every batch arrives intact and in order while
+    the consumer keeps the previous one busy (depth 2 and 3, more batches than buffers)."""
+    from audiotools_amd.data import DeviceStager
+    g = torch.Generator().manual_seed(1)
+    batches = [torch.randn(4, 2, 44100, generator=g) for _ in range(7)]
+    for depth in (2, 3):
+        sums = []
+        for x in DeviceStager(batches, "cuda", depth=depth):
+            assert x.is_cuda
+            s = A.AudioSignal(x, 44100)
+            sums.append((s.mel_spectrogram(80).sum() + s.loudness().sum()).clone())   # real work on the buffer
+        ref = [A.AudioSignal(b.cuda(), 44100) for b in batches]
+        ref = [r.mel_spectrogram(80).sum() + r.loudness().sum() for r in ref]
+        assert torch.allclose(torch.stack(sums), torch.stack(ref), rtol=1e-5)
+
+
 # ----------------------------------------------------------------------------- istft
 @pytest.mark.parametrize("win,hop,wt,ms", [(2048, 512, "hann", False), (2048, 512, "sqrt_hann", True),
                                            (512, 128, "sqrt_hann", False), (512, 128, "hann", True),

@@ -180,3 +180,13 @@ def test_native_dispatch_rules_on_cpu():
     assert s.stft_data is not before
     y = s.istft().audio_data
     assert y.shape == x.shape and torch.isfinite(y).all()
+
+
+def test_device_stager_passthrough_and_order():
+    """DeviceStager yields every batch once, in order (CPU device = pass-through; the CUDA path with
+    pinned buffers and events is covered by the GPU suite)."""
+    from audiotools_amd.data import DeviceStager
+    batches = [torch.full((2, 1, 8), float(i)) for i in range(5)]
+    got = [b.clone() for b in DeviceStager(batches, "cpu")]
+    assert len(got) == 5 and all(torch.equal(g, b) for g, b in zip(got, batches))
+    assert list(DeviceStager([], "cpu")) == []
