@@ -56,7 +56,6 @@ struct __attribute__((packed, aligned(4))) f2u { float x, y; };  // dword-aligne
 
 __global__ __launch_bounds__(FF_NW * 64, FF_WPS) void fir_fft_kernel(const FirFftArgs A) {
   constexpr int M = FF_M, N = FF_N, L = 64;
-  using P = Plan<M>;
   __shared__ float2 lds[FF_NW * WAVE_LDS_SLOTS];
   __shared__ float2 s_twp[M / 2 + 1];
   __shared__ __attribute__((aligned(16))) float s_tw2[16 * 36];

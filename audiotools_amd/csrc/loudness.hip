@@ -85,8 +85,6 @@ __device__ __forceinline__ float wave_shr1(float v, float lane0) {              
 // wave64 sum with DPP only (quad_perm xor 1/2, row_half_mirror, row_mirror, row_bcast15/31);
 // the total ends up in lane 63 and is broadcast with v_readlane
 __device__ __forceinline__ float wave_sum_dpp(float v) {
-  auto dpp = [](float x, int ctrl_dummy) { return x; };
-  (void)dpp;
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror

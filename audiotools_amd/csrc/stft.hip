@@ -110,7 +110,6 @@ __host__ __device__ constexpr int lds_fixed_floats(int nw) { return nw * 2 * WAV
 template <int M, int NW, bool VEC2, int NR /* mel rounds of 64 units; 0 = no mel */>
 __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const StftArgs A) {
   constexpr bool MEL = NR > 0;
-  constexpr bool WRITE_STFT = true;
   using P = Plan<M>;
   constexpr int L = P::L, FW = P::FW, N = 2 * M;
   constexpr int MAG_ROWS = M / 16 + 1;            // rows of 16 bins per frame (last row: Nyquist only)
@@ -169,7 +168,6 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
       tw3b[b] = A.tw[(j % NS) * (N / (NS * P::R3))];
     }
   }
-  constexpr int NRR = MEL ? NR : 1;
   const int Ti = (int)A.T;
   const int n_out = (int)A.n_out;
   const int gpr = A.groups_per_row;
