@@ -159,6 +159,11 @@ struct IstftFusedArgs {
   int run;                // segments per unit
   int runs_per_row;
   int64_t total_units;    // rows * runs_per_row
+  // mel backward (MELB): X holds the SAVED forward spectrum, the gradient comes from the mel output
+  const float* gmel;      // (rows, n_x, n_mels) dL/dmel, band-contiguous
+  const int* bin_bands;   // (M+1): the two bands whose triangles cover bin k: lo | hi << 16
+  const float2* bin_w;    // (M+1): their weights basis[lo][k], basis[hi][k] (0 where absent)
+  int n_mels;
 };
 
 struct __attribute__((packed, aligned(4))) f2u { float x, y; };  // dword-aligned pair
@@ -191,7 +196,11 @@ __global__ __launch_bounds__(256) void istft_env_kernel(const float* __restrict_
 // x_bar = OLA(window * sum_k Re(G_k e^{+2 pi i k n / N})) -- same data flow, but no 1/N, no factor 2 on
 // the interior bins (i.e. DC and Nyquist count double relative to c2r), no envelope division and no
 // removal of the centre padding (out covers the whole padded signal).
-template <int M, int SH /* hop = 2 L SH */, bool ADJ>
+// MELB (with ADJ): backward of the FUSED mel path.  X is the saved forward spectrum and the incoming
+// gradient is dL/dmel; the spectrum gradient  G[k] = (sum_m basis[m,k] gmel[m]) X[k] / |X[k]|  is formed
+// on the fly from a per-bin table (a triangular bank has at most two non-zero bands per bin) and
+// never touches HBM.
+template <int M, int SH /* hop = 2 L SH */, bool ADJ, bool MELB = false>
 __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const IstftFusedArgs A) {
   using P = Plan<M>;
   constexpr int L = P::L, FW = P::FW, N = 2 * M, HOP = 2 * L * SH, R = N / HOP;
@@ -199,6 +208,11 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   __shared__ float2 s_win2[M];
   __shared__ float2 s_twf[M];                                     // fold twiddles (cos, -sin)(2 pi k / N), k < M
   __shared__ __attribute__((aligned(16))) float s_tw2[16 * 36];   // pass-2 twiddles, row = j mod 16
+  __shared__ int s_bb[MELB ? M + 1 : 1];
+  __shared__ float2 s_bw[MELB ? M + 1 : 1];
+  if constexpr (MELB) {
+    for (int i = threadIdx.x; i <= M; i += 256) { s_bb[i] = A.bin_bands[i]; s_bw[i] = A.bin_w[i]; }
+  }
   for (int i = threadIdx.x; i < M; i += 256) {
     s_win2[i] = reinterpret_cast<const float2*>(A.window)[i];
     s_twf[i] = A.tw[i];
@@ -248,6 +262,8 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   // latency hides behind the FFT of the current frame.
   const int src_lane = (lane - t) + ((L - t) & (L - 1));
   float2 xa[16], xN;
+  constexpr int GP = 8;            // mel values per lane: n_mels <= GP * L
+  float gpre[MELB ? GP : 1];
   auto issue_loads = [&](int f) __attribute__((always_inline)) -> bool {
     const int fx = f - A.lead;
     const bool live = fx >= 0 && fx < A.n_x && f < h1;
@@ -255,6 +271,15 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
 #pragma unroll
     for (int q = 0; q < 16; ++q) xa[q] = Xf[t + L * q];
     xN = Xf[M];
+    if constexpr (MELB) {
+      const float* __restrict__ gr = A.gmel + (row * (int64_t)A.n_x + (live ? fx : 0)) * A.n_mels;
+#pragma unroll
+      for (int j = 0; j < GP; ++j) {
+        const int m = t + L * j;
+        const float v = gr[m < A.n_mels ? m : 0];    // branch-free: clamped address, select
+        gpre[j] = m < A.n_mels ? v : 0.f;
+      }
+    }
     return live;
   };
   bool live_nxt = issue_loads(h0 - (R - 1));
@@ -262,6 +287,27 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   for (int i = 0; i < A.run + R - 1; ++i) {
     const int f = h0 - (R - 1) + i;          // virtual frame added in this step = segment finished
     const bool live = live_nxt;
+    if constexpr (MELB) {
+      // dL/dmel row of this frame -> the frame slot's slab (free between frames), then per bin
+      // g_mag = w_lo g[lo] + w_hi g[hi]  and  G = g_mag X / |X|  (0 where X == 0, as torch's abs)
+      float* gs = reinterpret_cast<float*>(fbuf);
+#pragma unroll
+      for (int j = 0; j < GP; ++j)
+        if (t + L * j < A.n_mels) gs[t + L * j] = gpre[j];
+      wave_sync();
+      auto to_grad = [&](float2 x, int k) {
+        const int bb = s_bb[k];
+        const float2 bw = s_bw[k];
+        const float gm = fmaf(bw.x, gs[bb & 0xffff], bw.y * gs[bb >> 16]);
+        const float p = fmaf(x.x, x.x, x.y * x.y);
+        const float sc = p > 0.f ? gm * __builtin_amdgcn_rsqf(p) : 0.f;
+        return make_float2(x.x * sc, x.y * sc);
+      };
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xa[q] = to_grad(xa[q], t + L * q);
+      xN = to_grad(xN, M);
+      wave_sync();   // the slab is about to be overwritten by pass 1
+    }
     float2 a[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -361,13 +407,13 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   }
 }
 
-template <int M, int SH, bool ADJ>
+template <int M, int SH, bool ADJ, bool MELB = false>
 int launch_fused(const IstftFusedArgs& A, hipStream_t stream) {
   constexpr int FW = Plan<M>::FW;
   const int64_t waves = (A.total_units + FW - 1) / FW;
   const int64_t blocks = (waves + 3) / 4;
   if (blocks > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((istft_fused_kernel<M, SH, ADJ>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
+  hipLaunchKernelGGL((istft_fused_kernel<M, SH, ADJ, MELB>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }
@@ -379,6 +425,19 @@ int launch_fused_sh(int sh, const IstftFusedArgs& A, hipStream_t stream) {
     case 2: return launch_fused<M, 2, ADJ>(A, stream);
     case 4: return launch_fused<M, 4, ADJ>(A, stream);
     case 8: return launch_fused<M, 8, ADJ>(A, stream);
+  }
+  return AT_ERR_UNSUPPORTED;
+}
+
+// mel backward: hop = n_fft/4 only (the hop every mel loss of the reference uses), n_fft >= 64
+int launch_fused_melb(int M, const IstftFusedArgs& F, hipStream_t st) {
+  switch (M) {
+    case 32: return launch_fused<32, 4, true, true>(F, st);
+    case 64: return launch_fused<64, 4, true, true>(F, st);
+    case 128: return launch_fused<128, 4, true, true>(F, st);
+    case 256: return launch_fused<256, 4, true, true>(F, st);
+    case 512: return launch_fused<512, 4, true, true>(F, st);
+    case 1024: return launch_fused<1024, 4, true, true>(F, st);
   }
   return AT_ERR_UNSUPPORTED;
 }
@@ -465,6 +524,7 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
     F.X = reinterpret_cast<const float2*>(X); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
     F.inv_env = reinterpret_cast<const float*>(workspace); F.out = out; F.rows = rows; F.length = length;
     F.n_x = (int)n_x; F.lead = lead; F.n_frames = (int)n_frames;
+    F.gmel = nullptr; F.bin_bands = nullptr; F.bin_w = nullptr; F.n_mels = 0;
     plan_runs(F, rows, n_fft, hop);
     const int64_t env_n = (n_frames - 1) * hop + n_fft;
     int64_t eb = (env_n + 255) / 256;
@@ -523,8 +583,33 @@ int at_stft_adjoint_f32(const float* G, int64_t rows, int64_t n_frames, const fl
   F.X = reinterpret_cast<const float2*>(G); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
   F.inv_env = nullptr; F.out = out; F.rows = rows; F.length = out_len;
   F.n_x = (int)n_frames; F.lead = 0; F.n_frames = (int)n_frames;
+  F.gmel = nullptr; F.bin_bands = nullptr; F.bin_w = nullptr; F.n_mels = 0;
   plan_runs(F, rows, n_fft, hop);
   return launch_fused_m<true>(n_fft / 2, sh, F, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Backward of the fused STFT + mel path w.r.t. the signal, given ONLY dL/dmel:
+//   X     (rows, n_frames, n_fft/2+1) complex64: the spectrum the forward pass stored
+//   gmel  (rows, n_frames, n_mels) f32: dL/dmel, band-contiguous
+//   bin_bands (n_fft/2+1) i32 = lo | hi << 16, bin_w (n_fft/2+1, 2) f32: per bin the (at most two)
+//         bands of the triangular bank that cover it and their weights (0 where absent)
+//   out   as at_stft_adjoint_f32.  hop must be n_fft/4, 64 <= n_fft <= 2048, n_mels <= n_fft/8.
+int at_stft_mel_adjoint_f32(const float* X, const float* gmel, const int* bin_bands, const float* bin_w, int n_mels,
+                            int64_t rows, int64_t n_frames, const float* window, const float* twiddles, int n_fft,
+                            int hop, float* out, int64_t out_len, void* stream) {
+  if (rows == 0) return AT_OK;
+  if (!X || !gmel || !bin_bands || !bin_w || !window || !twiddles || !out || rows < 0 || n_frames <= 0 || n_mels <= 0 ||
+      out_len < (n_frames - 1) * (int64_t)hop + n_fft || out_len >= (1LL << 31))
+    return AT_ERR_INVALID;
+  if (!(n_fft >= 64 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0) || hop * 4 != n_fft) return AT_ERR_UNSUPPORTED;
+  if (n_mels > 8 * (n_fft / 32) || n_mels >= 0xffff || n_frames >= (1LL << 31) / n_fft) return AT_ERR_UNSUPPORTED;
+  IstftFusedArgs F;
+  F.X = reinterpret_cast<const float2*>(X); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
+  F.inv_env = nullptr; F.out = out; F.rows = rows; F.length = out_len;
+  F.n_x = (int)n_frames; F.lead = 0; F.n_frames = (int)n_frames;
+  F.gmel = gmel; F.bin_bands = bin_bands; F.bin_w = reinterpret_cast<const float2*>(bin_w); F.n_mels = n_mels;
+  plan_runs(F, rows, n_fft, hop);
+  return launch_fused_melb(n_fft / 2, F, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -162,6 +162,44 @@ def stft_adjoint(grad_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop:
     return g
 
 
+def stft_mel_adjoint_supported(n_fft: int, hop: int, n_mels: int) -> bool:
+    return 64 <= n_fft <= 2048 and hop * 4 == n_fft and n_mels <= 8 * (n_fft // 32) and have("at_stft_mel_adjoint_f32")
+
+
+def _fold_reflect(out: torch.Tensor, T: int, half: int) -> torch.Tensor:
+    """Gradient w.r.t. the centre-padded signal -> gradient w.r.t. the signal (reflect padding:
+    padded position j < half mirrors x[half - j]; position half + T + j mirrors x[T - 2 - j])."""
+    g = out[..., half: half + T].clone()
+    g[..., 1: half + 1] += out[..., :half].flip(-1)
+    g[..., T - 1 - half: T - 1] += out[..., half + T: half + T + half].flip(-1)
+    return g
+
+
+def stft_mel_adjoint(X_bcfn: torch.Tensor, gmel_bcmn: torch.Tensor, bin_table, window: torch.Tensor, n_fft: int,
+                     hop: int, T: int) -> torch.Tensor:
+    """Backward of the fused mel path given only dL/dmel (B, C, n_mels, N) and the saved spectrum
+    (B, C, F, N): dL/daudio (B, C, T) in one kernel (the spectrum gradient is never materialised)."""
+    _require_native_ok(X_bcfn)
+    B, C, F, N = X_bcfn.shape
+    n_mels = gmel_bcmn.shape[2]
+    X = X_bcfn.transpose(2, 3).contiguous()
+    gm = gmel_bcmn.transpose(2, 3).to(torch.float32).contiguous()
+    bands, w = bin_table
+    dev = X.device
+    half = n_fft // 2
+    Lp = (N - 1) * hop + n_fft
+    full = T + n_fft
+    out = torch.empty((B, C, full), dtype=torch.float32, device=dev)
+    if full > Lp:
+        out[..., Lp:] = 0
+    tw = tables.stft_twiddles(n_fft, dev)
+    code = _native.lib().at_stft_mel_adjoint_f32(_native.ptr(torch.view_as_real(X)), _native.ptr(gm), _native.ptr(bands),
+                                                 _native.ptr(w), n_mels, B * C, N, _native.ptr(window), _native.ptr(tw),
+                                                 n_fft, hop, _native.ptr(out), full, _native.current_stream(dev))
+    _native.check(code, "at_stft_mel_adjoint_f32")
+    return _fold_reflect(out, T, half)
+
+
 def lufs_block_params(rate: int, block_size: float):
     """(K, S) exactly as loudness.py:165-170 computes them (Python floats)."""
     overlap = 0.75

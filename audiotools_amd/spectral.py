@@ -54,17 +54,22 @@ class _NativeStftMel(torch.autograd.Function):
     ``g_X += g_mag * X / |X|``, the derivative torch's abs() uses) before the native adjoint."""
 
     @staticmethod
-    def forward(ctx, audio, window, n_fft, hop, units, basis):
+    def forward(ctx, audio, window, n_fft, hop, units, basis, bin_table):
         info, w, n_mels = units
         X, mel = kernels.stft_mel(audio.detach(), window, n_fft, hop, mel=(info, w, n_mels))
         ctx.save_for_backward(window, X, basis)
         ctx.cfg = (n_fft, hop, audio.shape[-1])
+        ctx.bin_table = bin_table
+        ctx.set_materialize_grads(False)   # an unused stft_data output must arrive as None, not as 7 GB of zeros
         return X, mel
 
     @staticmethod
     def backward(ctx, gX, gmel):
         window, X, basis = ctx.saved_tensors
         n_fft, hop, T = ctx.cfg
+        if gX is None and gmel is not None and ctx.bin_table is not None:
+            # the usual case (a loss on the mel output only): one kernel, dL/dX never materialised
+            return (kernels.stft_mel_adjoint(X, gmel, ctx.bin_table, window, n_fft, hop, T),) + (None,) * 6
         g = gX
         if gmel is not None:
             # mel[b,c,m,n] = sum_f basis[m,f] |X[b,c,f,n]|
@@ -74,8 +79,8 @@ class _NativeStftMel(torch.autograd.Function):
             gm = g_mag * unit
             g = gm if g is None else g + gm
         if g is None:
-            return None, None, None, None, None, None
-        return kernels.stft_adjoint(g, window, n_fft, hop, T), None, None, None, None, None
+            return (None,) * 7
+        return (kernels.stft_adjoint(g, window, n_fft, hop, T),) + (None,) * 6
 
 
 def _native_autograd_ok(audio: torch.Tensor, n_fft: int, hop: int, match_stride: bool) -> bool:
@@ -210,7 +215,11 @@ class SpectralMixin:
             dev = audio.device
             units = tuple(units) + (n_mels,)
             basis = torch.from_numpy(self.get_mel_filters(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax)).to(dev)
-            X, mel = _NativeStftMel.apply(audio, self.get_window(wtype, n_fft, str(dev)), n_fft, hop, units, basis)
+            bin_table = None
+            if kernels.stft_mel_adjoint_supported(n_fft, hop, n_mels):
+                bin_table = tables.mel_bin_table(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, dev)
+            X, mel = _NativeStftMel.apply(audio, self.get_window(wtype, n_fft, str(dev)), n_fft, hop, units, basis,
+                                          bin_table)
             self.stft_data = X
             return mel
         X = self.stft(**kwargs)

@@ -221,6 +221,35 @@ def mel_units(sr, n_fft, n_mels, fmin, fmax, device):
                         lambda: mel_units_np(mel_filters_np(sr, n_fft, n_mels, fmin, fmax)))
 
 
+def mel_bin_table_np(basis: np.ndarray):
+    """Per-bin view of a triangular filterbank for the mel backward kernel: bin k is covered by at
+    most two bands.  Returns ``(bands int32 (F,) = lo | hi << 16, weights float32 (F, 2))`` or None
+    when some bin has more than two non-zero bands (not a shared-edge triangular bank)."""
+    n_mels, F = basis.shape
+    bands = np.zeros(F, dtype=np.int64)
+    w = np.zeros((F, 2), dtype=np.float32)
+    for k in range(F):
+        nz = np.nonzero(basis[:, k])[0]
+        if len(nz) > 2:
+            return None
+        for j, m in enumerate(nz):
+            bands[k] |= int(m) << (16 * j)
+            w[k, j] = basis[m, k]
+    return bands.astype(np.int32), w
+
+
+def mel_bin_table(sr, n_fft, n_mels, fmin, fmax, device):
+    """Device copy of :func:`mel_bin_table_np` (cached), or None."""
+    key = ("mel_bins", sr, n_fft, n_mels, fmin, fmax)
+    if key in _mel_units_unsupported:
+        return None
+    t = mel_bin_table_np(mel_filters_np(sr, n_fft, n_mels, fmin, fmax))
+    if t is None or n_mels >= 0xffff:
+        _mel_units_unsupported.add(key)
+        return None
+    return device_table(key, device, lambda: t)
+
+
 _mel_units_unsupported = set()
 
 

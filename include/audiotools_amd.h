@@ -103,6 +103,20 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
 int at_stft_adjoint_f32(const float* G, int64_t rows, int64_t n_frames, const float* window, const float* twiddles,
                         int n_fft, int hop, float* out, int64_t out_len, void* stream);
 
+/* ---- backward of the fused STFT + mel path ---------------------------------------------------
+ * mel = basis . |X| (audio_signal.py:1355-1368) under autograd (metrics/spectral.py
+ * MelSpectrogramLoss): given ONLY dL/dmel, the spectrum gradient
+ *     G[f,k] = (sum_m basis[m,k] gmel[f,m]) * X[f,k] / |X[f,k]|        (0 where X == 0)
+ * is formed inside the adjoint kernel from the saved spectrum and never written to memory.
+ *   X (rows, n_frames, n_fft/2+1) complex64 saved by the forward pass; gmel (rows, n_frames, n_mels)
+ *   bin_bands (n_fft/2+1) i32 = lo | hi << 16 and bin_w (n_fft/2+1, 2) f32: the at most two bands of
+ *   a triangular filterbank that cover each bin and their weights (0 where absent)
+ *   out as at_stft_adjoint_f32.   hop == n_fft/4, 64 <= n_fft <= 2048, n_mels <= n_fft/4.
+ */
+int at_stft_mel_adjoint_f32(const float* X, const float* gmel, const int* bin_bands, const float* bin_w, int n_mels,
+                            int64_t rows, int64_t n_frames, const float* window, const float* twiddles, int n_fft,
+                            int hop, float* out, int64_t out_len, void* stream);
+
 /* ---- BS.1770 integrated loudness ---------------------------------------------------
  * Replaces  audiotools/core/loudness.py:102-126  (2x torchaudio.functional.lfilter, the
  *           CPU/IIR branch), :164-174 (julius.core.unfold), :176-247 (gated integration).

@@ -518,6 +518,32 @@ def test_device_stager_overlapped_copies():
         assert torch.allclose(torch.stack(sums), torch.stack(ref), rtol=1e-5)
 
 
+@pytest.mark.parametrize("win,n_mels,T", [(2048, 80, 22050 + 7), (512, 80, 16000), (1024, 64, 12001), (256, 40, 5000), (64, 10, 1000)])
+def test_mel_autograd_fused_backward(win, n_mels, T):
+    """Log-mel loss (metrics/spectral.py MelSpectrogramLoss) through the fused forward kernel and
+    at_stft_mel_adjoint_f32 (dL/dX never materialised) vs torch autograd of the reference
+    formulation on CPU; also the mixed case where stft_data is used as well (torch-composed
+    spectrum gradient + native adjoint)."""
+    x = synth.audio_batch(2, 2, T, seed=win + n_mels, gaps=False)
+
+    def grads(dev, use_X):
+        xa = x.clone().to(dev).requires_grad_(True)
+        s = A.AudioSignal(xa, 44100)
+        mel = s.mel_spectrogram(n_mels, window_length=win, hop_length=win // 4, window_type="hann")
+        wts = torch.randn(mel.shape, generator=torch.Generator().manual_seed(7)).to(dev)
+        loss = (mel.clamp(1e-5).log10() * wts).sum() + (mel * wts).mean()
+        if use_X:
+            loss = loss + s.stft_data.abs().pow(2).mean()
+        (g,) = torch.autograd.grad(loss, xa)
+        return float(loss), g
+
+    for use_X in (False, True):
+        l_ref, g_ref = grads("cpu", use_X)
+        l_got, g_got = grads("cuda", use_X)
+        assert abs(l_got - l_ref) <= 1e-4 * abs(l_ref)
+        assert rel_err(g_got, g_ref) < REL, use_X
+
+
 # ----------------------------------------------------------------------------- istft
 @pytest.mark.parametrize("win,hop,wt,ms", [(2048, 512, "hann", False), (2048, 512, "sqrt_hann", True),
                                            (512, 128, "sqrt_hann", False), (512, 128, "hann", True),
