@@ -43,7 +43,7 @@ def stft_native_supported(n_fft: int) -> bool:
 
 def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *, pad: int = 0,
              right_pad: int = 0, padding_type: str = "reflect", match_stride: bool = False,
-             want_stft: bool = True, mel=None):
+             want_stft: bool = True, mel=None, frame_range=None):
     """Fused STFT (+ mel).  ``audio`` (B, C, T) float32 HIP tensor.
 
     ``mel`` is ``None`` or a tuple ``(unit_info, unit_w, n_mels)`` of
@@ -62,6 +62,8 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
     audio = audio.contiguous()
     F = n_fft // 2 + 1
     frame_lo, n_out = stft_frames(T, n_fft, hop, pad, right_pad, match_stride)
+    if frame_range is not None:      # explicit (first frame, count) of the centre-padded transform
+        frame_lo, n_out = frame_range
     dev = audio.device
     tw = tables.stft_twiddles(n_fft, dev)
     if not want_stft:
@@ -198,6 +200,36 @@ def stft_mel_adjoint(X_bcfn: torch.Tensor, gmel_bcmn: torch.Tensor, bin_table, w
                                                  n_fft, hop, _native.ptr(out), full, _native.current_stream(dev))
     _native.check(code, "at_stft_mel_adjoint_f32")
     return _fold_reflect(out, T, half)
+
+
+def istft_adjoint_supported(n_fft: int, hop: int) -> bool:
+    return istft_fused_supported(n_fft, hop) and (n_fft // 2) % hop == 0 and stft_native_supported(n_fft)
+
+
+def istft_adjoint(grad_bct: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, n_frames: int) -> torch.Tensor:
+    """Backward pass of ``istft(X (B, C, F, n_frames)) -> (B, C, T)``: dL/dX of logical shape
+    (B, C, F, n_frames).  The adjoint of overlap-add + envelope division + c2r is the FORWARD kernel:
+    X_bar[f, k] = (c_k / N) sum_n w[n] u[f hop + n] e^{-2 pi i k n / N},  u = (g / envelope) embedded
+    at offset N/2 in zeros, c_k = 2 for interior bins and 1 for DC / Nyquist (what torch's
+    fft_c2r backward computes)."""
+    _require_native_ok(grad_bct)
+    B, C, T = grad_bct.shape
+    half = n_fft // 2
+    dev = grad_bct.device
+    w2 = (window.to(torch.float32) ** 2)[None, None]
+    env = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, n_frames, device=dev), w2, stride=hop)[0, 0]
+    inv_env = torch.where(env > 1e-11, 1.0 / env, torch.zeros_like(env))
+    seg = inv_env[half: half + T]
+    if seg.numel() < T:              # samples no frame covers: zero output, zero gradient
+        seg = torch.nn.functional.pad(seg, (0, T - seg.numel()))
+    v = (grad_bct * (seg * (2.0 / n_fft))).contiguous()
+    # enough zeros on the right that (a) the frame count fits and (b) no frame reaches the reflected margin
+    right = max(0, (n_frames + 1) * hop - half - T, (n_frames - 1) * hop - T)
+    X, _ = stft_mel(v, window, n_fft, hop, pad=half, right_pad=right, padding_type="constant",
+                    frame_range=(half // hop, n_frames))
+    X[:, :, 0, :] *= 0.5
+    X[:, :, half, :] *= 0.5
+    return X
 
 
 def lufs_block_params(rate: int, block_size: float):

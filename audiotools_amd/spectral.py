@@ -83,6 +83,23 @@ class _NativeStftMel(torch.autograd.Function):
         return (kernels.stft_adjoint(g, window, n_fft, hop, T),) + (None,) * 6
 
 
+class _NativeIstft(torch.autograd.Function):
+    """istft() with the HIP kernels in both directions: forward = fused inverse kernel, backward =
+    the forward STFT kernel applied to grad / envelope (``kernels.istft_adjoint``)."""
+
+    @staticmethod
+    def forward(ctx, X, window, n_fft, hop, length):
+        ctx.save_for_backward(window)
+        ctx.cfg = (n_fft, hop, X.shape[-1])
+        return kernels.istft(X.detach(), window, n_fft, hop, length)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (window,) = ctx.saved_tensors
+        n_fft, hop, n_frames = ctx.cfg
+        return kernels.istft_adjoint(grad.contiguous(), window, n_fft, hop, n_frames), None, None, None, None
+
+
 def _native_autograd_ok(audio: torch.Tensor, n_fft: int, hop: int, match_stride: bool) -> bool:
     """A HIP float32 tensor that needs gradients can use the native forward + adjoint pair."""
     return (audio.is_cuda and audio.dtype == torch.float32 and audio.requires_grad and torch.is_grad_enabled()
@@ -170,7 +187,12 @@ class SpectralMixin:
         right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
         if length is None:
             length = self.original_signal_length + 2 * pad + right_pad
-        if kernels.is_native(torch.view_as_real(self.stft_data)) and kernels.stft_native_supported(n_fft):
+        Xd = self.stft_data
+        if (Xd.is_cuda and Xd.dtype == torch.complex64 and Xd.requires_grad and torch.is_grad_enabled()
+                and not match_stride and kernels.istft_adjoint_supported(n_fft, hop)
+                and kernels.have("at_istft_f32")):
+            x = _NativeIstft.apply(Xd, window, n_fft, hop, int(length))
+        elif kernels.is_native(torch.view_as_real(self.stft_data)) and kernels.stft_native_supported(n_fft):
             edge = 2 if match_stride else 0   # the two frames per side the forward transform dropped
             x = kernels.istft(self.stft_data, window, n_fft, hop, int(length), lead=edge, trail=edge)
         else:

@@ -544,6 +544,30 @@ def test_mel_autograd_fused_backward(win, n_mels, T):
         assert rel_err(g_got, g_ref) < REL, use_X
 
 
+@pytest.mark.parametrize("win,hop,nfr,T", [(2048, 512, 40, 40 * 512 - 100), (512, 128, 60, 59 * 128), (1024, 512, 21, 10007),
+                                            (256, 32, 90, 89 * 32 + 5), (64, 4, 120, 470)])
+def test_istft_autograd_native(win, hop, nfr, T):
+    """Gradients through the native istft() (fused inverse kernel forward, forward-STFT kernel as its
+    adjoint) equal torch.istft's on CPU, for spectra that are NOT the STFT of a signal."""
+    g = torch.Generator().manual_seed(win + hop)
+    Xr = torch.randn(2, 2, win // 2 + 1, nfr, 2, generator=g)
+    wts = torch.randn(2, 2, T, generator=g)
+
+    def run(dev):
+        X = torch.view_as_complex(Xr.clone()).to(dev).requires_grad_(True)
+        s = A.AudioSignal(torch.zeros(2, 2, T), 44100).to(dev)
+        s.stft_data = X
+        y = s.istft(win, hop, "hann", False, length=T).audio_data
+        loss = (y * wts.to(dev)).sum() + (y ** 2).mean()
+        (gx,) = torch.autograd.grad(loss, X)
+        return y.detach(), gx
+
+    y_ref, g_ref = run("cpu")
+    y_got, g_got = run("cuda")
+    assert rel_err(y_got, y_ref) < REL
+    assert rel_err(torch.view_as_real(g_got), torch.view_as_real(g_ref)) < REL
+
+
 # ----------------------------------------------------------------------------- istft
 @pytest.mark.parametrize("win,hop,wt,ms", [(2048, 512, "hann", False), (2048, 512, "sqrt_hann", True),
                                            (512, 128, "sqrt_hann", False), (512, 128, "hann", True),
