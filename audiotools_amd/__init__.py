@@ -13,4 +13,4 @@ from . import util  # noqa: F401
 from .meter import Meter  # noqa: F401
 from .signal import AudioSignal, STFTParams  # noqa: F401
 from . import transforms  # noqa: F401,E402
-from . import core, data, metrics  # noqa: F401,E402
+from . import core, data, metrics, ml  # noqa: F401,E402

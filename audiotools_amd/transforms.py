@@ -365,6 +365,32 @@ class Equalizer(BaseTransform):
         return signal.equalizer(eq)
 
 
+class SpectralDenoising(Equalizer):
+    """Denoise with :class:`audiotools_amd.ml.layers.SpectralGate` against a random, equalised
+    white-noise clip normalised to ``nz_volume`` LUFS (transforms.py:1539-1592)."""
+
+    def __init__(self, eq_amount: tuple = ("const", 1.0), denoise_amount: tuple = ("uniform", 0.8, 1.0),
+                 nz_volume: float = -40, n_bands: int = 6, n_freq: int = 3, n_time: int = 5, name: str = None,
+                 prob: float = 1):
+        super().__init__(eq_amount=eq_amount, n_bands=n_bands, name=name, prob=prob)
+        from .ml.layers import SpectralGate
+
+        self.nz_volume = nz_volume
+        self.denoise_amount = denoise_amount
+        self.spectral_gate = SpectralGate(n_freq, n_time)
+
+    def _instantiate(self, state):
+        kwargs = super()._instantiate(state)
+        kwargs["denoise_amount"] = util.sample_from_dist(self.denoise_amount, state)
+        kwargs["nz"] = AudioSignal(state.randn(22050), 44100)
+        return kwargs
+
+    def _transform(self, signal, nz, eq, denoise_amount):
+        nz = nz.normalize(self.nz_volume).equalizer(eq)
+        self.spectral_gate = self.spectral_gate.to(signal.device)
+        return self.spectral_gate(signal, nz, denoise_amount)
+
+
 class NoiseFloor(BaseTransform):
     """Add white noise normalised to ``db`` LUFS (transforms.py:669-704)."""
 

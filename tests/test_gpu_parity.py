@@ -465,7 +465,7 @@ def test_c_abi_error_codes_and_degenerate_inputs():
 @pytest.mark.parametrize("name", ["ClippingDistortion", "Equalizer", "Quantization", "MuLawQuantization", "NoiseFloor",
                                   "VolumeChange", "VolumeNorm", "Silence", "LowPass", "HighPass", "RescaleAudio",
                                   "ShiftPhase", "InvertPhase", "FrequencyMask", "TimeMask", "MaskLowMagnitudes",
-                                  "Smoothing", "Identity"])
+                                  "Smoothing", "Identity", "SpectralDenoising"])
 def test_transforms_gpu_vs_cpu(name):
     """Every loader-free transform of data/transforms.py with the same instantiated parameters on
     the HIP path and on the CPU path (which tests/test_transforms.py pins seed-for-seed to the
@@ -477,7 +477,7 @@ def test_transforms_gpu_vs_cpu(name):
     kw = t.batch_instantiate([3, 4, 5, 6], sig)
     ref = t(sig.clone(), **kw).audio_data
     got = t(sig.clone().to("cuda"), **A.util.prepare_batch(kw, "cuda")).audio_data
-    if name == "MaskLowMagnitudes":   # threshold on a float32 log: allow isolated bin flips
+    if name in ("MaskLowMagnitudes", "SpectralDenoising"):   # threshold on a float32 log: allow isolated bin flips
         assert float(((got.cpu() - ref).abs() > 1e-3 * ref.abs().max()).float().mean()) < 1e-3
     else:
         assert rel_err(got, ref) < REL, name

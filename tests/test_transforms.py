@@ -11,7 +11,7 @@ from tests import synth
 
 NO_LOADER = ["ClippingDistortion", "Equalizer", "Quantization", "MuLawQuantization", "NoiseFloor", "VolumeChange",
              "VolumeNorm", "Silence", "LowPass", "HighPass", "RescaleAudio", "ShiftPhase", "InvertPhase",
-             "CorruptPhase", "FrequencyMask", "TimeMask", "MaskLowMagnitudes", "Smoothing", "Identity"]
+             "CorruptPhase", "FrequencyMask", "TimeMask", "MaskLowMagnitudes", "Smoothing", "Identity", "SpectralDenoising"]
 
 
 def _signal(mod, B=1, seed=5):
