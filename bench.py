@@ -107,9 +107,13 @@ def main():
     args = ap.parse_args()
 
     import audiotools_amd as A
-    from audiotools_amd import dist as adist
+    from audiotools_amd import _native, dist as adist
+
 
     rank, world, device = adist.init()
+    if int(os.environ.get("LOCAL_RANK", 0)) == 0:
+        _native.build()   # no-op when the in-tree library is up to date (it normally travels prebuilt)
+    adist.barrier()
     assert device.type == "cuda", "bench.py needs a GPU (the product has no CPU fallback)"
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)

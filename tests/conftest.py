@@ -30,6 +30,11 @@ def _build_oracle_c():
     from oracle import cport
 
     cport.build()
+    # the product library normally arrives prebuilt (driver build() / gpurun snapshot); a fresh
+    # checkout compiles it here once (hipcc cross-compiles gfx950 without a GPU)
+    from audiotools_amd import _native
+
+    _native.build()
     yield
 
 
