@@ -9,16 +9,19 @@
 //   at_spec_maxpow_f32 +
 //   at_spec_mask_lowmag_f32   dsp.py:308-334  mask_low_magnitudes (log_magnitude incl. the global
 //                                             top_db floor of audio_signal.py:1457-1487)
-// Unmasked elements are left untouched (the reference rewrites them as |X| e^{i angle X}, which
-// is X up to rounding).  Only the masked region is written.
+// Every kernel works out of place (src -> X: the reference returns a NEW stft_data, and reading src
+// while writing X costs one pass instead of clone + edit) or in place (src NULL or == X: only the
+// masked region is written).  Unmasked elements are copied / left untouched (the reference rewrites
+// them as |X| e^{i angle X}, which is X up to rounding).
 #include "at_common.h"
 
 namespace {
 
 // one wave per (row, frame); lanes stride over the bins
-__global__ __launch_bounds__(256) void spec_mask_kernel(float2* __restrict__ X, int64_t rows, int C, int N, int F, int axis,
-                                                        const double* __restrict__ lo, const double* __restrict__ hi,
-                                                        const float* __restrict__ grid, float2 fill) {
+__global__ __launch_bounds__(256) void spec_mask_kernel(const float2* __restrict__ S, float2* __restrict__ X, int64_t rows,
+                                                        int C, int N, int F, int axis, const double* __restrict__ lo,
+                                                        const double* __restrict__ hi, const float* __restrict__ grid,
+                                                        float2 fill) {
   const int lane = threadIdx.x & 63;
   const int64_t total = rows * N;
   for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += (int64_t)gridDim.x * 4) {
@@ -27,7 +30,15 @@ __global__ __launch_bounds__(256) void spec_mask_kernel(float2* __restrict__ X, 
     const int64_t b = row / C;
     const double l = lo[b], h = hi[b];
     float2* __restrict__ Xf = X + w * F;
-    if (axis == 1) {  // time: the whole frame or nothing
+    if (S) {  // out of place: every element is written (copied or filled)
+      const float2* __restrict__ Sf = S + w * F;
+      const bool whole = axis == 1 && l <= (double)grid[n] && (double)grid[n] < h;
+      for (int f = lane; f < F; f += 64) {
+        const double g = (double)grid[axis == 1 ? n : f];
+        const bool m = axis == 1 ? whole : (l <= g && g < h);
+        Xf[f] = m ? fill : Sf[f];
+      }
+    } else if (axis == 1) {  // in place, time: the whole frame or nothing
       const double g = (double)grid[n];
       if (!(l <= g && g < h)) continue;
       for (int f = lane; f < F; f += 64) Xf[f] = fill;
@@ -40,15 +51,17 @@ __global__ __launch_bounds__(256) void spec_mask_kernel(float2* __restrict__ X, 
   }
 }
 
-__global__ __launch_bounds__(256) void spec_phase_shift_kernel(float2* __restrict__ X, int64_t rows, int C,
-                                                               int64_t per_row, const float* __restrict__ shift) {
+__global__ __launch_bounds__(256) void spec_phase_shift_kernel(const float2* __restrict__ S, float2* __restrict__ X,
+                                                               int64_t rows, int C, int64_t per_row,
+                                                               const float* __restrict__ shift) {
   const int64_t row = blockIdx.y;
   const float sh = shift[row / C];
   float sn, cs;
   sincosf(sh, &sn, &cs);
   float2* __restrict__ Xr = X + row * per_row;
+  const float2* __restrict__ Sr = (S ? S : X) + row * per_row;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_row; i += (int64_t)gridDim.x * blockDim.x) {
-    const float2 v = Xr[i];
+    const float2 v = Sr[i];
     Xr[i] = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
   }
 }
@@ -66,7 +79,8 @@ __global__ __launch_bounds__(256) void spec_maxpow_kernel(const float2* __restri
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
-__global__ __launch_bounds__(256) void spec_mask_lowmag_kernel(float2* __restrict__ X, int64_t rows, int C, int64_t per_row,
+__global__ __launch_bounds__(256) void spec_mask_lowmag_kernel(const float2* __restrict__ S, float2* __restrict__ X, int64_t rows,
+                                                               int C, int64_t per_row,
                                                                const double* __restrict__ cutoff_db,
                                                                const unsigned* __restrict__ maxpow, float top_db,
                                                                int use_top_db, float val) {
@@ -76,8 +90,9 @@ __global__ __launch_bounds__(256) void spec_mask_lowmag_kernel(float2* __restric
   // log_spec.max() - top_db
   const float floor_db = 10.0f * log10f(fmaxf(__uint_as_float(*maxpow), amin2)) - top_db;
   float2* __restrict__ Xr = X + row * per_row;
+  const float2* __restrict__ Sr = (S ? S : X) + row * per_row;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_row; i += (int64_t)gridDim.x * blockDim.x) {
-    const float2 v = Xr[i];
+    const float2 v = Sr[i];
     const float mag = hypotf(v.x, v.y);
     float ls = 10.0f * log10f(fmaxf(mag * mag, amin2));
     if (use_top_db) ls = fmaxf(ls, floor_db);
@@ -85,6 +100,8 @@ __global__ __launch_bounds__(256) void spec_mask_lowmag_kernel(float2* __restric
       // magnitude := val, phase kept: val * e^{i angle(X)}  (angle(0) = 0)
       const float inv = mag > 0.f ? 1.0f / mag : 0.f;
       Xr[i] = mag > 0.f ? make_float2(val * v.x * inv, val * v.y * inv) : make_float2(val, 0.f);
+    } else if (S) {
+      Xr[i] = v;
     }
   }
 }
@@ -96,8 +113,8 @@ extern "C" {
 // X (B, C, N, F) complex64 interleaved, bin-contiguous.  axis 0: bins f with lo[b] <= grid[f] < hi[b]
 // (grid = linspace(0, sr/2, F) as float32); axis 1: frames n with lo[b] <= grid[n] < hi[b]
 // (grid = linspace(0, duration, N)).  Masked elements become fill = (re, im) = val * e^{i val}.
-int at_spec_mask_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, int axis, const double* lo, const double* hi,
-                     const float* grid, float fill_re, float fill_im, void* stream) {
+int at_spec_mask_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, int axis, const double* lo,
+                     const double* hi, const float* grid, float fill_re, float fill_im, void* stream) {
   if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!X || !lo || !hi || !grid || B < 0 || C <= 0 || N <= 0 || F <= 0 || (axis != 0 && axis != 1) || N >= (1LL << 31) ||
       F >= (1LL << 31))
@@ -107,14 +124,15 @@ int at_spec_mask_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, int a
   int64_t blocks = (waves + 3) / 4;
   if (blocks > 256 * 64) blocks = 256 * 64;
   hipLaunchKernelGGL(spec_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<float2*>(X), B * C, (int)C, (int)N, (int)F, axis, lo, hi, grid,
-                     make_float2(fill_re, fill_im));
+                     reinterpret_cast<const float2*>(src == X ? nullptr : src), reinterpret_cast<float2*>(X), B * C, (int)C, (int)N,
+                     (int)F, axis, lo, hi, grid, make_float2(fill_re, fill_im));
   AT_LAUNCH_CHECK();
   return AT_OK;
 }
 
 // X *= e^{i shift[b]}  (shift_phase with one value per item)
-int at_spec_phase_shift_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, const float* shift, void* stream) {
+int at_spec_phase_shift_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const float* shift,
+                            void* stream) {
   if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!X || !shift || B < 0 || C <= 0 || N <= 0 || F <= 0) return AT_ERR_INVALID;
   if (B == 0) return AT_OK;
@@ -123,7 +141,8 @@ int at_spec_phase_shift_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F
   int64_t bx = (per_row + 256 * 8 - 1) / (256 * 8);
   if (bx > 2048) bx = 2048;
   hipLaunchKernelGGL(spec_phase_shift_kernel, dim3((unsigned)bx, (unsigned)rows), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<float2*>(X), rows, (int)C, per_row, shift);
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(src == X ? nullptr : src),
+                     reinterpret_cast<float2*>(X), rows, (int)C, per_row, shift);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }
@@ -146,7 +165,7 @@ int at_spec_maxpow_f32(const float* X, int64_t n, float* out, void* stream) {
 // mask_low_magnitudes: elements whose log-magnitude (10 log10 max(|X|^2, 1e-10), floored at the
 // global maximum - top_db when use_top_db) is below cutoff_db[b] get magnitude `val`, phase kept.
 // maxpow: device float from at_spec_maxpow_f32 of the same tensor.
-int at_spec_mask_lowmag_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, const double* cutoff_db,
+int at_spec_mask_lowmag_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const double* cutoff_db,
                             const float* maxpow, float top_db, int use_top_db, float val, void* stream) {
   if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!X || !cutoff_db || !maxpow || B < 0 || C <= 0 || N <= 0 || F <= 0) return AT_ERR_INVALID;
@@ -156,8 +175,9 @@ int at_spec_mask_lowmag_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F
   int64_t bx = (per_row + 256 * 8 - 1) / (256 * 8);
   if (bx > 2048) bx = 2048;
   hipLaunchKernelGGL(spec_mask_lowmag_kernel, dim3((unsigned)bx, (unsigned)rows), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<float2*>(X), rows, (int)C, per_row, cutoff_db,
-                     reinterpret_cast<const unsigned*>(maxpow), top_db, use_top_db, val);
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(src == X ? nullptr : src),
+                     reinterpret_cast<float2*>(X), rows, (int)C, per_row, cutoff_db, reinterpret_cast<const unsigned*>(maxpow), top_db,
+                     use_top_db, val);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }

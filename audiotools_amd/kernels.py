@@ -332,16 +332,17 @@ def spec_native(X: torch.Tensor) -> bool:
             and not (X.requires_grad and torch.is_grad_enabled()) and X.transpose(2, 3).is_contiguous())
 
 
-def _spec_copy(X: torch.Tensor):
-    """Fresh (B, C, F, N) tensor with the same physical layout (the reference's edits return NEW
-    tensors; the old stft_data a caller may still hold must not change)."""
-    Y = X.transpose(2, 3).clone().transpose(2, 3)
-    B, C, F, N = Y.shape
-    return Y, torch.view_as_real(Y.transpose(2, 3)), B, C, N, F
+def _spec_out(X: torch.Tensor):
+    """(fresh result tensor of the same physical layout, its real view, the input's real view, sizes):
+    the reference's edits return NEW tensors (the old stft_data a caller may still hold must not
+    change), so the kernels read the input and write the result in one pass."""
+    B, C, F, N = X.shape
+    Y = torch.empty((B, C, N, F), dtype=X.dtype, device=X.device)
+    return Y.transpose(2, 3), torch.view_as_real(Y), torch.view_as_real(X.transpose(2, 3)), B, C, N, F
 
 
 def spec_mask(X: torch.Tensor, axis: int, lo: torch.Tensor, hi: torch.Tensor, grid: torch.Tensor, val: float):
-    Y, Yr, B, C, N, F = _spec_copy(X)
+    Y, Yr, Xr, B, C, N, F = _spec_out(X)
     lo = lo.reshape(-1).to(X.device, torch.float64).expand(B).contiguous()
     hi = hi.reshape(-1).to(X.device, torch.float64).expand(B).contiguous()
     grid = grid.to(X.device, torch.float32).contiguous()
@@ -349,7 +350,7 @@ def spec_mask(X: torch.Tensor, axis: int, lo: torch.Tensor, hi: torch.Tensor, gr
     v = float(val)
     # magnitude = phase = val, as float32 ops: val * exp(1j * val)
     fill = torch.tensor(v, dtype=torch.float32) * torch.exp(1j * torch.tensor(v, dtype=torch.float32))
-    code = _native.lib().at_spec_mask_f32(_native.ptr(Yr), B, C, N, F, axis, _native.ptr(lo), _native.ptr(hi),
+    code = _native.lib().at_spec_mask_f32(_native.ptr(Xr), _native.ptr(Yr), B, C, N, F, axis, _native.ptr(lo), _native.ptr(hi),
                                           _native.ptr(grid), float(fill.real), float(fill.imag),
                                           _native.current_stream(X.device))
     _native.check(code, "at_spec_mask_f32")
@@ -357,22 +358,22 @@ def spec_mask(X: torch.Tensor, axis: int, lo: torch.Tensor, hi: torch.Tensor, gr
 
 
 def spec_phase_shift(X: torch.Tensor, shift: torch.Tensor):
-    Y, Yr, B, C, N, F = _spec_copy(X)
+    Y, Yr, Xr, B, C, N, F = _spec_out(X)
     sh = shift.reshape(-1).to(X.device, torch.float32).expand(B).contiguous()
-    code = _native.lib().at_spec_phase_shift_f32(_native.ptr(Yr), B, C, N, F, _native.ptr(sh),
+    code = _native.lib().at_spec_phase_shift_f32(_native.ptr(Xr), _native.ptr(Yr), B, C, N, F, _native.ptr(sh),
                                                  _native.current_stream(X.device))
     _native.check(code, "at_spec_phase_shift_f32")
     return Y
 
 
 def spec_mask_lowmag(X: torch.Tensor, cutoff_db: torch.Tensor, val: float, top_db=80.0):
-    Y, Yr, B, C, N, F = _spec_copy(X)
+    Y, Yr, Xr, B, C, N, F = _spec_out(X)
     cut = cutoff_db.reshape(-1).to(X.device, torch.float64).expand(B).contiguous()
     mp = torch.empty(1, dtype=torch.float32, device=X.device)
     lib = _native.lib()
     st = _native.current_stream(X.device)
-    _native.check(lib.at_spec_maxpow_f32(_native.ptr(Yr), B * C * N * F, _native.ptr(mp), st), "at_spec_maxpow_f32")
-    code = lib.at_spec_mask_lowmag_f32(_native.ptr(Yr), B, C, N, F, _native.ptr(cut), _native.ptr(mp),
+    _native.check(lib.at_spec_maxpow_f32(_native.ptr(Xr), B * C * N * F, _native.ptr(mp), st), "at_spec_maxpow_f32")
+    code = lib.at_spec_mask_lowmag_f32(_native.ptr(Xr), _native.ptr(Yr), B, C, N, F, _native.ptr(cut), _native.ptr(mp),
                                        float(top_db if top_db is not None else 0.0), 0 if top_db is None else 1,
                                        float(val), st)
     _native.check(code, "at_spec_mask_lowmag_f32")

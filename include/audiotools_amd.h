@@ -163,18 +163,21 @@ int at_fir_fft_f32(const float* x, int64_t B, int64_t C, int64_t T, const float*
  * of  audiotools/core/dsp.py:217-306 (mask_frequencies / mask_timesteps),  :308-334
  * (mask_low_magnitudes, with log_magnitude of audio_signal.py:1457-1487 incl. its batch-global
  * top_db floor)  and  :336-352 (shift_phase with one value per item).
- *   X  (B, C, N, F) complex64 interleaved, bin-contiguous, edited IN PLACE; unmasked elements are
- *      not rewritten (the reference rewrites them as |X| e^{i angle X} = X up to rounding)
+ *   X  (B, C, N, F) complex64 interleaved, bin-contiguous: the result.  src: the input spectrum of
+ *      the same layout (out of place: one read + one write instead of clone + edit), or NULL / == X
+ *      for in place (only the masked region is written).  Unmasked elements are copied unchanged
+ *      (the reference rewrites them as |X| e^{i angle X} = X up to rounding)
  *   at_spec_mask_f32: axis 0 masks bins f with lo[b] <= grid[f] < hi[b]; axis 1 masks frames n with
  *      lo[b] <= grid[n] < hi[b]; lo/hi (B) float64, grid float32 (torch.linspace of the reference);
  *      masked elements := (fill_re, fill_im) = val e^{i val}
  *   at_spec_maxpow_f32: *out (device float) = max |X|^2;  at_spec_mask_lowmag_f32 consumes it
  */
-int at_spec_mask_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, int axis, const double* lo, const double* hi,
-                     const float* grid, float fill_re, float fill_im, void* stream);
-int at_spec_phase_shift_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, const float* shift, void* stream);
+int at_spec_mask_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, int axis, const double* lo,
+                     const double* hi, const float* grid, float fill_re, float fill_im, void* stream);
+int at_spec_phase_shift_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const float* shift,
+                            void* stream);
 int at_spec_maxpow_f32(const float* X, int64_t n, float* out, void* stream);
-int at_spec_mask_lowmag_f32(float* X, int64_t B, int64_t C, int64_t N, int64_t F, const double* cutoff_db,
+int at_spec_mask_lowmag_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const double* cutoff_db,
                             const float* maxpow, float top_db, int use_top_db, float val, void* stream);
 
 /* ---- row peaks and impulse-response preparation -----------------------------------------------
