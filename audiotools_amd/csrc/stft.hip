@@ -128,7 +128,9 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
   int2* s_uinfo = reinterpret_cast<int2*>(s_melw + A.n_units * MELW_ROW);
 
   // ---- block-shared tables -> LDS (once per persistent block)
-  for (int i = threadIdx.x; i < N; i += NW * 64) s_win[i] = A.window[i];
+  // the window is stored HALVED: the factor 1/2 of the split step (X = (Z + conj Z')/2 ...) is exact
+  // in binary floating point wherever it is applied, so it rides on the window multiply for free
+  for (int i = threadIdx.x; i < N; i += NW * 64) s_win[i] = 0.5f * A.window[i];
   for (int i = threadIdx.x; i < M / 2; i += NW * 64) s_twp[i] = A.tw[i];
   if constexpr (P::R2 > 1) {
     // row = j mod 16, column r: exp(-2 pi i r (j mod 16) / (16 R2))
@@ -303,8 +305,8 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
       const int k = t + L * q;
       float2 xa, xb;
       if (q == 0 && t == 0) {  // k == 0: DC (here) and Nyquist (kept as this lane's partner)
-        xa = make_float2(zk[0].x + zk[0].y, 0.f);
-        xb = make_float2(zk[0].x - zk[0].y, 0.f);
+        xa = make_float2(2.f * (zk[0].x + zk[0].y), 0.f);   // (Z is computed from the halved window)
+        xb = make_float2(2.f * (zk[0].x - zk[0].y), 0.f);
       } else {
         const float2 twp = s_twp[k];  // (cos, -sin)(2 pi k / N)
         const float sr = zk[q].x + zm[q].x, si = zk[q].y - zm[q].y;
@@ -312,8 +314,8 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
         const float c = twp.x, s = -twp.y;
         const float pp = fmaf(s, dr, -c * di);
         const float qq = fmaf(s, di, c * dr);
-        xa = make_float2(0.5f * (sr - pp), 0.5f * (si - qq));
-        xb = make_float2(0.5f * (sr + pp), 0.5f * (-si - qq));
+        xa = make_float2(sr - pp, si - qq);          // the 1/2 is in the window table
+        xb = make_float2(sr + pp, -si - qq);
       }
       if (STORE_OK(xa.x)) orow[k] = xa;
       if constexpr (MEL) magbuf[k + 4 * (k >> 4)] = cabs_fast(xa);
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
       if constexpr (MEL) magbuf[kb + 4 * (kb >> 4)] = cabs_fast(xbs[q]);
     }
     if (t == 0) {  // k == M/2: X = conj(Z[M/2])
-      const float2 xh = make_float2(zh.x, -zh.y);
+      const float2 xh = make_float2(2.f * zh.x, -2.f * zh.y);
       if (STORE_OK(xh.x)) orow[M / 2] = xh;
       if constexpr (MEL) magbuf[M / 2 + 4 * ((M / 2) >> 4)] = cabs_fast(xh);
     }
