@@ -13,7 +13,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libaudiotools_amd.so")
+LIB_PATH = os.environ.get("AT_LIB_PATH") or os.path.join(LIB_DIR, "libaudiotools_amd.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "firfft.hip", "irtools.hip", "specedit.hip", "fftconv.hip"]
 
@@ -25,27 +25,71 @@ class NativeError(RuntimeError):
     """Raised when the HIP library is unavailable or an entry point fails."""
 
 
-def hipcc_command(out=LIB_PATH):
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
+HEADERS = ["at_common.h", "fft_wave.h"]
+# per-source extra flags.  stft.hip: the SLP vectoriser turns the float2 butterflies into v_pk_*_f32,
+# which issue at half rate on gfx950 (no throughput gain) and cost ~110 v_mov per frame to build the
+# operand pairs (DESIGN.md 5.1); scalar code is shorter AND needs 30 fewer registers.
+FILE_FLAGS = {"stft.hip": ["-fno-slp-vectorize"]}
+LINK_FLAGS = ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
+
+
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def compile_command(src, obj):
     extra = os.environ.get("AT_HIPCC_FLAGS", "").split()
-    return ([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", out] + srcs
-            + ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"])
+    per_file = FILE_FLAGS.get(os.path.basename(src), [])
+    if os.environ.get("AT_STFT_SLP") == "1" and os.path.basename(src) == "stft.hip":
+        per_file = []
+    return [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + per_file + extra + ["-o", obj, src]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into ``lib/libaudiotools_amd.so``
-    (hipcc cross-compiles without a GPU)."""
-    os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES] + [os.path.join(CSRC_DIR, h) for h in ("at_common.h", "fft_wave.h")]
-    if not force and os.path.exists(LIB_PATH):
-        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-            return LIB_PATH
-    cmd = hipcc_command()
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB_PATH
+def link_command(objs, out=LIB_PATH):
+    return [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + list(objs) + LINK_FLAGS
+
+
+def hipcc_command(out=LIB_PATH):
+    """The build as shell commands (INTEGRATION.md quotes these)."""
+    objs = [os.path.join(LIB_DIR, "obj", s.replace(".hip", ".o")) for s in SOURCES]
+    cmds = [compile_command(os.path.join(CSRC_DIR, s), o) for s, o in zip(SOURCES, objs)]
+    return cmds + [link_command(objs, out)]
+
+
+def build(force: bool = False, verbose: bool = False, out: str = None) -> str:
+    """Compile every HIP source for gfx950 (one object per source, in parallel; hipcc cross-compiles
+    without a GPU) and link ``lib/libaudiotools_amd.so``."""
+    out = out or LIB_PATH
+    obj_dir = os.path.join(os.path.dirname(out), "obj" if out == LIB_PATH else "obj_" + os.path.basename(out))
+    os.makedirs(obj_dir, exist_ok=True)
+    hdrs = [os.path.join(CSRC_DIR, h) for h in HEADERS]
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    flag_stamp = os.path.join(obj_dir, "flags.txt")
+    flags_now = repr((os.environ.get("AT_HIPCC_FLAGS", ""), os.environ.get("AT_STFT_SLP", ""), FILE_FLAGS))
+    flags_same = os.path.exists(flag_stamp) and open(flag_stamp).read() == flags_now
+    jobs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC_DIR, s)
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        stale = (force or not flags_same or not os.path.exists(obj)
+                 or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time))
+        if stale:
+            cmd = compile_command(src, obj)
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    if jobs or not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(o) for o in objs):
+        cmd = link_command(objs, out)
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        with open(flag_stamp, "w") as f:
+            f.write(flags_now)
+    return out
 
 
 _i64, _i32, _p, _f32, _f64 = (ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <atomic>
+#include <mutex>
 
 #define AT_OK 0
 #define AT_ERR_INVALID (-1)      // bad argument
@@ -15,6 +18,62 @@
   } while (0)
 
 namespace at {
+
+constexpr int MAX_DEVICES = 64;
+
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize
+// raised once per (kernel, device).  Keyed by the kernel's host address and the CURRENT device, so
+// one process can drive several GPUs (a per-process flag made the second device's launch fail).
+inline int allow_big_lds(const void* fn) {
+  struct Entry { std::atomic<const void*> fn; std::atomic<uint64_t> devmask; };
+  static Entry table[256];
+  static std::atomic<int> count{0};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return AT_ERR_INVALID;
+  const uint64_t bit = 1ull << dev;
+  const int n = count.load(std::memory_order_acquire);
+  for (int i = 0; i < n; ++i)
+    if (table[i].fn.load(std::memory_order_relaxed) == fn)
+      if (table[i].devmask.load(std::memory_order_acquire) & bit) return AT_OK;
+  std::lock_guard<std::mutex> g(mu);
+  int slot = -1;
+  const int n2 = count.load(std::memory_order_relaxed);
+  for (int i = 0; i < n2; ++i)
+    if (table[i].fn.load(std::memory_order_relaxed) == fn) slot = i;
+  if (slot < 0) {
+    if (n2 >= 256) return AT_ERR_UNSUPPORTED;
+    slot = n2;
+    table[slot].fn.store(fn, std::memory_order_relaxed);
+    table[slot].devmask.store(0, std::memory_order_relaxed);
+    count.store(n2 + 1, std::memory_order_release);
+  }
+  if (!(table[slot].devmask.load(std::memory_order_relaxed) & bit)) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return AT_ERR_HIP(e);
+    table[slot].devmask.fetch_or(bit, std::memory_order_release);
+  }
+  return AT_OK;
+}
+
+// Compute units of the CURRENT device (cached per device; one process may drive several GPUs).
+inline int device_cu_count() {
+  static std::atomic<int> cached[MAX_DEVICES];
+  int dev = 0, cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 256;
+  const int c = cached[dev].load(std::memory_order_relaxed);
+  if (c > 0) return c;
+  if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return 256;
+  cached[dev].store(cu, std::memory_order_relaxed);
+  return cu;
+}
+
+// Development switches are environment variables read ONCE per process, never on the launch path:
+//   static const int v = at::env_int_once("AT_...", default);
+inline int env_int_once(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 
 // Wave-level rendezvous for LDS exchange between the lanes of ONE wave64.
 // DS operations of a wave execute in issue order; the fences stop the

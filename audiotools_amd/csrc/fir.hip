@@ -238,12 +238,9 @@ int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* wg, co
   A.xs_len = FT * old_sr + 2 * width + LG;
   const size_t lds = (size_t)((A.xs_len + 3) / 4 * 4) * 4;
   if (lds > 160 * 1024) return AT_ERR_UNSUPPORTED;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return AT_ERR_HIP(e);
-    attr_done = true;
+  {
+    int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_kernel));
+    if (e != AT_OK) return e;
   }
   const int64_t blocks = rows * A.tiles_per_row;
   if (blocks > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;

@@ -504,7 +504,8 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
       for (int e = 0; e < 4; ++e) P[e] = n[e];
     }
   }
-  { const char* e = getenv("AT_LUFS_DEBUG"); A.debug = e ? atoi(e) : 0; }
+  static const int dbg_mode = at::env_int_once("AT_LUFS_DEBUG", 0);
+  A.debug = dbg_mode;
   A.vec4 = ((T % 4) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0) ? 1 : 0;
   double* E = reinterpret_cast<double*>(workspace);
   int H;
@@ -524,12 +525,7 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
   // slots run two rounds for the work of 1.04 (B=64 took 2x its share of the B=512 time).
   int64_t seg;
   {
-    static const int n_cu = [] {
-      int dev = 0, cu = 0;
-      if (hipGetDevice(&dev) != hipSuccess) return 256;
-      if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return 256;
-      return cu;
-    }();
+    const int n_cu = at::device_cu_count();
     const int64_t slots = (int64_t)n_cu * 4 * AT_LUFS_WPS;
     int64_t best_s = 1;
     double best_cost = 1e300;
@@ -541,8 +537,8 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
       if (cost < best_cost * 0.999) { best_cost = cost; best_s = sp; }
     }
     seg = (H_data + best_s - 1) / best_s;
-    const char* e = getenv("AT_LUFS_WAVES");  // development override: target wave count
-    if (e && atoi(e) > 0) seg = (rows * H_data + atoi(e) - 1) / atoi(e);
+    static const int want_waves = at::env_int_once("AT_LUFS_WAVES", 0);  // development override: target wave count
+    if (want_waves > 0) seg = (rows * H_data + want_waves - 1) / want_waves;
   }
   if (seg < 1) seg = 1;
   if (seg > H_data) seg = H_data;

@@ -30,6 +30,7 @@
 #include "at_common.h"
 #include "fft_wave.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // build-time tuning knobs (see DESIGN.md "STFT kernel tuning")
 #ifndef AT_STFT_NW
@@ -455,15 +456,367 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
   }
 }
 
+
+// =============================================================================================
+// n_fft = 2048 / hop = 512 specialisation (the reference's default parameters at 44.1 kHz,
+// audio_signal.py:1066-1070): same algorithm as stft_mel_kernel<1024, ...> with three changes
+// aimed at the two busiest units of that kernel (LDS array ~55 %, VALU ~41 % of the launch):
+//  * PAIRED LAST PASS.  The final radix-4 pass gives every thread both members of each
+//    (k, M - k) pair: thread t runs butterflies t, 256 - t, 64 + t, 192 - t (thread 0: 0, 128, 64,
+//    192), so the real-FFT split step runs on registers -- no slab write of Z (16 ds_write_b64)
+//    and no re-read of Z[k], Z[M-k] (33 ds_read_b64, half of them 2-way bank conflicts).  The
+//    partner outputs X[M-k] descend with the lane; they are handed to lane (64 - t) mod 64 with
+//    one ds_bpermute per dword so that every store instruction writes 512 contiguous bytes with
+//    ascending lanes (tools/emulate_stft_v2.py is the lane-level model of this index algebra);
+//  * NO REGISTER SHUFFLING.  With hop = n_fft/4 consecutive frames share 12 of 16 sample
+//    registers.  The sample registers stay where they are and the frame PHASE (0..3) rotates the
+//    logical view (logical q lives in raw[(q + 4 phase) & 15]); the 4 new loads of the next frame
+//    land directly in the 4 registers the current frame consumed first (the generic kernel spends
+//    ~145 v_mov per frame on the shift);
+//  * window and pass-2 twiddles are read as ds_read_b128 rows (the stride-64 float2 reads were
+//    merged by the compiler into half-rate ds_read2st64_b64).
+template <int NR /* mel rounds of 64 units; 0 = no mel */>
+__global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
+  constexpr bool MEL = NR > 0;
+  constexpr int M = 1024, L = 64, N = 2048, NW = 4, SH = 4;
+  constexpr int WROW = 36;  // floats per window row (32 used): conflict-free ds_read_b128
+  constexpr int TROW = 20;  // floats per split-twiddle row (16 used): conflict-free ds_read_b128
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  float* s_winr = lds_f + NW * 2 * WAVE_LDS_SLOTS;                       // [64 threads][16 q] float2, halved
+  float* s_twp = s_winr + 64 * WROW;              // [64 t] rows of 20 floats: split twiddles, pair A r=0..3, pair B r=0..3
+  float* s_tw2 = s_twp + 64 * TROW;                // 16 rows x 36: pass-2 twiddles r = 1..15 of row (j mod 16)
+  float* s_melw = s_tw2 + 16 * 36;
+  int2* s_uinfo = reinterpret_cast<int2*>(s_melw + A.n_units * MELW_ROW);
+
+  for (int i = threadIdx.x; i < N; i += NW * 64) {
+    const int n2 = i >> 1;
+    s_winr[(n2 & 63) * WROW + 2 * (n2 >> 6) + (i & 1)] = 0.5f * A.window[i];
+  }
+  for (int i = threadIdx.x; i < 256; i += NW * 64) {
+    const int r = i >> 6, tt = i & 63;
+    // thread 0 of pair A runs the self-paired butterflies 0 and 128: its slots use k = 128, 256, 384
+    const int kA = tt == 0 ? (r < 3 ? 128 * (r + 1) : 0) : tt + 256 * r;
+    reinterpret_cast<float2*>(s_twp + tt * TROW)[r] = A.tw[kA];
+    reinterpret_cast<float2*>(s_twp + tt * TROW)[4 + r] = A.tw[64 + tt + 256 * r];
+  }
+  for (int i = threadIdx.x; i < 16 * 16; i += NW * 64) {
+    const int jj = i / 16, r = i % 16;   // column r - 1 holds w_256^(jj r); the last column is padding
+    reinterpret_cast<float2*>(s_tw2 + jj * 36)[(r + 15) & 15] = r == 0 ? make_float2(0.f, 0.f) : A.tw[r * jj * (N / 256)];
+  }
+  if constexpr (MEL) {
+    for (int i = threadIdx.x; i < A.n_units * 16; i += NW * 64)
+      s_melw[(i >> 4) * MELW_ROW + (i & 15)] = A.unit_w[i];
+    for (int i = threadIdx.x; i < A.n_units; i += NW * 64) {
+      const int info = A.unit_info[2 * i], fl = A.unit_info[2 * i + 1];
+      s_uinfo[i] = make_int2((info & 0xffff) * MAG_ROW, (fl & 0xff) | (((info >> 16) & 0xffff) << 8));
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t = lane;
+  const bool t0 = t == 0;
+  float2* fbuf = reinterpret_cast<float2*>(lds_f) + wave * WAVE_LDS_SLOTS;
+  float* magbuf = reinterpret_cast<float*>(fbuf);
+
+  // butterflies of the paired last pass and their base twiddles w_1024^j
+  const int jb[4] = {t, t0 ? 128 : 256 - t, 64 + t, 192 - t};
+  int pj[4];
+  float2 twb[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    pj[b] = phys<L, true>(jb[b]);
+    twb[b] = A.tw[2 * jb[b]];
+  }
+  const int src_lane4 = ((64 - lane) & 63) << 2;   // ds_bpermute byte index of the partner lane
+
+  const int Ti = (int)A.T;
+  const int n_out = (int)A.n_out;
+  const int gpr = A.groups_per_row;
+  const int n_x = gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int xcd = blockIdx.x % n_x;
+  const int lblk = blockIdx.x / n_x;
+  const int nblk_x = ((int)gridDim.x - xcd + n_x - 1) / n_x;
+  const int64_t g_lo = A.total_groups * xcd / n_x;
+  const int64_t g_hi = A.total_groups * (xcd + 1) / n_x;
+  const int RUN = A.run;
+  const int64_t Wtot = (int64_t)nblk_x * NW;
+  const int64_t w0 = g_lo + ((int64_t)lblk * NW + wave) * RUN;
+
+  float2 raw[16];   // un-windowed samples; logical q of a phase-p frame is raw[(q + 4 p) & 15]
+  float2 nxt[SH];   // the 4 new loads of the NEXT frame, issued ahead of this frame's stores
+
+  auto split = [&](float2 zk, float2 zm, float2 twp, float2& xa, float2& xb) __attribute__((always_inline)) {
+    const float sr = zk.x + zm.x, si = zk.y - zm.y;
+    const float dr = zk.x - zm.x, di = zk.y + zm.y;
+    const float c = twp.x, s = -twp.y;
+    const float pp = fmaf(s, dr, -c * di);
+    const float qq = fmaf(s, di, c * dr);
+    xa = make_float2(sr - pp, si - qq);      // X[k]      (the 1/2 is in the window table)
+    xb = make_float2(sr + pp, -si - qq);     // X[M - k]
+  };
+  auto to_partner = [&](float2 v) __attribute__((always_inline)) -> float2 {
+    return make_float2(
+        __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane4, __builtin_bit_cast(int, v.x))),
+        __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane4, __builtin_bit_cast(int, v.y))));
+  };
+
+  // one frame of phase p.  Returns true when the 4 new loads of the next frame were issued.
+  auto frame_body = [&](auto phase_c, auto steady_c, const float* __restrict__ xr, int64_t row, int fo, int64_t s0,
+                        bool want_next) __attribute__((always_inline)) -> bool {
+    constexpr int P = decltype(phase_c)::value;
+    if constexpr (decltype(steady_c)::value) {
+      // the 4 samples loaded during the previous frame become logical q = 12..15 of this one
+#pragma unroll
+      for (int i = 0; i < SH; ++i) raw[(12 + i + 4 * P) & 15] = nxt[i];
+    }
+    float2 a[16];
+    {
+      const float4* wr = reinterpret_cast<const float4*>(s_winr + t * WROW);
+      float4 w4[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w4[i] = wr[i];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float2 r_ = raw[(q + 4 * P) & 15];
+        const float4 w_ = w4[q >> 1];
+        a[q] = (q & 1) ? make_float2(r_.x * w_.z, r_.y * w_.w) : make_float2(r_.x * w_.x, r_.y * w_.y);
+      }
+    }
+    // ---- passes 1 and 2 (radix 16, 16) through the slab
+    pass_compute_store<16, 1, L, true>(a, fbuf, t, nullptr);
+    wave_sync();
+    load_points<L, true>(a, fbuf, t);
+    wave_sync();
+    {
+      float2 tw2[16];
+      const float4* rp = reinterpret_cast<const float4*>(s_tw2 + (t & 15) * 36);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 v = rp[i];
+        tw2[2 * i + 1] = make_float2(v.x, v.y);
+        if (i < 7) tw2[2 * i + 2] = make_float2(v.z, v.w);
+      }
+      pass_compute_store<16, 16, L, true>(a, fbuf, t, tw2);
+    }
+    wave_sync();
+    // ---- pass 3 (radix 4), paired butterflies, results stay in registers
+    float2 Z[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Z[b][r] = fbuf[pj[b] + 257 * r];
+    wave_sync();   // slab free: it is reused for |X| below
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float2 w1 = twb[b], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+      Z[b][1] = cmul(Z[b][1], w1);
+      Z[b][2] = cmul(Z[b][2], w2);
+      Z[b][3] = cmul(Z[b][3], w3);
+      dft4(Z[b][0], Z[b][1], Z[b][2], Z[b][3]);
+    }
+
+    // ---- next frame's 4 new loads, BEFORE this frame's stores (vmcnt retires in order)
+    // Issued UNCONDITIONALLY (from the row start when there is no next interior frame; T >= N is
+    // a launch condition): a conditional load leaves a phi on nxt[] that the register allocator
+    // resolves with copies right behind the loads, i.e. with a wait for HBM in the middle of
+    // the frame.
+    const int64_t s0n = s0 + A.hop;
+    const bool have_nxt = want_next && fo + 1 < gpr && s0n >= 0 && s0n + N <= Ti;
+    {
+      const float2* __restrict__ p2 = reinterpret_cast<const float2*>(xr + (have_nxt ? s0n : 0)) + t + L * (16 - SH);
+#pragma unroll
+      for (int i = 0; i < SH; ++i) nxt[i] = p2[L * i];
+    }
+
+    // ---- split step on registers
+    float2 xaA[4], xbA[4], xaB[4], xbB[4];
+    float2 twp[8];
+    {
+      const float4* tp = reinterpret_cast<const float4*>(s_twp + t * TROW);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = tp[i];
+        twp[2 * i] = make_float2(v.x, v.y);
+        twp[2 * i + 1] = make_float2(v.z, v.w);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float2 zk = Z[0][r], zm = Z[1][3 - r];
+      if (r == 0) zk = t0 ? Z[1][0] : zk;                 // thread 0: (Z[128], Z[896])
+      if (r == 1) zm = t0 ? Z[0][3] : zm;                 // thread 0: (Z[256], Z[768])
+      if (r == 2) { zk = t0 ? Z[1][1] : zk; zm = t0 ? Z[1][2] : zm; }   // thread 0: (Z[384], Z[640])
+      split(zk, zm, twp[r], xaA[r], xbA[r]);
+      split(Z[2][r], Z[3][3 - r], twp[4 + r], xaB[r], xbB[r]);
+    }
+    const float2 z00 = Z[0][0], z02 = Z[0][2];
+    const float2 dc = make_float2(2.f * (z00.x + z00.y), 0.f);
+    const float2 nyq = make_float2(2.f * (z00.x - z00.y), 0.f);
+    const float2 x512 = make_float2(2.f * z02.x, -2.f * z02.y);
+    float2 ascA[4];
+    ascA[0] = t0 ? dc : xaA[0];
+    ascA[1] = xaA[1];
+    ascA[2] = t0 ? x512 : xaA[2];
+    ascA[3] = t0 ? xbA[1] : xaA[3];
+    const float2 t0B[4] = {xaA[0], xaA[2], xbA[2], xbA[0]};   // thread 0: X[128], X[384], X[640], X[896]
+    float2 rcA[4], rcB[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      rcA[m] = to_partner(t0 ? xbB[3 - m] : xbA[3 - m]);      // bins 256 m + 192 + lane
+      rcB[m] = to_partner(t0 ? t0B[m] : xbB[3 - m]);          // bins 256 m + 128 + lane
+    }
+    float2* __restrict__ orow = A.out + ((int64_t)row * n_out + fo) * (M + 1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int k0 = 256 * m + t;
+      orow[k0] = ascA[m];
+      orow[k0 + 64] = xaB[m];
+      orow[k0 + 128] = rcB[m];
+      orow[k0 + 192] = rcA[m];
+      if constexpr (MEL) {
+        magbuf[k0 + 4 * (k0 >> 4)] = cabs_fast(ascA[m]);
+        magbuf[k0 + 64 + 4 * ((k0 + 64) >> 4)] = cabs_fast(xaB[m]);
+        magbuf[k0 + 128 + 4 * ((k0 + 128) >> 4)] = cabs_fast(rcB[m]);
+        magbuf[k0 + 192 + 4 * ((k0 + 192) >> 4)] = cabs_fast(rcA[m]);
+      }
+    }
+    if (t0) {
+      orow[M] = nyq;
+      if constexpr (MEL) magbuf[M + 4 * (M >> 4)] = fabsf(nyq.x);
+    }
+    if constexpr (MEL) {
+      // the last magnitude row holds only the Nyquist bin: zero its other 15 columns (see the
+      // generic kernel)
+      if (t >= 1 && t < 16) magbuf[(M / 16) * MAG_ROW + t] = 0.f;
+      wave_sync();
+      float* mrow = A.mel + ((int64_t)row * n_out + fo) * A.n_mels;
+#pragma unroll
+      for (int r0 = 0; r0 < NR; r0 += 2) {
+        float acc[2];
+        int u_fl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int r = r0 + j;
+          const int2 ui = s_uinfo[r * 64 + lane];
+          u_fl[j] = ui.y;
+          const float4* mq = reinterpret_cast<const float4*>(magbuf + ui.x);
+          const float4* wq = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW);
+          float v = 0.f;
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4) {
+            const float4 w = wq[i4];
+            const float4 m = mq[i4];
+            v = fmaf(w.x, m.x, v);
+            v = fmaf(w.y, m.y, v);
+            v = fmaf(w.z, m.z, v);
+            v = fmaf(w.w, m.w, v);
+          }
+          acc[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float sh;
+          sh = dpp_row_shl<1>(acc[j]); acc[j] += (u_fl[j] & 1) ? sh : 0.f;
+          sh = dpp_row_shl<2>(acc[j]); acc[j] += (u_fl[j] & 2) ? sh : 0.f;
+          sh = dpp_row_shl<4>(acc[j]); acc[j] += (u_fl[j] & 4) ? sh : 0.f;
+          sh = dpp_row_shl<8>(acc[j]); acc[j] += (u_fl[j] & 8) ? sh : 0.f;
+          if (u_fl[j] & 16) mrow[u_fl[j] >> 8] = acc[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wave_sync();
+    }
+    return have_nxt;
+  };
+
+  for (int64_t gbase = w0; gbase < g_hi; gbase += Wtot * RUN) {
+    const int64_t g_end = min(gbase + RUN, g_hi);
+    int64_t g = gbase;
+    while (g < g_end) {
+      // ---- first frame of a stretch: all 16 loads (or the edge path), phase 0
+      const int64_t row = g / gpr;
+      int fo = (int)(g - row * gpr);
+      const float* __restrict__ xr = A.x + row * A.T;
+      int64_t s0 = ((int64_t)fo + A.frame_lo) * A.hop - M;
+      if (s0 >= 0 && s0 + N <= Ti) {   // wave-uniform
+        const float2* __restrict__ p2 = reinterpret_cast<const float2*>(xr + s0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) raw[q] = p2[t + L * q];
+      } else {
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) {
+          const int n = t + L * q;
+          fbuf[n] = make_float2(fetch_padded(xr, s0 + 2 * n, A.T, A.T2, 0, A.pad_mode),
+                                fetch_padded(xr, s0 + 2 * n + 1, A.T, A.T2, 0, A.pad_mode));
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) raw[q] = fbuf[t + L * q];
+        wave_sync();
+      }
+      bool more = frame_body(std::integral_constant<int, 0>{}, std::false_type{}, xr, row, fo, s0, g + 1 < g_end);
+      ++g;
+      // steady state: "4 loads, then the stores of one frame" in flight on every path; the phase
+      // (which 4 sample registers are the newest) is a compile-time constant of each copy
+      while (more) {
+#define AT_NEXT(P)                                                                                   \
+  ++fo; s0 += A.hop;                                                                                 \
+  more = frame_body(std::integral_constant<int, P>{}, std::true_type{}, xr, row, fo, s0, g + 1 < g_end);               \
+  ++g;
+        AT_NEXT(1) if (!more) break;
+        AT_NEXT(2) if (!more) break;
+        AT_NEXT(3) if (!more) break;
+        AT_NEXT(0)
+#undef AT_NEXT
+      }
+    }
+  }
+}
+
+constexpr size_t v2_lds_floats(int n_units) {
+  return (size_t)4 * 2 * WAVE_LDS_SLOTS + 64 * 36 + 64 * 20 + 16 * 36 + (size_t)n_units * (MELW_ROW + 2);
+}
+
+// Run-length balancing shared by both kernels: every wave of an XCD span gets the same number of
+// whole runs (see launch_one).
+static int balanced_run(int64_t total_groups, int64_t blocks, int nw) {
+  const int64_t n_x = blocks < 8 ? blocks : 8;
+  const int64_t waves_x = (blocks / n_x) * nw;
+  const int64_t span = (total_groups + n_x - 1) / n_x;
+  const int64_t per_wave = (span + waves_x - 1) / (waves_x > 0 ? waves_x : 1);
+  const int64_t runs = (per_wave + AT_STFT_RUN - 1) / AT_STFT_RUN;
+  int64_t run = (per_wave + runs - 1) / (runs > 0 ? runs : 1);
+  if (run < 1) run = 1;
+  if (run > AT_STFT_RUN) run = AT_STFT_RUN;
+  return (int)run;
+}
+
+template <int NR>
+int launch_v2(const StftArgs& A, int n_cu, hipStream_t stream) {
+  auto kern = stft_mel_kernel_v2<NR>;
+  const size_t bytes = v2_lds_floats(A.n_units) * 4;
+  if (bytes > 160 * 1024) return AT_ERR_UNSUPPORTED;
+  int e = at::allow_big_lds(reinterpret_cast<const void*>(kern));
+  if (e != AT_OK) return e;
+  int per_cu = (int)((160 * 1024) / bytes);
+  if (per_cu > 2) per_cu = 2;   // 2 waves per SIMD (launch bounds)
+  int64_t blocks = (A.total_groups + 3) / 4;
+  if (blocks > (int64_t)n_cu * per_cu) blocks = (int64_t)n_cu * per_cu;
+  StftArgs B = A;
+  B.run = balanced_run(A.total_groups, blocks, 4);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), bytes, stream, B);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
 template <int M, int NW, bool VEC2, int NR>
 int launch_one(const StftArgs& A, size_t lds_bytes, int max_blocks, hipStream_t stream) {
   auto kern = stft_mel_kernel<M, NW, VEC2, NR>;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return AT_ERR_HIP(e);
-    attr_done = true;
+  {
+    int e = at::allow_big_lds(reinterpret_cast<const void*>(kern));
+    if (e != AT_OK) return e;
   }
   int64_t blocks = (A.total_groups + NW - 1) / NW;
   if (blocks > max_blocks) blocks = max_blocks;
@@ -471,17 +824,7 @@ int launch_one(const StftArgs& A, size_t lds_bytes, int max_blocks, hipStream_t 
   // run of 16 a small batch (54 frame groups per wave at B=64) leaves some waves with 4 runs and
   // others with 3 -- the launch then lasts 64/54 of its balanced time.
   StftArgs B = A;
-  {
-    const int64_t n_x = blocks < 8 ? blocks : 8;
-    const int64_t waves_x = (blocks / n_x) * NW;                       // waves per XCD span
-    const int64_t span = (A.total_groups + n_x - 1) / n_x;
-    const int64_t per_wave = (span + waves_x - 1) / (waves_x > 0 ? waves_x : 1);
-    const int64_t runs = (per_wave + AT_STFT_RUN - 1) / AT_STFT_RUN;
-    int64_t run = (per_wave + runs - 1) / (runs > 0 ? runs : 1);
-    if (run < 1) run = 1;
-    if (run > AT_STFT_RUN) run = AT_STFT_RUN;
-    B.run = (int)run;
-  }
+  B.run = balanced_run(A.total_groups, blocks, NW);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, stream, B);
   AT_LAUNCH_CHECK();
   return AT_OK;
@@ -515,15 +858,8 @@ int launch_m(const StftArgs& A, bool vec2, int n_cu, hipStream_t stream) {
 
 }  // namespace
 
-static int device_cu_count() {
-  static int n = [] {
-    int dev = 0, cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return 256;
-    return cu;
-  }();
-  return n;
-}
+using at::device_cu_count;
+using at::env_int_once;
 
 extern "C" {
 
@@ -631,12 +967,24 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   A.T2 = T2; A.pad_mode = pad_mode; A.n_units = mel ? n_units : 0; A.n_mels = n_mels;
   A.groups_per_row = (int)((n_frames_out + FW - 1) / FW);
   A.total_groups = rows * A.groups_per_row;
-  { const char* e = getenv("AT_STFT_DEBUG"); A.debug = e ? atoi(e) : 0; }
+  static const int dbg_mode = AT_STFT_DEBUGMODES ? env_int_once("AT_STFT_DEBUG", 0) : 0;
+  static const int allow_reuse = env_int_once("AT_STFT_REUSE", 1);
+  static const int use_v2 = env_int_once("AT_STFT_V2", 1);
+  A.debug = dbg_mode;
   A.reuse_shift = (FW == 1 && hop % (2 * (M / 16)) == 0 && pad == 0) ? hop / (2 * (M / 16)) : 0;
-  { const char* e = getenv("AT_STFT_REUSE"); if (e && atoi(e) == 0) A.reuse_shift = 0; }
+  if (!allow_reuse) A.reuse_shift = 0;
   const bool vec2 = ((T % 2) == 0 && (hop % 2) == 0 && (M % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 8) == 0);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int n_cu = device_cu_count();
+  if (use_v2 && M == 1024 && vec2 && A.reuse_shift == 4 && A.debug == 0 && T >= 2 * 2048) {
+    // the reference's default transform at 44.1 / 48 kHz: n_fft 2048, hop 512, no match_stride
+    switch (A.n_units / 64) {
+      case 0: return launch_v2<0>(A, n_cu, s);
+      case 2: return launch_v2<2>(A, n_cu, s);
+      case 4: return launch_v2<4>(A, n_cu, s);
+      case 6: return launch_v2<6>(A, n_cu, s);
+    }
+  }
   switch (M) {
     case 16: return launch_m<16>(A, vec2, n_cu, s);
     case 32: return launch_m<32>(A, vec2, n_cu, s);
