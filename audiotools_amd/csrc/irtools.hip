@@ -19,10 +19,16 @@ struct MaxIdx {
   int64_t i;
 };
 
-// first-occurrence arg-max: larger value wins, ties go to the smaller index (torch semantics)
+// first-occurrence arg-max: larger value wins, ties go to the smaller index, NaN beats every
+// number (torch semantics: abs().max() / argmax() propagate NaN and report the first one)
 __device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {
+  const bool an = a.v != a.v, bn = b.v != b.v;
+  if (an || bn) return (bn && (!an || b.i < a.i)) ? b : a;
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
+// per-thread running maximum in index order: `cand` replaces the current best when it is larger or
+// is the first NaN (a NaN best is sticky: every comparison with it is false)
+__device__ __forceinline__ bool takes_over(float cand, float best) { return !(cand <= best) && best == best; }
 
 __device__ __forceinline__ MaxIdx block_argmax(MaxIdx m, MaxIdx* sh) {
 #pragma unroll
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(RT) void absmax_kernel(const float* __restrict__ x,
         const float a[4] = {fabsf(v[k].x), fabsf(v[k].y), fabsf(v[k].z), fabsf(v[k].w)};
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (a[u] > m.v) { m.v = a[u]; m.i = 4 * (i + k * RT) + u; }
+          if (takes_over(a[u], m.v)) { m.v = a[u]; m.i = 4 * (i + k * RT) + u; }
       }
     }
     for (; i < T4; i += RT) {
@@ -91,11 +97,11 @@ __global__ __launch_bounds__(RT) void absmax_kernel(const float* __restrict__ x,
       const float a[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (a[u] > m.v) { m.v = a[u]; m.i = 4 * i + u; }
+        if (takes_over(a[u], m.v)) { m.v = a[u]; m.i = 4 * i + u; }
     }
     for (int64_t j = 4 * T4 + threadIdx.x; j < T; j += RT) {
       const float a = fabsf(xr[j]);
-      if (a > m.v) { m.v = a; m.i = j; }
+      if (takes_over(a, m.v)) { m.v = a; m.i = j; }
     }
     m = block_argmax(m, sh);
     if (threadIdx.x == 0) {

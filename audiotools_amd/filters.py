@@ -56,7 +56,7 @@ def resample_torch(audio: torch.Tensor, old_sr: int, new_sr: int) -> torch.Tenso
 def _per_item_native(X, *params) -> bool:
     """The in-place stft_data kernels apply: native spectrum and every parameter is a scalar or
     has one value per item (shape (), (1,), (B,), (B,1,1,1))."""
-    if not (kernels.spec_native(X) and kernels.have("at_spec_mask_f32")):
+    if not (kernels.spec_native(X)):
         return False
     B = X.shape[0]
     for p in params:
@@ -78,7 +78,7 @@ class DSPMixin:
         if sample_rate == self.sample_rate:
             return self
         audio = self.audio_data
-        if kernels.is_native(audio) and kernels.have("at_resample_f32"):
+        if kernels.is_native(audio) and kernels.resample_supported(self.sample_rate, int(sample_rate)):
             self.audio_data = kernels.resample(audio, self.sample_rate, int(sample_rate))
         else:
             self.audio_data = resample_torch(audio, self.sample_rate, int(sample_rate))
@@ -136,7 +136,7 @@ class DSPMixin:
         cutoffs = util.ensure_tensor(cutoffs, 2, self.batch_size)
         cutoffs = cutoffs / self.sample_rate
         audio = self.audio_data
-        if kernels.is_native(audio) and kernels.have("at_fir_per_item_f32"):
+        if kernels.is_native(audio):
             filtered = kernels.sinc_filter(audio, cutoffs, zeros, highpass)
         else:
             filtered = lowpass_torch(audio, cutoffs, zeros, highpass)

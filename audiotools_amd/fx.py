@@ -35,9 +35,15 @@ def _roll_to_peak(ir: torch.Tensor) -> torch.Tensor:
 
 def _peak(x: torch.Tensor) -> torch.Tensor:
     """max |x| over time, keepdim -- one fused pass on the HIP path."""
-    if kernels.is_native(x) and kernels.have("at_absmax_f32"):
+    if kernels.is_native(x):
         return kernels.absmax(x)[..., None]
     return x.abs().max(dim=-1, keepdim=True).values
+
+
+def _conv_shapes_ok(x: torch.Tensor, ir: torch.Tensor) -> bool:
+    """Shapes the native circular convolution covers: IR batch B or 1; IR channels 1, C, or any
+    count on a mono signal (the broadcasting cases of effects.py:106-111)."""
+    return ir.shape[0] in (1, x.shape[0]) and (ir.shape[1] in (1, x.shape[1]) or x.shape[1] == 1)
 
 
 def fftconv_torch(x: torch.Tensor, ir: torch.Tensor) -> torch.Tensor:
@@ -103,7 +109,7 @@ class EffectMixin:
             other.truncate_samples(self.signal_length)
         ir = other.audio_data
         x = self.audio_data
-        if kernels.is_native(x) and kernels.is_native(ir) and kernels.have("at_fftconv_circ_f32"):
+        if kernels.is_native(x) and kernels.is_native(ir) and _conv_shapes_ok(x, ir):
             # one pass for the peak value + position, one for the rotation (instead of abs, argmax,
             # arange, mod, gather, abs, max over (B, C, T) tensors)
             peak, idx = kernels.absmax(ir, want_index=True)
@@ -112,6 +118,13 @@ class EffectMixin:
                     raise RuntimeError("start_at_max requires a single-channel impulse response")
                 ir = kernels.roll_pad(ir, idx, ir.shape[-1])
             scale = 1 / peak[..., None].clamp(1e-5)
+            # the reference broadcasts rfft(ir) * rfft(x): one IR for the whole batch, or a
+            # multi-channel IR on a mono signal (effects.py:106-111)
+            B, C = x.shape[0], x.shape[1]
+            if ir.shape[0] != B:
+                ir, scale = ir.expand(B, -1, -1), scale.expand(B, -1, -1)
+            if ir.shape[1] not in (1, C):
+                x = x.expand(-1, ir.shape[1], -1)
             y = kernels.fftconv(x, ir, scale)
         else:
             if start_at_max:
@@ -203,7 +216,7 @@ class EffectMixin:
             db = db.unsqueeze(0)
         weights = (10 ** db).float()
         audio = self.audio_data
-        if kernels.is_native(audio) and kernels.have("at_fir_per_item_f32"):
+        if kernels.is_native(audio):
             taps, half = equalizer_taps(self.sample_rate, weights.expand(self.batch_size, n_bands), audio.device)
             self.audio_data = kernels.fir_per_item(audio, taps, replicate=True)
         else:
@@ -280,7 +293,7 @@ class ImpulseResponseMixin:
     def alter_drr(self, drr: typing.Union[torch.Tensor, np.ndarray, float]):
         drr = util.ensure_tensor(drr, 2, self.batch_size).to(self.device)
         x = self.audio_data
-        if kernels.is_native(x) and kernels.have("at_alter_drr_f32") and drr.shape[-1] == 1:
+        if kernels.is_native(x) and drr.shape[-1] == 1:
             # decompose + solve_alpha + recombination + ensure_max_of_audio in one kernel
             self.audio_data = kernels.alter_drr(x, int(self.sample_rate * 0.0025), drr[:, 0])
             return self

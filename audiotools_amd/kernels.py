@@ -90,17 +90,39 @@ _nola_cache = {}
 
 
 def _nola_ok(window: torch.Tensor, n_fft: int, hop: int) -> bool:
-    key = (window.data_ptr(), n_fft, hop)
-    if key not in _nola_cache:
-        w2 = window.detach().float().cpu().numpy().astype("float64") ** 2
-        reps = -(-n_fft // hop)
+    """torch.istft's NOLA check, cached per window CONTENT (a data_ptr key goes stale when the
+    allocator reuses the address for another window)."""
+    w = window.detach().to("cpu", torch.float64).contiguous()
+    key = (w.numpy().tobytes(), n_fft, hop)
+    ok = _nola_cache.get(key)
+    if ok is None:
         import numpy as np
+        w2 = w.numpy() ** 2
+        reps = -(-n_fft // hop)
         env = np.zeros(hop)
         for j in range(reps):
             seg = w2[j * hop: (j + 1) * hop]
             env[: len(seg)] += seg
-        _nola_cache[key] = bool(env.min() > 1e-11)
-    return _nola_cache[key]
+        ok = _nola_cache[key] = bool(env.min() > 1e-11)
+    return ok
+
+
+_nola_by_tensor = {}
+
+
+def _nola_ok_cached(window: torch.Tensor, n_fft: int, hop: int) -> bool:
+    """Per-tensor memo in front of the content check: valid while the SAME tensor object is alive
+    and unmodified (`_version`), so the steady state costs no device-to-host copy."""
+    key = (id(window), window._version, n_fft, hop)
+    hit = _nola_by_tensor.get(key)
+    if hit is not None and hit[0]() is window:
+        return hit[1]
+    import weakref
+    ok = _nola_ok(window, n_fft, hop)
+    if len(_nola_by_tensor) > 256:
+        _nola_by_tensor.clear()
+    _nola_by_tensor[key] = (weakref.ref(window), ok)
+    return ok
 
 
 def istft_fused_supported(n_fft: int, hop: int) -> bool:
@@ -123,7 +145,7 @@ def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, l
     X = stft_bcfn.transpose(2, 3).contiguous()
     dev = X.device
     # torch.istft refuses windows whose overlap-add envelope vanishes (NOLA)
-    if not _nola_ok(window, n_fft, hop):
+    if not _nola_ok_cached(window, n_fft, hop):
         raise RuntimeError("istft: window overlap add min is (nearly) zero -- the STFT is not invertible")
     lib = _native.lib()
     n_frames = lead + N + trail
@@ -165,7 +187,7 @@ def stft_adjoint(grad_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop:
 
 
 def stft_mel_adjoint_supported(n_fft: int, hop: int, n_mels: int) -> bool:
-    return 64 <= n_fft <= 2048 and hop * 4 == n_fft and n_mels <= 8 * (n_fft // 32) and have("at_stft_mel_adjoint_f32")
+    return 64 <= n_fft <= 2048 and hop * 4 == n_fft and n_mels <= 8 * (n_fft // 32)
 
 
 def _fold_reflect(out: torch.Tensor, T: int, half: int) -> torch.Tensor:
@@ -245,7 +267,9 @@ _ws_cache = {}
 
 
 def _workspace(nbytes: int, device):
-    key = (device.type, device.index)
+    """Scratch buffer cached per (device, stream): kernels on different streams never share one
+    (a single per-device buffer raced when two streams measured loudness concurrently)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -282,7 +306,8 @@ def integrated_loudness(audio_bct: torch.Tensor, rate: int, filter_class: str = 
 
 
 def have(symbol: str) -> bool:
-    """True when the loaded library exports ``symbol`` (kernels land incrementally)."""
+    """Diagnostic only (never a dispatch switch): the loader already refuses a library that lacks
+    any declared entry point, so there is no silent fallback to route around a missing kernel."""
     return hasattr(_native.lib(), symbol)
 
 
@@ -458,6 +483,25 @@ def sinc_filter(audio: torch.Tensor, cutoffs_norm: torch.Tensor, zeros: float, h
     return fir_per_item(audio, taps, highpass=highpass)
 
 
+RESAMPLE_LDS_LIMIT = 160 * 1024
+
+
+def resample_supported(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945) -> bool:
+    """True when at_resample_f32 has a tile for this ratio: one thread tile of 4 frames needs
+    (4 old + 2 width + LG) floats of LDS with ``old`` gcd-reduced (csrc/fir.hip); reduced rates
+    above ~9 k (44100 -> 16001) do not fit 160 KB and take the torch formulation, as every ratio
+    julius handles must (audio_signal.py:732)."""
+    g = math.gcd(int(old_sr), int(new_sr))
+    old, new = int(old_sr) // g, int(new_sr) // g
+    if old == new:
+        return True
+    sr = min(new, old) * rolloff
+    width = math.ceil(zeros * old / sr)
+    # LG <= taps of the dense bank = 2 width + old
+    need = (4 * old + 2 * width + (2 * width + old) + 8) * 4
+    return need <= RESAMPLE_LDS_LIMIT
+
+
 def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
     _require_native_ok(audio)
     plan = tables.resample_grouped_bank(int(old_sr), int(new_sr))
@@ -487,9 +531,11 @@ def fftconv(x: torch.Tensor, ir: torch.Tensor, scale: torch.Tensor = None):
         scale = scale.reshape(B, Cir).to(torch.float32).contiguous()
     lib = _native.lib()
     need = int(lib.at_fftconv_workspace_bytes(B, C, Cir, T))
-    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    if need < 0:
+        _native.check(need, "at_fftconv_workspace_bytes")
+    ws = _workspace(need, x.device)      # spectra + rocFFT's work buffer, cached per (device, stream)
     out = torch.empty_like(x)
     code = lib.at_fftconv_circ_f32(_native.ptr(x), _native.ptr(ir), _native.ptr(scale), B, C, Cir, T, _native.ptr(out),
-                                   _native.ptr(ws), need, _native.current_stream(x.device))
+                                   _native.ptr(ws), ws.numel(), _native.current_stream(x.device))
     _native.check(code, "at_fftconv_circ_f32")
     return out

@@ -104,7 +104,7 @@ def _native_autograd_ok(audio: torch.Tensor, n_fft: int, hop: int, match_stride:
     """A HIP float32 tensor that needs gradients can use the native forward + adjoint pair."""
     return (audio.is_cuda and audio.dtype == torch.float32 and audio.requires_grad and torch.is_grad_enabled()
             and not match_stride and kernels.stft_native_supported(n_fft) and kernels.istft_fused_supported(n_fft, hop)
-            and audio.shape[-1] > n_fft // 2 and kernels.have("at_stft_adjoint_f32"))
+            and audio.shape[-1] > n_fft // 2)
 
 
 class SpectralMixin:
@@ -190,7 +190,7 @@ class SpectralMixin:
         Xd = self.stft_data
         if (Xd.is_cuda and Xd.dtype == torch.complex64 and Xd.requires_grad and torch.is_grad_enabled()
                 and not match_stride and kernels.istft_adjoint_supported(n_fft, hop)
-                and kernels.have("at_istft_f32")):
+               ):
             x = _NativeIstft.apply(Xd, window, n_fft, hop, int(length))
         elif kernels.is_native(torch.view_as_real(self.stft_data)) and kernels.stft_native_supported(n_fft):
             edge = 2 if match_stride else 0   # the two frames per side the forward transform dropped

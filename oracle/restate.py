@@ -274,6 +274,78 @@ def convolve(audio: torch.Tensor, ir: torch.Tensor, start_at_max: bool = True) -
     return convolved * (1 / delta_max.clamp(1e-5))
 
 
+def alter_drr(ir: torch.Tensor, sample_rate: int, drr) -> torch.Tensor:
+    """effects.py:540-647 for mono impulse responses (B, 1, T): decompose_ir (early span = +-2.5 ms
+    around the arg-max; the "Hann window over the early span" is get_window("hann", n) with
+    n = window_idx.shape[-1] == 1 of the (n, 1) nonzero() result, i.e. all ones -- reproduced as
+    written, effects.py:569-573), solve_alpha (eq. 5), recombination, ensure_max_of_audio."""
+    B = ir.shape[0]
+    drr = _ensure(drr, 2, B).to(torch.float32)
+    td = torch.argmax(ir, dim=-1, keepdim=True)
+    t0 = int(sample_rate * 0.0025)
+    idx = torch.arange(ir.shape[-1])[None, None, :].expand(B, -1, -1)
+    early_idx = (idx >= td - t0) * (idx <= td + t0)
+    early = torch.zeros_like(ir)
+    early[early_idx] = ir[early_idx]
+    late = torch.zeros_like(ir)
+    late[~early_idx] = ir[~early_idx]
+    window = torch.zeros_like(ir)
+    for i in range(B):
+        window_idx = early_idx[i, 0].nonzero()
+        window[i, ..., window_idx] = get_window("hann", window_idx.shape[-1])
+    wd = window
+    e_sq, l_sq = early ** 2, late ** 2
+    a = ((wd ** 2) * e_sq).sum(dim=-1)
+    b = (2 * (1 - wd) * wd * e_sq).sum(dim=-1)
+    c = (((1 - wd) ** 2) * e_sq).sum(dim=-1) - torch.pow(10, drr / 10) * l_sq.sum(dim=-1)
+    expr = ((b ** 2) - 4 * a * c).sqrt()
+    alpha = torch.maximum((-b - expr) / (2 * a), (-b + expr) / (2 * a))
+    min_alpha = late.abs().max(dim=-1)[0] / early.abs().max(dim=-1)[0]
+    alpha = torch.maximum(alpha, min_alpha)[..., None]
+    out = alpha * window * early + ((1 - window) * early) + late
+    peak = out.abs().max(dim=-1, keepdim=True)[0]          # ensure_max_of_audio, effects.py:213-238
+    return out * torch.where(peak > 1.0, 1.0 / peak, torch.ones_like(peak))
+
+
+def apply_ir(audio: torch.Tensor, ir: torch.Tensor, sample_rate: int, drr=None, ir_eq=None) -> torch.Tensor:
+    """effects.py:155-179 with use_original_phase=False: IR EQ -> DRR -> convolve -> restore the
+    input peak."""
+    if ir_eq is not None:
+        ir = equalizer(ir, sample_rate, ir_eq)
+    if drr is not None:
+        ir = alter_drr(ir, sample_rate, drr)
+    max_spk = audio.abs().max(dim=-1, keepdims=True).values
+    y = convolve(audio, ir)
+    max_tr = y.abs().max(dim=-1, keepdims=True).values
+    return y * (max_spk.clamp(1e-8) / max_tr.clamp(1e-8))
+
+
+def log_magnitude(X: torch.Tensor, ref_value: float = 1.0, amin: float = 1e-5, top_db: float = 80.0) -> torch.Tensor:
+    """audio_signal.py:1457-1487 (the top_db floor uses the maximum over the WHOLE batch tensor)."""
+    magnitude = X.abs()
+    amin = amin ** 2
+    log_spec = 10.0 * torch.log10(magnitude.pow(2).clamp(min=amin))
+    log_spec -= 10.0 * np.log10(np.maximum(amin, ref_value))
+    if top_db is not None:
+        log_spec = torch.maximum(log_spec, log_spec.max() - top_db)
+    return log_spec
+
+
+def mix(audio: torch.Tensor, other: torch.Tensor, sample_rate: int, snr=10, other_eq=None) -> torch.Tensor:
+    """effects.py:27-64: pad/truncate ``other`` to the signal length, optional EQ, bring it to
+    ``loudness(self) - snr`` LUFS, add."""
+    B = audio.shape[0]
+    snr = _ensure(snr).to(torch.float32)
+    T = audio.shape[-1]
+    pad_len = max(0, T - other.shape[-1])
+    other = F.pad(other, (0, pad_len))[..., :T]
+    if other_eq is not None:
+        other = equalizer(other, sample_rate, other_eq)
+    tgt = loudness(audio, sample_rate) - snr
+    gain = torch.exp((tgt - loudness(other, sample_rate)) * (np.log(10) / 20))
+    return audio + other * gain[:, None, None]
+
+
 def _ensure(x, ndim=None, batch_size=None):
     """core/util.py:56-89."""
     if not torch.is_tensor(x):

@@ -1,0 +1,165 @@
+"""CPU parity of the rows the round-1 review found untested: magnitude / phase / log_magnitude
+(audio_signal.py:1428-1516), mix (effects.py:27-64), and the loader-backed transforms
+BackgroundNoise / CrossTalk / RoomImpulseResponse / GlobalVolumeNorm (transforms.py:707-938,
+1006-1063) -- each against the UNMODIFIED reference imported from /root/reference, seed for seed,
+plus the oracle's own restatements of apply_ir / alter_drr / mix / log_magnitude against it."""
+import numpy as np
+import pytest
+import torch
+
+import audiotools_amd as A
+from audiotools_amd import transforms as tfm
+from oracle import restate
+from tests import synth
+
+
+def _pair(reference, B=3, C=2, T=12000, sr=16000, seed=3):
+    x = synth.audio_batch(B, C, T, seed=seed, gaps=False, sample_rate=sr)
+    return A.AudioSignal(x.clone(), sr), reference.AudioSignal(x.clone(), sr), x
+
+
+# ------------------------------------------------------------------ a9
+def test_magnitude_phase_getters_and_setters(reference):
+    a, r, _ = _pair(reference)
+    # getters run stft() on demand (audio_signal.py:1441-1443, 1502-1504)
+    assert a.stft_data is None
+    assert torch.equal(a.magnitude, r.magnitude)
+    assert a.stft_data is not None and torch.equal(a.phase, r.phase)
+    g = torch.Generator().manual_seed(0)
+    new_mag = torch.rand(a.magnitude.shape, generator=g)
+    a.magnitude = new_mag.clone()
+    r.magnitude = new_mag.clone()
+    assert torch.equal(a.stft_data, r.stft_data)
+    new_ph = (torch.rand(a.phase.shape, generator=g) - 0.5) * 6
+    a.phase = new_ph.clone()
+    r.phase = new_ph.clone()
+    assert torch.equal(a.stft_data, r.stft_data)
+    assert torch.allclose(a.magnitude, new_mag, atol=1e-6)
+
+
+@pytest.mark.parametrize("kw", [{}, {"ref_value": 0.5}, {"amin": 1e-3}, {"top_db": None}, {"top_db": 40.0, "ref_value": 2.0}])
+def test_log_magnitude(reference, kw):
+    a, r, _ = _pair(reference, seed=11)
+    assert torch.equal(a.log_magnitude(**kw), r.log_magnitude(**kw))
+    assert torch.equal(restate.log_magnitude(r.stft_data, **kw), r.log_magnitude(**kw))
+
+
+# ------------------------------------------------------------------ mix
+@pytest.mark.parametrize("snr", [10, 3.5, "tensor"])
+@pytest.mark.parametrize("eq", [False, True])
+@pytest.mark.parametrize("other_len", [8000, 30000])
+def test_mix(reference, snr, eq, other_len):
+    sr = 16000
+    a, r, x = _pair(reference, B=3, C=1, T=20000, sr=sr, seed=5)
+    o = synth.audio_batch(3, 1, other_len, seed=6, gaps=False, sample_rate=sr)
+    snr_v = torch.tensor([0.0, 10.0, 20.0]) if snr == "tensor" else snr
+    eq_v = -torch.rand(3, 4, generator=torch.Generator().manual_seed(1)) if eq else None
+    oa, orr = A.AudioSignal(o.clone(), sr), reference.AudioSignal(o.clone(), sr)
+    ya = a.mix(oa, snr_v, eq_v).audio_data
+    yr = r.mix(orr, snr_v, eq_v).audio_data
+    assert torch.allclose(ya, yr, atol=2e-6), float((ya - yr).abs().max())
+    # `other` is padded / truncated IN PLACE to the signal length (effects.py:53-55)
+    assert oa.signal_length == orr.signal_length == 20000
+    yo = restate.mix(x, o, sr, snr_v, eq_v)
+    assert torch.allclose(yo, yr, atol=2e-5), float((yo - yr).abs().max())
+
+
+# ------------------------------------------------ loader-backed transforms
+class BankLoader:
+    """AudioLoader.__call__-compatible callable over an in-memory bank, usable by BOTH packages
+    (it builds the AudioSignal class it is given), so that the reference transform and ours see
+    the same draws from ``state`` and the same excerpts."""
+
+    def __init__(self, mod, bank, sr, loudness=None):
+        self.mod, self.bank, self.sr, self.loudness = mod, bank, sr, loudness
+
+    def __call__(self, state, sample_rate, duration, loudness_cutoff=-40, num_channels=1, offset=None, **kw):
+        idx = int(state.choice(self.bank.shape[0]))
+        n = int(duration * self.sr)
+        hi = max(self.bank.shape[-1] - n, 0)
+        start = int(offset * self.sr) if offset is not None else (int(state.randint(0, hi + 1)) if hi else 0)
+        sig = self.mod.AudioSignal(self.bank[idx: idx + 1, :, start: start + n].clone(), self.sr)
+        if num_channels == 1:
+            sig = sig.to_mono()
+        sig = sig.resample(sample_rate)
+        sig = sig.zero_pad_to(int(duration * sample_rate))
+        if self.loudness is not None:
+            sig.metadata["loudness"] = self.loudness[idx]
+        return {"signal": sig, "source_idx": 0, "item_idx": idx, "source": "bank", "path": ""}
+
+
+def _make(reference, name, bank, sr, **kw):
+    """(ours, theirs): the same transform from both packages with the bank loader installed the way
+    the review prescribes -- the reference object is built normally (with an empty source list) and its
+    ``self.loader`` replaced."""
+    ours = getattr(tfm, name)(loader=BankLoader(A, bank, sr), **kw)
+    theirs = getattr(reference.data.transforms, name)(sources=[], **kw)   # AudioLoader([]): no files
+    theirs.loader = BankLoader(reference, bank, sr)
+    return ours, theirs
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("BackgroundNoise", {}),
+    ("BackgroundNoise", {"snr": ("uniform", 0.0, 5.0), "n_bands": 4, "eq_amount": ("uniform", 0.5, 1.0)}),
+    ("CrossTalk", {}),
+    ("RoomImpulseResponse", {"duration": 0.5}),
+    ("RoomImpulseResponse", {"duration": 0.25, "offset": 0.1, "drr": ("uniform", 5.0, 10.0), "n_bands": 3}),
+])
+def test_loader_transforms_seeded_equality_with_reference(reference, name, kw):
+    sr = 16000
+    g = torch.Generator().manual_seed(7)
+    if name == "RoomImpulseResponse":
+        bank = torch.randn(6, 1, 12000, generator=g) * torch.exp(-torch.arange(12000) / 1500.0)
+    else:
+        bank = 0.1 * torch.randn(6, 2, 40000, generator=g)
+    ours, theirs = _make(reference, name, bank, sr, **kw)
+    B = 4
+    x = synth.audio_batch(B, 1, 16000, seed=9, gaps=False, sample_rate=sr)
+    sa, sr_ = A.AudioSignal(x.clone(), sr), reference.AudioSignal(x.clone(), sr)
+    ka = ours.batch_instantiate(list(range(10, 10 + B)), sa)
+    kr = theirs.batch_instantiate(list(range(10, 10 + B)), sr_)
+    assert sorted(ka[ours.name]) == sorted(kr[theirs.name])
+    for k, v in ka[ours.name].items():          # every drawn parameter equal, incl. the loaded excerpts
+        w = kr[theirs.name][k]
+        if hasattr(v, "audio_data"):
+            assert torch.equal(v.audio_data, w.audio_data), k
+        else:
+            assert torch.equal(torch.as_tensor(v), torch.as_tensor(w)), k
+    oa = ours(sa.clone(), **ka).audio_data
+    orr = theirs(sr_.clone(), **kr).audio_data
+    assert torch.allclose(oa, orr, atol=5e-6), float((oa - orr).abs().max())
+    # single item == batch item (tests/data/test_transforms.py:64-76)
+    k0 = ours.instantiate(10, sa[0])
+    assert torch.allclose(ours(sa[0].clone(), **k0).audio_data, oa[:1], atol=5e-6)
+
+
+def test_global_volume_norm(reference):
+    sr = 16000
+    x = synth.audio_batch(1, 1, 16000, seed=2, gaps=False, sample_rate=sr)
+    for loud in (-16.3, float("-inf"), None):
+        sa, sr_ = A.AudioSignal(x.clone(), sr), reference.AudioSignal(x.clone(), sr)
+        if loud is not None:
+            sa.metadata["loudness"] = loud
+            sr_.metadata["loudness"] = loud
+        ours = tfm.GlobalVolumeNorm(db=("uniform", -30, -20))
+        theirs = reference.data.transforms.GlobalVolumeNorm(db=("uniform", -30, -20))
+        ka, kr = ours.instantiate(4, sa), theirs.instantiate(4, sr_)
+        assert float(ka[ours.name]["db"]) == float(kr[theirs.name]["db"])
+        assert torch.allclose(ours(sa.clone(), **ka).audio_data, theirs(sr_.clone(), **kr).audio_data, atol=1e-7)
+
+
+# ------------------------------------------------ oracle restatements used by the GPU tests
+def test_oracle_apply_ir_and_alter_drr_match_reference(reference):
+    g = torch.Generator().manual_seed(1)
+    sr = 48000
+    ir = torch.randn(4, 1, 24000, generator=g) * torch.exp(-torch.arange(24000) / 3000.0)
+    ir[1] = torch.roll(ir[1], 40, -1)
+    drr = torch.tensor([3.0, 10.0, 20.0, 0.0])
+    got = restate.alter_drr(ir.clone(), sr, drr)
+    ref = reference.AudioSignal(ir.clone(), sr).alter_drr(drr).audio_data
+    assert torch.equal(got, ref)
+    x = 0.1 * torch.randn(4, 1, 48000, generator=g)
+    eq = -torch.rand(4, 6, generator=g)
+    got = restate.apply_ir(x.clone(), ir.clone(), sr, drr, eq)
+    ref = reference.AudioSignal(x.clone(), sr).apply_ir(reference.AudioSignal(ir.clone(), sr), drr, eq).audio_data
+    assert torch.allclose(got, ref, atol=1e-7), float((got - ref).abs().max())
