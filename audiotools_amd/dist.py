@@ -83,19 +83,53 @@ def broadcast_table(key, builder, device, src: int = 0):
 
 def broadcast_stft_mel_tables(sample_rate, n_fft, window_type, n_mels, device, fmin=0.0, fmax=None):
     """The shared tables of the STFT+mel kernel: window, twiddles, mel unit tables (info, weights)."""
-    import numpy as np
-
-    from . import _native
-
     def tw():
-        out = np.empty(2 * n_fft, dtype=np.float32)
-        _native.check(_native.lib().at_stft_twiddles_host(n_fft, out.ctypes.data), "at_stft_twiddles_host")
-        return out
+        return _twiddles_np(n_fft)
 
     broadcast_table(("window", window_type, n_fft), lambda: tables.window_np(window_type, n_fft), device)
     broadcast_table(("stft_tw", n_fft), tw, device)
     broadcast_table(("mel_units", sample_rate, n_fft, n_mels, fmin, fmax),
                     lambda: tables.mel_units_np(tables.mel_filters_np(sample_rate, n_fft, n_mels, fmin, fmax)), device)
+
+
+def _twiddles_np(n_fft):
+    import numpy as np
+
+    from . import _native
+
+    out = np.empty(2 * n_fft, dtype=np.float32)
+    _native.check(_native.lib().at_stft_twiddles_host(n_fft, out.ctypes.data), "at_stft_twiddles_host")
+    return out
+
+
+def broadcast_cfg4_tables(sample_rate, n_bands, device):
+    """Shared tables of the LowPass -> Equalizer -> RoomImpulseResponse chain (BASELINE configs[3]):
+    the mel band-split low-pass bank the equaliser FIRs are composed from, and the 2048-point
+    twiddles of the overlap-save FIR kernel.  (The IR bank itself is a caller-owned table:
+    ``broadcast_table(key, builder, device)``.)"""
+    def bank():
+        b, _half = tables.band_split_bank(int(sample_rate), int(n_bands))
+        return (b.numpy(),)
+
+    broadcast_table(("band_split_bank", int(sample_rate), int(n_bands)), bank, device)
+    broadcast_table(("stft_tw", 2048), lambda: _twiddles_np(2048), device)
+
+
+def broadcast_cfg5_tables(old_sr, new_sr, n_fft, n_mels, device, window_type="hann", fmin=0.0, fmax=None):
+    """Shared tables of resample -> mel_spectrogram (BASELINE configs[4]): the grouped sparse
+    polyphase bank of the resampler, then window / twiddles / mel units at the NEW rate."""
+    import math
+
+    g = math.gcd(int(old_sr), int(new_sr))
+    old, new = int(old_sr) // g, int(new_sr) // g
+
+    def bank():
+        wg, base = tables.resample_grouped_bank(int(old_sr), int(new_sr))[:2]
+        return (wg, base)
+
+    if old != new:
+        broadcast_table(("resample_grouped", old, new), bank, device)
+    broadcast_stft_mel_tables(int(new_sr), n_fft, window_type, n_mels, device, fmin, fmax)
 
 
 def gather_items(local: torch.Tensor, n_items: int):

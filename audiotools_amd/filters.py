@@ -134,10 +134,13 @@ class DSPMixin:
     # -------------------------------------------------------- low/high pass
     def _sinc_filter(self, cutoffs, zeros, highpass):
         cutoffs = util.ensure_tensor(cutoffs, 2, self.batch_size)
+        host = util.host_copy(cutoffs)
         cutoffs = cutoffs / self.sample_rate
         audio = self.audio_data
         if kernels.is_native(audio):
-            filtered = kernels.sinc_filter(audio, cutoffs, zeros, highpass)
+            # the host twin goes through the same float32 division as the device tensor
+            host = None if host is None else host.to(cutoffs.dtype) / self.sample_rate
+            filtered = kernels.sinc_filter(audio, cutoffs, zeros, highpass, host_cutoffs=host)
         else:
             filtered = lowpass_torch(audio, cutoffs, zeros, highpass)
         self.audio_data = filtered

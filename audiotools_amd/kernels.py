@@ -447,16 +447,28 @@ def alter_drr(x: torch.Tensor, t0: int, drr: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def sinc_taps_batched(cutoffs: torch.Tensor, zeros: float):
+def sinc_taps_batched(cutoffs: torch.Tensor, zeros: float, host_cutoffs: torch.Tensor = None):
     """Vectorised design of the per-item windowed-sinc low-pass taps of ``low_pass`` /
     ``high_pass`` (dsp.py:177-179 -> julius.LowPassFilter): every item has its own length
     2*half_i+1, ``half_i = int(zeros / c_i / 2)`` in float32 exactly as upstream; the rows are
-    centred in a common (B, 2*Hmax+1) array.  Runs on ``cutoffs.device``."""
+    centred in a common (B, 2*Hmax+1) array.  Runs on ``cutoffs.device``.
+
+    The range checks (julius raises ValueError) and the common length need the cutoffs on the
+    HOST.  ``host_cutoffs`` (the CPU twin that ``util.prepare_batch`` keeps of every small parameter
+    tensor) answers them without a device-to-host synchronisation; without it there is one."""
     c = cutoffs.reshape(-1).to(torch.float32)
     pos = c > 0
     half = torch.where(pos, (zeros / torch.where(pos, c, torch.ones_like(c)) / 2).to(torch.int64), torch.zeros_like(c, dtype=torch.int64))
-    # one host round trip for the two range checks and the common length
-    cmin, cmax, hmax = torch.stack([c.min().double(), c.max().double(), half.max().double()]).tolist()
+    if host_cutoffs is not None:
+        # the same float32 arithmetic on the host (IEEE division on both sides: identical half sizes)
+        ch = host_cutoffs.reshape(-1).to(torch.float32)
+        posh = ch > 0
+        halfh = torch.where(posh, (zeros / torch.where(posh, ch, torch.ones_like(ch)) / 2).to(torch.int64),
+                            torch.zeros_like(ch, dtype=torch.int64))
+        cmin, cmax, hmax = float(ch.min()), float(ch.max()), float(halfh.max())
+    else:
+        # one host round trip for the two range checks and the common length
+        cmin, cmax, hmax = torch.stack([c.min().double(), c.max().double(), half.max().double()]).tolist()
     if cmin < 0:
         raise ValueError("Minimum cutoff must be larger than zero.")
     if cmax > 0.5:
@@ -477,9 +489,10 @@ def sinc_taps_batched(cutoffs: torch.Tensor, zeros: float):
     return h
 
 
-def sinc_filter(audio: torch.Tensor, cutoffs_norm: torch.Tensor, zeros: float, highpass: bool):
+def sinc_filter(audio: torch.Tensor, cutoffs_norm: torch.Tensor, zeros: float, highpass: bool, host_cutoffs=None):
     B = audio.shape[0]
-    taps = sinc_taps_batched(cutoffs_norm.to(audio.device).reshape(B), zeros)
+    taps = sinc_taps_batched(cutoffs_norm.to(audio.device).reshape(B), zeros,
+                             None if host_cutoffs is None else host_cutoffs.reshape(B))
     return fir_per_item(audio, taps, highpass=highpass)
 
 

@@ -81,26 +81,54 @@ class BaseTransform:
     def apply_mask(batch: dict, mask: torch.Tensor):
         return _unflatten({k: v[mask] for k, v in _flatten(batch).items()})
 
+    @staticmethod
+    def _select(batch: dict, idx: torch.Tensor, idx_host: torch.Tensor):
+        """``apply_mask`` with the selected item indices already known on the host: ``v[mask]`` with a
+        device mask is a nonzero() + synchronisation PER VALUE; an index gather is neither.  Host
+        twins of small parameter tensors follow the selection."""
+        out = {}
+        for k, v in _flatten(batch).items():
+            sel = v[idx]
+            if torch.is_tensor(v):
+                h = util.host_copy(v)
+                if h is not None and h is not v:
+                    util.attach_host(sel, h[idx_host])
+            out[k] = sel
+        return _unflatten(out)
+
     def transform(self, signal: AudioSignal, **kwargs):
         params = self._prepare(kwargs)
         mask = params["mask"]
-        if torch.any(mask):
-            params = self.apply_mask(params, mask)
-            params = {k: v for k, v in params.items() if k != "mask"}
-            if bool(torch.all(mask)) and mask.ndim == 1 and mask.numel() == signal.batch_size:
+        hmask = util.host_values(mask)         # no synchronisation when prepare_batch() moved the batch
+        if bool(hmask.any()):
+            if bool(hmask.all()) and mask.ndim == 1 and mask.numel() == signal.batch_size:
                 # Every item selected: transform in place instead of the reference's gather ->
-                # transform -> scatter copy of the whole batch (transforms.py:159-164).  The cache
-                # semantics of that round trip are reproduced: AudioSignal.__setitem__ only writes
-                # _loudness / stft_data back when BOTH sides have them (audio_signal.py:1672-1679).
+                # transform -> scatter copy of the whole batch and of every parameter
+                # (transforms.py:159-164).  The cache semantics of that round trip are reproduced:
+                # AudioSignal.__setitem__ only writes _loudness / stft_data back when BOTH sides have
+                # them (audio_signal.py:1672-1679).
+                params = {k: v for k, v in params.items() if k != "mask"}
                 loud0, stft0 = signal._loudness, signal.stft_data
                 out = self._transform(signal, **params)
                 loud1, stft1 = out._loudness, out.stft_data
                 if out is not signal:
-                    signal.audio_data[...] = out.audio_data
+                    # rebind instead of copying into the old storage (a 2 GB pass at cfg4): like the
+                    # methods that return ``self`` with a fresh ``audio_data`` tensor (low_pass,
+                    # equalizer ...), the transformed samples live in a new tensor
+                    signal.audio_data = out.audio_data
                 signal._loudness = None if loud0 is None else (loud0 if loud1 is None else loud1)
                 signal._stft_data = None if stft0 is None else (stft0 if stft1 is None else stft1)
-            else:
+            elif mask.ndim == 0:
+                # un-batched use (instantiate() of one item): the reference's scalar-mask indexing
+                params = self.apply_mask(params, mask)
+                params = {k: v for k, v in params.items() if k != "mask"}
                 signal[mask] = self._transform(signal[mask], **params)
+            else:
+                idx_host = hmask.reshape(-1).nonzero()[:, 0]
+                idx = idx_host.to(mask.device, non_blocking=True)
+                params = self._select(params, idx, idx_host)
+                params = {k: v for k, v in params.items() if k != "mask"}
+                signal[idx] = self._transform(signal[idx], **params)
         return signal
 
     def __call__(self, *args, **kwargs):

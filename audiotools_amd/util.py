@@ -12,16 +12,49 @@ import numpy as np
 import torch
 
 
+HOST_SHADOW_MAX = 1 << 16   # elements; transform parameters (masks, cutoffs, dB values ...) are tiny
+
+
+def attach_host(dev_t: torch.Tensor, host_t: torch.Tensor) -> torch.Tensor:
+    """Remember the CPU original of a small parameter tensor that was moved to a device.  Host-side
+    decisions about it (is the mask all true? which filter length does the largest cutoff need?)
+    then cost no device-to-host synchronisation: in the reference every such question is a
+    ``.item()`` / boolean-mask sync in the middle of the launch stream (SURVEY.md 8(e) "scaling risk")."""
+    if dev_t is not host_t and dev_t.is_cuda and not host_t.is_cuda and host_t.numel() <= HOST_SHADOW_MAX:
+        dev_t._at_host = host_t
+    return dev_t
+
+
+def host_copy(t: torch.Tensor):
+    """CPU twin of ``t`` if it is known without a synchronisation (``t`` itself when it lives on
+    the CPU), else None."""
+    if not t.is_cuda:
+        return t
+    return getattr(t, "_at_host", None)
+
+
+def host_values(t: torch.Tensor) -> torch.Tensor:
+    """CPU values of ``t``; synchronises only when no host twin is attached."""
+    h = host_copy(t)
+    return t.cpu() if h is None else h
+
+
 def ensure_tensor(x, ndim: int = None, batch_size: int = None) -> torch.Tensor:
     """Make ``x`` a tensor; right-pad its shape with singleton axes up to
     ``ndim``; broadcast axis 0 to ``batch_size`` (a view, as in the reference)."""
     t = x if torch.is_tensor(x) else torch.as_tensor(x)
+    h = getattr(t, "_at_host", None)
     if ndim is not None:
         assert t.ndim <= ndim
         if t.ndim < ndim:
-            t = t.reshape(tuple(t.shape) + (1,) * (ndim - t.ndim))
+            shape = tuple(t.shape) + (1,) * (ndim - t.ndim)
+            t = t.reshape(shape)
+            h = None if h is None else h.reshape(shape)
     if batch_size is not None and t.shape[0] != batch_size:
         t = t.expand(batch_size, *t.shape[1:])
+        h = None if h is None else h.expand(batch_size, *h.shape[1:])
+    if h is not None:
+        attach_host(t, h)
     return t
 
 
@@ -122,7 +155,7 @@ def prepare_batch(batch, device="cpu"):
     if isinstance(batch, list):
         return [prepare_batch(v, device) for v in batch]
     if torch.is_tensor(batch):
-        return batch.to(device)
+        return attach_host(batch.to(device), batch)
     if hasattr(batch, "to") and hasattr(batch, "audio_data"):
         return batch.to(device)
     return batch

@@ -1,24 +1,41 @@
 #!/usr/bin/env python
-"""Headline benchmark: audio-seconds/sec of the STFT+mel+LUFS pipeline on a
-batch of 512 x 2 ch x 10 s @ 44.1 kHz (BASELINE.json `metric`), 1/2/4/8 GPUs.
+"""Benchmarks of the batched DSP hot path on 1/2/4/8 MI355X (BASELINE.json).
 
-One "step" = one pass of the hot path over the whole synthetic batch, inputs resident in
-HBM:   sig.mel_spectrogram(80)   -> fused HIP STFT (2048/512 hann, stores stft_data) + mel
-       sig.loudness()            -> HIP K-weighting IIR + gated BS.1770 integration
-Multi-GPU: the 512 items are sharded in contiguous slabs over the ranks (strong scaling, the
-total work is fixed as BASELINE.json's metric states), tables broadcast once over RCCL, no
-collective on the data path.  value = 512 items * 10 s / (max over ranks of the time of K
-steps / K).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config north_star|cfg4|cfg5]
 
-Prints ONE JSON line on rank 0 (see the contract in the task description), including
-  "roofline":     the fused STFT+mel kernel, algorithmic bytes / HIP-event duration vs 8 TB/s
-  "cpu_baseline": the oracle port (torch CPU stft/abs/matmul + C DF-I lfilter + gating, i.e.
-                  the ops the reference's CPU path executes) timed on the host cores on a
-                  bounded sample of the same workload (rank 0, N = 1 only).
+``--gpus N`` with N > 1 and no torchrun environment re-launches this script under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` (one
+process per GPU, the reference's own convention, audiotools/ml/accelerator.py:35-48); under an
+existing torchrun environment (the driver's) it just joins the group.  The world size must equal
+``--gpus``.  Rank 0 prints ONE JSON line.
+
+Configurations (SURVEY.md 8(d) synthetic inputs, resident in HBM before the timed region):
+  north_star  batch 512 x 2ch x 10 s @44.1 kHz:  sig.mel_spectrogram(80) [fused STFT 2048/512 hann
+              + mel, stores stft_data]  +  sig.loudness() [K-weighting IIR + gated BS.1770]
+              -- BASELINE.json ``metric``; this is what the driver runs.
+  cfg4        batch 1024 x mono x 5 s @48 kHz:  Compose(LowPass(4/8/16 kHz), Equalizer(6 bands),
+              RoomImpulseResponse(2 s RIR, DRR, EQ)) with parameters drawn beforehand
+  cfg5        batch 2048 x 2ch x 30 s @44.1 kHz:  resample(16000) + mel_spectrogram(80)
+Multi-GPU: the batch is sharded in contiguous slabs over the ranks (strong scaling: the metric
+fixes the global batch); shared tables (window, twiddles, mel units, band-split bank, resample
+bank, the IR bank) are built on rank 0 and broadcast once over RCCL; no collective on the data path.
+value = global items x seconds per item / (max over ranks of the K-step time / K).
+
+The north-star step is a HIP graph replay of the captured API calls by default (``--no-graph`` for
+eager launches): at 64 items per GPU the kernels take ~0.45 ms and Python dispatch of the same
+calls ~0.15 ms, which is what limits strong scaling, not the kernels.
+
+JSON extras: "roofline" (algorithmic HBM bytes of the dominant kernel / its HIP-event duration vs
+8 TB/s) and "cpu_baseline" (the oracle's port of the reference's CPU path -- bit-equal to the
+unmodified reference for stft/mel, <= 1e-5 LU for loudness, tests/test_oracle_vs_reference.py --
+timed on the host cores on a bounded sample; rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -28,71 +45,170 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-SR = 44100
-DUR = 10.0
-CH = 2
 N_MELS = 80
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
+CONFIGS = {
+    "north_star": dict(batch=512, ch=2, sr=44100, dur=10.0,
+                       metric="audio-seconds/sec (STFT+mel+LUFS pipeline), batch 512x2chx10s@44.1kHz"),
+    "cfg4": dict(batch=1024, ch=1, sr=48000, dur=5.0,
+                 metric="audio-seconds/sec (LowPass->Equalizer->RoomImpulseResponse chain), batch 1024xmonox5s@48kHz"),
+    "cfg5": dict(batch=2048, ch=2, sr=44100, dur=30.0,
+                 metric="audio-seconds/sec (resample 44.1k->16k + STFT + mel), batch 2048x2chx30s@44.1kHz"),
+}
 
-def make_batch(n_items, device, seed):
+
+def make_batch(n_items, ch, T, sr, device, seed):
     """SURVEY.md 8(d) synthetic input, generated directly on the owning device."""
-    T = int(SR * DUR)
     g = torch.Generator(device=device).manual_seed(seed)
-    x = (0.1 * torch.randn(n_items, CH, T, device=device, generator=g)).clamp_(-1, 1)
+    x = (0.1 * torch.randn(n_items, ch, T, device=device, generator=g)).clamp_(-1, 1)
     gain = 10 ** (-30 * torch.rand(n_items, device=device, generator=g) / 20)
     x *= gain[:, None, None]
-    for i in range(0, n_items, 20):  # 5 % of the items: 2 s of digital silence
-        x[i, :, 3 * SR: 5 * SR] = 0
+    if T >= 5 * sr:
+        for i in range(0, n_items, 20):  # 5 % of the items: 2 s of digital silence
+            x[i, :, 3 * sr: 5 * sr] = 0
     return x
 
 
-def cpu_baseline(n_items, iters):
-    """Reference CPU path restated (oracle port) on the host cores.  torch's CPU kernels do not
-    scale to very wide hosts, so a few thread counts are tried and the FASTEST is reported
-    (`cores` = the thread count that won)."""
+# ----------------------------------------------------------------------------- CPU baseline
+def cpu_baseline_north_star(n_items, iters):
+    """The reference's CPU path as restated by the oracle (torch CPU stft/abs/matmul + the C DF-I
+    lfilter + gating: the ops the reference executes), B = 64 by default, median of >= 3 passes.
+    torch's CPU kernels do not scale to very wide hosts, so a few thread counts are tried and
+    the best MEDIAN is reported with its thread count."""
     from oracle import cport, restate
 
     cport.build()
     ncpu = os.cpu_count()
-    x = make_batch(n_items, torch.device("cpu"), 999)
+    sr, T = 44100, 441000
+    x = make_batch(n_items, 2, T, sr, torch.device("cpu"), 999)
     best, best_threads, spent = None, None, 0.0
     for threads in sorted({min(ncpu, t) for t in (16, 32, 64, ncpu)}):
         torch.set_num_threads(threads)
         os.environ["OMP_NUM_THREADS"] = str(threads)
-        for _ in range(iters):
+        times = []
+        for _ in range(max(iters, 3)):
             t0 = time.perf_counter()
             X = restate.stft(x, 2048, 512, "hann")
-            mel = restate.mel_spectrogram(X, SR, N_MELS)
-            lufs = restate.loudness(x, SR)
-            dt = time.perf_counter() - t0
-            spent += dt
+            mel = restate.mel_spectrogram(X, sr, N_MELS)
+            lufs = restate.loudness(x, sr)
+            times.append(time.perf_counter() - t0)
             del X, mel, lufs
-            if best is None or dt < best:
-                best, best_threads = dt, threads
+        spent += sum(times)
+        med = statistics.median(times)
+        if best is None or med < best:
+            best, best_threads = med, threads
         if spent > 25.0:
             break
-    return {"value": n_items * DUR / best, "unit": "audio-seconds/sec", "cores": best_threads, "kind": "port",
-            "host_cpus": ncpu,
-            "sample": f"{n_items} items x 2ch x 10s@44.1kHz, stft(2048/512)+mel80+LUFS(IIR), best single pass "
-                      f"({best:.2f} s) over thread counts <= {ncpu}; torch CPU ops + oracle/c DF-I lfilter (OpenMP)"}
+    return {"value": n_items * 10.0 / best, "unit": "audio-seconds/sec", "cores": best_threads,
+            "kind": "port", "host_cpus": ncpu,
+            "port_evidence": "oracle/restate.py is bit-equal to the unmodified reference on stft/mel and within "
+                             "1e-5 LU on loudness (tests/test_oracle_vs_reference.py; /root/reference is absent here)",
+            "sample": f"{n_items} items x 2ch x 10s@44.1kHz, stft(2048/512)+mel80+LUFS(IIR), median of "
+                      f"{max(iters, 3)} passes ({best:.2f} s) at the best of the thread counts tried (<= {ncpu}); "
+                      f"torch CPU ops + oracle/c DF-I lfilter (OpenMP)"}
 
 
-def measured_traffic(n_local):
-    """HBM bytes per launch of the fused STFT+mel kernel from the committed rocprofv3 PMC pass
-    (profiles/r01_bench_pmc_summary.json; FETCH_SIZE and WRITE_SIZE collected in separate passes,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the
-    configuration that was profiled (512 items on one GPU)."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")
-    if n_local != 512 or not os.path.exists(path):
-        return None
+def cpu_baseline_cfg(config, kw_cpu, n_items):
+    """Oracle port of the other configurations on a few items (bounded CPU time)."""
+    from oracle import restate
+
+    ncpu = os.cpu_count()
+    torch.set_num_threads(min(ncpu, 32))
+    c = CONFIGS[config]
+    sr, T = c["sr"], int(c["sr"] * c["dur"])
+    x = make_batch(n_items, c["ch"], T, sr, torch.device("cpu"), 999)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        if config == "cfg4":
+            k = kw_cpu["Compose"]
+            y = restate.low_pass(x, k["0.LowPass"]["cutoff"][:n_items], sr)
+            y = restate.equalizer(y, sr, k["1.Equalizer"]["eq"][:n_items])
+            r = k["2.RoomImpulseResponse"]
+            restate.apply_ir(y, r["ir_signal"].audio_data[:n_items], sr, r["drr"][:n_items], r["eq"][:n_items])
+        else:
+            y = restate.resample(x, sr, 16000)
+            restate.mel_spectrogram(restate.stft(y, 2048, 512), 16000, N_MELS)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": n_items * c["dur"] / med, "unit": "audio-seconds/sec", "cores": min(ncpu, 32), "kind": "port",
+            "host_cpus": ncpu, "sample": f"{n_items} items of {config}, median of 3 passes ({med:.2f} s), oracle/restate.py"}
+
+
+def committed_traffic(config, n_local):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS
+    configuration (profiles/r02_*_pmc_summary.json; FETCH_SIZE and WRITE_SIZE in separate passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this
+    exact shape is committed -- it is a recorded measurement, not one made by this run."""
+    path = os.path.join(ROOT, "profiles", "r02_bench_pmc_summary.json")
+    if config != "north_star" or n_local != 512 or not os.path.exists(path):
+        return None, None
     try:
         d = json.load(open(path))
         f = [v["FETCH_SIZE"] for k, v in d["pmc_fetch"].items() if "stft_mel_kernel" in k][0]
         w = [v["WRITE_SIZE"] for k, v in d["pmc_write"].items() if "stft_mel_kernel" in k][0]
-        return (2.0 * f + w) * 1024.0
+        return (2.0 * f + w) * 1024.0, "profiles/r02_bench_pmc_summary.json (rocprofv3 --pmc, same command)"
     except Exception:
-        return None
+        return None, None
+
+
+# ----------------------------------------------------------------------------- launching
+def respawn_under_torchrun(n):
+    """python bench.py --gpus N without a torchrun environment: start N ranks on this node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, adist, rank, world, device):
+    """Everything around the kernels: one process per rank, the world size check, contiguous batch
+    slabs, the table broadcasts of the chosen configuration (gloo when there is no GPU)."""
+    cfg = CONFIGS[args.config]
+    batch = cfg["batch"] if args.batch is None else args.batch
+    lo, hi = adist.shard_range(batch, rank, world)
+    if args.config == "north_star":
+        adist.broadcast_stft_mel_tables(cfg["sr"], 2048, "hann", N_MELS, device)
+    elif args.config == "cfg4":
+        import numpy as np
+        adist.broadcast_table(("bench_ir_bank", cfg["sr"]), lambda: np.arange(12, dtype=np.float32).reshape(3, 1, 4), device)
+        adist.broadcast_cfg4_tables(cfg["sr"], 6, device)
+    else:
+        adist.broadcast_cfg5_tables(cfg["sr"], 16000, 2048, N_MELS, device)
+    sizes = torch.tensor([hi - lo], dtype=torch.int64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(sizes)
+    assert int(sizes[0]) == batch, "the slabs must cover the batch exactly once"
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "config": args.config, "n_gpus": world, "global_batch": batch,
+                          "items_rank0": hi - lo, "backend": torch.distributed.get_backend() if world > 1 else None}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def time_steps(step, steps, warmup, adist, device, world, n_events=0):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; the
+    elapsed time is the MAX over ranks."""
+    for _ in range(warmup):
+        step(None)
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_events)] for _ in range(steps)] if n_events else None
+    adist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(events[k] if events else None)
+    torch.cuda.synchronize()
+    adist.barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+    return float(elapsed[0]), events
 
 
 def main():
@@ -100,91 +216,196 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="GLOBAL batch (items)")
-    ap.add_argument("--cpu-items", type=int, default=32)
+    ap.add_argument("--config", default="north_star", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="GLOBAL batch (items); default: the configuration's")
+    ap.add_argument("--cpu-items", type=int, default=None)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph replay (north_star)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch path only (process group, sharding, table broadcast; gloo on a CPU-only host): no kernels")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args.gpus))
 
     import audiotools_amd as A
     from audiotools_amd import _native, dist as adist
 
-
     rank, world, device = adist.init()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s) "
+                         f"(WORLD_SIZE={os.environ.get('WORLD_SIZE')})")
     if int(os.environ.get("LOCAL_RANK", 0)) == 0:
         _native.build()   # no-op when the in-tree library is up to date (it normally travels prebuilt)
     adist.barrier()
+    if args.dry_run:
+        return dry_run(args, adist, rank, world, device)
     assert device.type == "cuda", "bench.py needs a GPU (the product has no CPU fallback)"
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    lo, hi = adist.shard_range(args.batch, rank, world)
-    n_local = hi - lo
-    x = make_batch(n_local, device, 1234 + rank)
-    sig = A.AudioSignal(x, SR)
-    n_fft, hop = sig.stft_params.window_length, sig.stft_params.hop_length
-    adist.broadcast_stft_mel_tables(SR, n_fft, "hann", N_MELS, device)
-
-    T = x.shape[-1]
-    rows = n_local * CH
-    n_frames = 1 + T // hop
-    F = n_fft // 2 + 1
-    stft_bytes = rows * T * 4 + rows * n_frames * F * 8 + rows * n_frames * N_MELS * 4
-    lufs_bytes = rows * T * 4 + n_local * 4
-
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record()
-        mel = sig.mel_spectrogram(N_MELS)
-        if ev is not None:
-            ev[1].record()
-        sig._loudness = None
-        lufs = sig.loudness()
-        if ev is not None:
-            ev[2].record()
-        return mel, lufs
-
-    for _ in range(args.warmup):
-        step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    adist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        mel, lufs = step(events[k])
-    torch.cuda.synchronize()
-    adist.barrier()
-    t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
     if world > 1:
-        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(elapsed[0])
-    stft_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
-    lufs_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
-    assert torch.isfinite(mel).all() and torch.isfinite(lufs).all()
+        assert torch.distributed.get_backend() == "nccl", "multi-GPU runs use RCCL (torch backend 'nccl')"
+
+    cfg = CONFIGS[args.config]
+    batch = cfg["batch"] if args.batch is None else args.batch
+    sr, ch, dur = cfg["sr"], cfg["ch"], cfg["dur"]
+    T = int(sr * dur)
+    lo, hi = adist.shard_range(batch, rank, world)
+    n_local = hi - lo
+    x = make_batch(n_local, ch, T, sr, device, 1234 + rank)
+    rows = n_local * ch
+    out = {"metric": cfg["metric"], "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    kw_cpu = None
+
+    if args.config == "north_star":
+        sig = A.AudioSignal(x, sr)
+        n_fft, hop = sig.stft_params.window_length, sig.stft_params.hop_length
+        adist.broadcast_stft_mel_tables(sr, n_fft, "hann", N_MELS, device)
+        n_frames, F = 1 + T // hop, n_fft // 2 + 1
+        stft_bytes = rows * T * 4 + rows * n_frames * F * 8 + rows * n_frames * N_MELS * 4
+        lufs_bytes = rows * T * 4 + n_local * 4
+        res = {}
+
+        def api_step():
+            res["mel"] = sig.mel_spectrogram(N_MELS)
+            sig._loudness = None
+            res["lufs"] = sig.loudness()
+
+        # per-kernel durations (HIP events on the launch stream), eager launches
+        def step_events(ev):
+            if ev is not None:
+                ev[0].record()
+            res["mel"] = sig.mel_spectrogram(N_MELS)
+            if ev is not None:
+                ev[1].record()
+            sig._loudness = None
+            res["lufs"] = sig.loudness()
+            if ev is not None:
+                ev[2].record()
+
+        _, events = time_steps(step_events, max(5, min(args.steps, 20)), args.warmup, adist, device, world, n_events=3)
+        stft_ms = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
+        lufs_ms = sum(e[1].elapsed_time(e[2]) for e in events) / len(events)
+
+        launch = "eager"
+        step = lambda ev: api_step()
+        if not args.no_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    api_step()
+                torch.cuda.current_stream().wait_stream(s)
+                with torch.cuda.graph(graph):
+                    api_step()
+                step = lambda ev: graph.replay()
+                launch = "hipGraph replay of the captured API calls (mel_spectrogram + loudness)"
+            except Exception as e:  # pragma: no cover - capture not supported on this stack
+                launch = f"eager (graph capture failed: {type(e).__name__})"
+                step = lambda ev: api_step()
+        elapsed, _ = time_steps(step, args.steps, args.warmup, adist, device, world)
+        mel, lufs = res["mel"], res["lufs"]
+        assert torch.isfinite(mel).all() and torch.isfinite(lufs).all()
+        achieved = stft_bytes / (stft_ms * 1e-3) / 1e9
+        traffic, traffic_src = committed_traffic(args.config, n_local)
+        out["config"] = {"workload": f"north-star: batch={batch} 2ch 10s@44.1kHz mel_spectrogram(80) "
+                                     f"[fused STFT {n_fft}/{hop} hann + mel] + loudness()",
+                         "global_batch": batch, "items_per_gpu": n_local, "parallelism": f"batch-shard x{world}",
+                         "inputs": "device-resident (H2D excluded)", "launch": launch}
+        out["roofline"] = {"bound": "hbm", "kernel": "stft_mel_kernel_v2<4> (fused STFT 2048/512 + 80-band mel)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": traffic, "traffic_source": traffic_src,
+                           "algorithmic_bytes_per_launch": stft_bytes, "avg_launch_ms": stft_ms,
+                           "frac_of_measured_copy_6290": achieved / 6290.0}
+        out["kernels_ms"] = {"stft_mel": stft_ms, "lufs_total": lufs_ms, "lufs_GBps": lufs_bytes / (lufs_ms * 1e-3) / 1e9,
+                             "timing": "HIP events around eager launches, separate from the timed region"}
+
+    elif args.config == "cfg4":
+        from audiotools_amd import transforms as tfm
+
+        # rank 0 owns the impulse-response bank and broadcasts it (RCCL); every rank then draws its
+        # own items' parameters on the host (the reference's DataLoader-worker job, not timed)
+        def make_bank():
+            g = torch.Generator().manual_seed(77)
+            t_ir = torch.arange(2 * sr) / sr
+            return (torch.randn(64, 1, 2 * sr, generator=g) * torch.exp(-t_ir / 0.3)).numpy()
+
+        bank = adist.broadcast_table(("bench_ir_bank", sr), make_bank, device)
+        adist.broadcast_cfg4_tables(sr, 6, device)
+        chain = tfm.Compose(tfm.LowPass(cutoff=("choice", [4000, 8000, 16000])), tfm.Equalizer(n_bands=6),
+                            tfm.RoomImpulseResponse(loader=tfm.TensorLoader(bank.cpu(), sr), duration=2.0, offset=0.0))
+        proto = A.AudioSignal(torch.zeros(n_local, 1, 8), sr)
+        t0 = time.perf_counter()
+        kw_cpu = chain.batch_instantiate([1000 + lo + i for i in range(n_local)], proto)
+        inst_ms = (time.perf_counter() - t0) * 1e3
+        kw = A.util.prepare_batch(kw_cpu, device)
+        res = {}
+
+        def step(ev):
+            res["y"] = chain(A.AudioSignal(x, sr), **kw).audio_data
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(None)
+        enq_ms = (time.perf_counter() - t0) * 1e3          # host time to enqueue one chain (no sync inside)
+        elapsed, _ = time_steps(step, args.steps, args.warmup, adist, device, world)
+        assert torch.isfinite(res["y"]).all()
+        chain_bytes = 3 * 2 * rows * T * 4 + rows * 2 * sr * 4
+        achieved = chain_bytes / (elapsed / args.steps) / 1e9
+        out["config"] = {"workload": f"cfg4: batch={batch} mono 5s@48kHz Compose(LowPass, Equalizer(6), "
+                                     f"RoomImpulseResponse(2 s RIR, DRR, EQ))", "global_batch": batch,
+                         "items_per_gpu": n_local, "parallelism": f"batch-shard x{world} + RCCL broadcast of the IR bank / tables",
+                         "inputs": "device-resident; transform parameters drawn before the timed region",
+                         "host_instantiate_ms": inst_ms, "host_enqueue_ms_first_step": enq_ms}
+        out["roofline"] = {"bound": "hbm", "kernel": "whole chain (fir_fft x2, alter_drr, absmax, roll_pad, FFT convolution)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes_per_launch": chain_bytes,
+                           "avg_launch_ms": 1e3 * elapsed / args.steps}
+
+    else:  # cfg5
+        adist.broadcast_cfg5_tables(sr, 16000, 2048, N_MELS, device)
+        res = {}
+
+        def step(ev):
+            s = A.AudioSignal(x, sr)
+            if ev is not None:
+                ev[0].record()
+            s.resample(16000)
+            if ev is not None:
+                ev[1].record()
+            res["mel"] = s.mel_spectrogram(N_MELS)
+            if ev is not None:
+                ev[2].record()
+
+        _, events = time_steps(step, max(3, min(args.steps, 10)), args.warmup, adist, device, world, n_events=3)
+        rs_ms = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
+        mel_ms = sum(e[1].elapsed_time(e[2]) for e in events) / len(events)
+        elapsed, _ = time_steps(step, args.steps, args.warmup, adist, device, world)
+        assert torch.isfinite(res["mel"]).all()
+        T2 = int(16000 * T // sr)
+        n_frames = 1 + T2 // 512
+        rs_bytes = rows * T * 4 + rows * T2 * 4
+        mel_bytes = rows * T2 * 4 + rows * n_frames * 1025 * 8 + rows * n_frames * N_MELS * 4
+        achieved = rs_bytes / (rs_ms * 1e-3) / 1e9
+        out["config"] = {"workload": f"cfg5: batch={batch} 2ch 30s@44.1kHz resample(16000) + mel_spectrogram(80) "
+                                     f"[STFT 2048/512 as the signal keeps its stft_params]", "global_batch": batch,
+                         "items_per_gpu": n_local, "parallelism": f"batch-shard x{world} + RCCL broadcast of the resample bank / tables",
+                         "inputs": "device-resident (H2D excluded)"}
+        out["roofline"] = {"bound": "hbm", "kernel": "resample_kernel (sparse polyphase 441->160)", "achieved": achieved,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": rs_bytes, "avg_launch_ms": rs_ms}
+        out["kernels_ms"] = {"resample": rs_ms, "stft_mel": mel_ms, "stft_mel_GBps": mel_bytes / (mel_ms * 1e-3) / 1e9}
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = args.batch * DUR / (elapsed / args.steps)
-        achieved = stft_bytes / (stft_ms * 1e-3) / 1e9
-        out = {
-            "metric": "audio-seconds/sec (STFT+mel+LUFS pipeline), batch 512x2chx10s@44.1kHz",
-            "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"north-star: batch={args.batch} 2ch 10s@44.1kHz "
-                                   f"mel_spectrogram(80) [fused STFT {n_fft}/{hop} hann + mel] + loudness()",
-                       "global_batch": args.batch, "items_per_gpu": n_local, "parallelism": f"batch-shard x{world}",
-                       "inputs": "device-resident (H2D excluded)"},
-            "roofline": {"bound": "hbm", "kernel": "stft_mel_kernel<1024,4,true,4>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n_local),
-                         "algorithmic_bytes_per_launch": stft_bytes, "avg_launch_ms": stft_ms,
-                         "frac_of_measured_copy_6290": achieved / 6290.0},
-            "kernels_ms": {"stft_mel": stft_ms, "lufs_total": lufs_ms,
-                           "lufs_GBps": lufs_bytes / (lufs_ms * 1e-3) / 1e9},
-        }
+        out["ms_per_step"] = 1e3 * elapsed / args.steps
+        out["value"] = batch * dur / (elapsed / args.steps)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_items, args.cpu_iters)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            if args.config == "north_star":
+                out["cpu_baseline"] = cpu_baseline_north_star(args.cpu_items or 64, args.cpu_iters)
+            else:
+                out["cpu_baseline"] = cpu_baseline_cfg(args.config, kw_cpu, args.cpu_items or (8 if args.config == "cfg4" else 4))
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -87,3 +87,27 @@ def test_shard_range_partitions_batch():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("config", ["north_star", "cfg4", "cfg5"])
+def test_bench_spawns_its_own_ranks(config):
+    """`python bench.py --gpus 2` without a torchrun environment starts 2 ranks itself, checks the
+    world size, shards the batch and broadcasts the configuration's tables (gloo here; the same code
+    runs RCCL on a GPU node).  --dry-run stops before the kernels."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--config", config],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"] == config and d["items_rank0"] * 2 == d["global_batch"]
+    # a world size that does not match --gpus is an error, not a warning
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "--gpus 2" in (bad.stderr + bad.stdout)

@@ -718,8 +718,9 @@ def test_magnitude_phase_log_magnitude_gpu():
         assert float((got - ref).abs().max()) < 2e-3, kw          # dB; 1e-4 relative on |X| = 8.7e-4 dB
     g = torch.Generator().manual_seed(0)
     mag = torch.rand(X.shape, generator=g)
+    ph0 = s.phase.cpu()       # the phase of a near-zero bin is ill-conditioned: use the device's own
     s.magnitude = mag.cuda()
-    assert rel_err(s.stft_data, mag * torch.exp(1j * X.angle())) < REL
+    assert rel_err(s.stft_data, mag * torch.exp(1j * ph0)) < REL
     ph = (torch.rand(X.shape, generator=g) - 0.5) * 6
     s.phase = ph.cuda()
     assert rel_err(s.stft_data, mag * torch.exp(1j * ph)) < REL
