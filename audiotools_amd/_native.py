@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("AT_LIB_PATH") or os.path.join(LIB_DIR, "libaudiotools_amd.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "firfft.hip", "irtools.hip", "specedit.hip", "fftconv.hip"]
+SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "firfft.hip", "irtools.hip", "specedit.hip", "fftconv.hip", "vocoder.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -112,6 +112,8 @@ SIGNATURES = {
     "at_spec_phase_shift_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "at_spec_maxpow_f32": (_i32, [_p, _i64, _p, _p]),
     "at_spec_mask_lowmag_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _p, _p, _f32, _i32, _f32, _p]),
+    "at_phase_vocoder_frames": (_i64, [_i64, _i64, _i64]),
+    "at_phase_vocoder_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p]),
     "at_absmax_f32": (_i32, [_p, _i64, _i64, _p, _p, _p]),
     "at_roll_pad_f32": (_i32, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "at_alter_drr_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p, _p]),

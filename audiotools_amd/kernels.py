@@ -552,3 +552,21 @@ def fftconv(x: torch.Tensor, ir: torch.Tensor, scale: torch.Tensor = None):
                                    _native.ptr(ws), ws.numel(), _native.current_stream(x.device))
     _native.check(code, "at_fftconv_circ_f32")
     return out
+
+
+# ----------------------------------------------------------- phase vocoder
+def phase_vocoder(X_bcfn: torch.Tensor, p: int, q: int, hop: int) -> torch.Tensor:
+    """Time-scale modification of a (B, C, F, N) complex64 HIP spectrum by the rate p/q:
+    returns (B, C, F, ceil(N q / p)) in the same bin-contiguous physical layout."""
+    _require_native_ok(X_bcfn)
+    B, C, F, N = X_bcfn.shape
+    X = X_bcfn.transpose(2, 3).contiguous()        # physical (B, C, N, F); no copy for stft() outputs
+    lib = _native.lib()
+    n_out = int(lib.at_phase_vocoder_frames(N, int(p), int(q)))
+    if n_out < 0:
+        _native.check(n_out, "at_phase_vocoder_frames")
+    Y = torch.empty((B, C, n_out, F), dtype=torch.complex64, device=X.device)
+    code = lib.at_phase_vocoder_f32(_native.ptr(torch.view_as_real(X)), B * C, N, F, int(p), int(q), int(hop),
+                                    _native.ptr(torch.view_as_real(Y)), n_out, _native.current_stream(X.device))
+    _native.check(code, "at_phase_vocoder_f32")
+    return Y.transpose(2, 3)

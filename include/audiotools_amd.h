@@ -180,6 +180,21 @@ int at_spec_maxpow_f32(const float* X, int64_t n, float* out, void* stream);
 int at_spec_mask_lowmag_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const double* cutoff_db,
                             const float* maxpow, float top_db, int use_top_db, float val, void* stream);
 
+/* ---- phase vocoder (time_stretch / pitch_shift) --------------------------------------------------
+ * Replaces audiotools/core/effects.py:247-309: the reference pipes the batch through CPU libsox
+ * ("tempo" / "pitch" + "rate", torchaudio.sox_effects.apply_effects_tensor).  Device-side
+ * behavioural equivalent (sox's WSOLA is not reproducible sample for sample; parity is by
+ * properties -- length, pitch ratio, batched == single):  stft -> at_phase_vocoder_f32 -> istft,
+ * plus at_resample_f32 for pitch_shift.
+ *   X (rows, n_in, F) complex64 (physical layout of stft_data), rate = p / q as an exact rational
+ *   Y (rows, n_out, F), n_out = at_phase_vocoder_frames(n_in, p, q) = ceil(n_in q / p)
+ *   |Y_k| interpolates |X| linearly at t_k = k p / q; the phase advances by the wrapped
+ *   inter-frame phase difference (the formulation of torchaudio.functional.phase_vocoder).
+ */
+int64_t at_phase_vocoder_frames(int64_t n_in, int64_t p, int64_t q);
+int at_phase_vocoder_f32(const float* X, int64_t rows, int64_t n_in, int64_t F, int64_t p, int64_t q, int hop,
+                         float* Y, int64_t n_out, void* stream);
+
 /* ---- row peaks and impulse-response preparation -----------------------------------------------
  * Replaces whole-tensor torch chains of the reference by single passes:
  *   at_absmax_f32     audiotools/core/effects.py:100 (ir.abs().argmax), :118 (max|ir| clamp),

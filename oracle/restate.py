@@ -346,6 +346,32 @@ def mix(audio: torch.Tensor, other: torch.Tensor, sample_rate: int, snr=10, othe
     return audio + other * gain[:, None, None]
 
 
+def phase_vocoder_f64(X: np.ndarray, p: int, q: int, hop: int) -> np.ndarray:
+    """Checker for the device phase vocoder (csrc/vocoder.hip): float64, explicit loops over output
+    frames.  PARITY UNPINNED against the reference: effects.py:247-309 pipes the audio through CPU
+    libsox ("tempo" / "pitch"), whose output is not reproducible here (no sox, no fixtures; the
+    reference's own tests only compare batched with single, tests/core/test_effects.py:156-181).
+    The algorithm restated is the published phase vocoder as torchaudio.functional.phase_vocoder
+    formulates it (X: (..., F, N) complex), with the rate as the rational p/q."""
+    X = np.asarray(X, dtype=np.complex128)
+    F_bins, N = X.shape[-2], X.shape[-1]
+    n_out = (N * q + p - 1) // p
+    Xp = np.concatenate([X, np.zeros(X.shape[:-1] + (2,), X.dtype)], axis=-1)
+    adv = np.pi * hop * np.arange(F_bins) / (F_bins - 1)
+    out = np.zeros(X.shape[:-1] + (n_out,), np.complex128)
+    acc = np.angle(X[..., 0])
+    for k in range(n_out):
+        j, rem = divmod(k * p, q)
+        alpha = rem / q
+        x0, x1 = Xp[..., j], Xp[..., j + 1]
+        mag = alpha * np.abs(x1) + (1 - alpha) * np.abs(x0)
+        out[..., k] = mag * np.exp(1j * acc)
+        d = np.angle(x1) - np.angle(x0) - adv
+        d = d - 2 * np.pi * np.round(d / (2 * np.pi))
+        acc = acc + d + adv
+    return out
+
+
 def _ensure(x, ndim=None, batch_size=None):
     """core/util.py:56-89."""
     if not torch.is_tensor(x):
