@@ -64,6 +64,87 @@ class AudioSignal(SpectralMixin, EffectMixin, LoudnessMixin, ImpulseResponseMixi
         return cls(torch.zeros(batch_size, num_channels, int(duration * sample_rate)), sample_rate, **kwargs)
 
     @classmethod
+    def excerpt(cls, audio_path, offset: float = None, duration: float = None, state=None, **kwargs):
+        """Random excerpt of ``duration`` seconds between ``offset`` and the end of the source
+        (audio_signal.py:180-226): ONE ``state.uniform`` draw."""
+        total_duration = util.info(audio_path).duration
+        state = util.random_state(state)
+        lower_bound = 0 if offset is None else offset
+        upper_bound = max(total_duration - duration, 0)
+        offset = state.uniform(lower_bound, upper_bound)
+        signal = cls(audio_path, offset=offset, duration=duration, **kwargs)
+        signal.metadata["offset"] = offset
+        signal.metadata["duration"] = duration
+        return signal
+
+    @classmethod
+    def salient_excerpt(cls, audio_path, loudness_cutoff: float = None, num_tries: int = 8, state=None, **kwargs):
+        """Random excerpt whose loudness exceeds ``loudness_cutoff`` LUFS, giving up after
+        ``num_tries`` draws (audio_signal.py:228-286).
+
+        The reference measures one candidate at a time (a full ``loudness()`` per try).  For sources
+        resident on a GPU the candidates of ALL tries are measured by one batched launch: the
+        offsets are drawn from a COPY of ``state``, the first candidate above the cutoff wins, and
+        the real ``state`` is then advanced by exactly the draws the sequential loop would have
+        made -- same excerpt, same RNG state afterwards, one launch + one synchronisation."""
+        state = util.random_state(state)
+        if loudness_cutoff is None:
+            return cls.excerpt(audio_path, state=state, **kwargs)
+        mem = util.memory_audio(audio_path)
+        if mem is not None and mem[0].is_cuda and num_tries is not None and num_tries > 1:
+            return cls._salient_excerpt_batched(audio_path, mem, loudness_cutoff, int(num_tries), state, **kwargs)
+        loudness = -np.inf
+        num_try = 0
+        while loudness <= loudness_cutoff:
+            excerpt = cls.excerpt(audio_path, state=state, **kwargs)
+            loudness = excerpt.loudness()
+            num_try += 1
+            if num_tries is not None and num_try >= num_tries:
+                break
+        return excerpt
+
+    @classmethod
+    def _salient_excerpt_batched(cls, audio_path, mem, loudness_cutoff, num_tries, state, offset: float = None,
+                                 duration: float = None, **kwargs):
+        bank, sr = mem
+        total_duration = bank.shape[-1] / sr
+        lower_bound = 0 if offset is None else offset
+        upper_bound = max(total_duration - duration, 0)
+        probe = np.random.RandomState()
+        probe.set_state(state.get_state())
+        offsets = [probe.uniform(lower_bound, upper_bound) for _ in range(num_tries)]
+        n = int(duration * sr)
+        rows = []
+        for o in offsets:
+            seg = bank[:, int(o * sr): int(o * sr) + n]
+            if seg.shape[-1] == 0:
+                raise RuntimeError(f"Audio file {audio_path} with offset {o} and duration {duration} is empty!")
+            if seg.shape[-1] < n:         # the last excerpt of a short source: measured as is in the reference
+                rows = None
+                break
+            rows.append(seg)
+        if rows is None:                  # ragged candidates: keep the sequential form
+            loudness, num_try = -np.inf, 0
+            while loudness <= loudness_cutoff:
+                excerpt = cls.excerpt(audio_path, offset=offset, duration=duration, state=state, **kwargs)
+                loudness = excerpt.loudness()
+                num_try += 1
+                if num_try >= num_tries:
+                    break
+            return excerpt
+        cand = cls(torch.stack(rows), sr)
+        loud = cand.loudness().cpu()                                   # one launch, one synchronisation
+        above = (loud > loudness_cutoff).nonzero()
+        pick = int(above[0]) if above.numel() else num_tries - 1
+        for _ in range(pick + 1):                                      # the draws the sequential loop makes
+            state.uniform(lower_bound, upper_bound)
+        signal = cls(audio_path, offset=offsets[pick], duration=duration, **kwargs)
+        signal.metadata["offset"] = offsets[pick]
+        signal.metadata["duration"] = duration
+        signal._loudness = loud[pick: pick + 1].to(signal.device)
+        return signal
+
+    @classmethod
     def wave(cls, frequency: float, duration: float, sample_rate: int, num_channels: int = 1,
              shape: str = "sine", **kwargs):
         """Simple test tone ("sine", "square", "sawtooth", "triangle")."""
@@ -87,20 +168,51 @@ class AudioSignal(SpectralMixin, EffectMixin, LoudnessMixin, ImpulseResponseMixi
     @classmethod
     def batch(cls, audio_signals: list, pad_signals: bool = False, truncate_signals: bool = False,
               resample: bool = False, dim: int = 0):
-        """Concatenate signals along ``dim`` after equalising rate/length
-        (RuntimeError if they differ and no policy is given)."""
+        """Concatenate signals along ``dim`` after equalising rate/length (audio_signal.py:380-470;
+        RuntimeError if they differ and no policy is given).  Signals that need resampling are
+        grouped by (rate, length, channels, device) and every group is ONE resampler launch;
+        padding writes each signal once into the batch tensor (no per-signal F.pad + cat)."""
         rates = [s.sample_rate for s in audio_signals]
+        # As in the reference (audio_signal.py:437-438) the lengths are taken BEFORE resampling: the
+        # batch is as long as the longest ORIGINAL signal, and a resampled signal that ends up longer
+        # is cut by its negative pad length.
+        lengths = [s.signal_length for s in audio_signals]
         if len(set(rates)) != 1:
             if not resample:
                 raise RuntimeError(
                     f"Not all signals had the same sample rate! Got {rates}. "
                     f"All signals must have the same sample rate, or resample must be True. ")
+            groups = {}
             for s in audio_signals:
-                s.resample(rates[0])
-        lengths = [s.signal_length for s in audio_signals]
+                if s.sample_rate != rates[0]:
+                    key = (s.sample_rate, tuple(s.audio_data.shape[1:]), s.audio_data.device, s.audio_data.dtype)
+                    groups.setdefault(key, []).append(s)
+            for (rate, _, _, _), members in groups.items():
+                if len(members) == 1:
+                    members[0].resample(rates[0])
+                    continue
+                sizes = [m.batch_size for m in members]
+                stacked = cls(torch.cat([m.audio_data for m in members], 0), rate).resample(rates[0])
+                for m, part in zip(members, torch.split(stacked.audio_data, sizes, 0)):
+                    m.audio_data = part
+                    m.sample_rate = rates[0]
         if len(set(lengths)) != 1:
             if pad_signals:
                 longest = max(lengths)
+                if dim == 0 and len({(s.num_channels, s.audio_data.device, s.audio_data.dtype) for s in audio_signals}) == 1:
+                    first = audio_signals[0].audio_data
+                    total = sum(s.batch_size for s in audio_signals)
+                    out_data = torch.zeros((total, first.shape[1], longest), dtype=first.dtype, device=first.device)
+                    at = 0
+                    for s in audio_signals:
+                        n = min(s.signal_length, longest)
+                        out_data[at: at + s.batch_size, :, :n] = s.audio_data[..., :n]
+                        # the reference pads every input signal in place; keep that observable effect
+                        s.audio_data = out_data[at: at + s.batch_size]
+                        at += s.batch_size
+                    out = cls(out_data, sample_rate=audio_signals[0].sample_rate)
+                    out.path_to_file = [s.path_to_file for s in audio_signals]
+                    return out
                 for s in audio_signals:
                     s.zero_pad(0, longest - s.signal_length)
             elif truncate_signals:
@@ -116,24 +228,37 @@ class AudioSignal(SpectralMixin, EffectMixin, LoudnessMixin, ImpulseResponseMixi
         return out
 
     # ------------------------------------------------------------------ I/O
-    def load_from_file(self, audio_path, offset: float, duration: float = None, device: str = "cpu"):
-        """File decoding is outside the accelerated path (I/O
-        is out of scope); supported only when ``soundfile`` is installed."""
-        try:
-            import soundfile
-        except ImportError as e:
-            raise RuntimeError("loading audio files needs the optional `soundfile` package") from e
-        info = soundfile.info(str(audio_path))
-        start = int(offset * info.samplerate)
-        frames = -1 if duration is None else int(duration * info.samplerate)
-        data, sr = soundfile.read(str(audio_path), start=start, frames=frames, always_2d=True, dtype="float32")
-        if data.shape[0] == 0:
-            raise RuntimeError(f"Audio file {audio_path} with offset {offset} and duration {duration} is empty!")
-        self.audio_data = torch.from_numpy(data.T.copy()).unsqueeze(0)
+    def load_from_file(self, audio_path, offset: float, duration: float = None, device: str = None):
+        """Decode ``duration`` seconds from ``offset`` (audio_signal.py:473-531).  ``mem://`` sources
+        registered with ``util.register_memory_audio`` are sliced where they live (host or HBM);
+        real files need the optional ``soundfile`` package -- file decoding is outside the
+        accelerated path."""
+        mem = util.memory_audio(audio_path)
+        if mem is not None:
+            bank, sr = mem
+            start = int(offset * sr)
+            stop = bank.shape[-1] if duration is None else start + int(duration * sr)
+            data = bank[:, start:stop]
+            if data.shape[-1] == 0:
+                raise RuntimeError(f"Audio file {audio_path} with offset {offset} and duration {duration} is empty!")
+            self.audio_data = data.unsqueeze(0)
+        else:
+            try:
+                import soundfile
+            except ImportError as e:
+                raise RuntimeError("loading audio files needs the optional `soundfile` package") from e
+            info = soundfile.info(str(audio_path))
+            sr = info.samplerate
+            start = int(offset * sr)
+            frames = -1 if duration is None else int(duration * sr)
+            data, sr = soundfile.read(str(audio_path), start=start, frames=frames, always_2d=True, dtype="float32")
+            if data.shape[0] == 0:
+                raise RuntimeError(f"Audio file {audio_path} with offset {offset} and duration {duration} is empty!")
+            self.audio_data = torch.from_numpy(data.T.copy()).unsqueeze(0)
         self.original_signal_length = self.signal_length
         self.sample_rate = sr
         self.path_to_file = audio_path
-        return self.to(device)
+        return self if device is None else self.to(device)
 
     def load_from_array(self, audio_array, sample_rate: int, device: str = "cpu"):
         data = util.ensure_tensor(audio_array)

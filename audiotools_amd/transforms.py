@@ -484,14 +484,17 @@ class TensorLoader:
 
 
 def _resolve_loader(sources, weights, loader, who):
+    """``loader`` (any callable with the AudioLoader.__call__ signature, e.g. a TensorLoader over an
+    HBM-resident bank) wins; otherwise the reference's construction ``AudioLoader(sources, weights)``
+    (transforms.py:773, 836, 917) -- CSV files / folders through the optional soundfile package, or
+    lists of ``mem://`` sources."""
     if loader is not None:
         return loader
     if sources is None:
         return None
-    raise NotImplementedError(
-        f"{who}: file-backed `sources` need the reference's AudioLoader (file I/O is outside the "
-        f"accelerated path, SURVEY.md 2.1); pass loader=TensorLoader(bank, sample_rate) or any callable "
-        f"with the AudioLoader.__call__ signature")
+    from .data.datasets import AudioLoader
+
+    return AudioLoader(sources, weights)
 
 
 class BackgroundNoise(BaseTransform):

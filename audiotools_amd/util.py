@@ -3,10 +3,15 @@
 ``audiotools/core/util.py``: ``ensure_tensor`` :56-89, ``_get_value`` :92-96,
 ``random_state`` :99-126, ``seed`` :129-151, ``sample_from_dist`` :383-423,
 ``collate`` :426-479, ``prepare_batch`` :346-380)."""
+import csv
+import dataclasses
+import glob
 import numbers
+import os
 import random
 import typing
 from contextlib import contextmanager
+from pathlib import Path
 
 import numpy as np
 import torch
@@ -159,3 +164,114 @@ def prepare_batch(batch, device="cpu"):
     if hasattr(batch, "to") and hasattr(batch, "audio_data"):
         return batch.to(device)
     return batch
+
+
+# ------------------------------------------------------------------ audio sources
+AUDIO_EXTENSIONS = [".wav", ".flac", ".mp3", ".mp4"]
+MEMORY_PREFIX = "mem://"
+_memory_audio = {}
+
+
+@dataclasses.dataclass
+class Info:
+    """Length and rate of an audio source (reference core/util.py:20-30)."""
+    sample_rate: float
+    num_frames: int
+
+    @property
+    def duration(self) -> float:
+        return self.num_frames / self.sample_rate
+
+
+def register_memory_audio(name: str, audio: torch.Tensor, sample_rate: int) -> str:
+    """Make an in-memory recording addressable like a file: returns the path ``"mem://name"`` that
+    ``AudioSignal(path, offset=, duration=)``, ``AudioSignal.excerpt``, ``salient_excerpt`` and
+    ``AudioLoader`` accept.  ``audio`` is (C, T) or (T,), on ANY device: decoded audio that already
+    sits in HBM is excerpted by slicing, with no host round trip (file decoding itself is outside
+    the accelerated path)."""
+    a = audio if torch.is_tensor(audio) else torch.as_tensor(audio)
+    if a.ndim == 1:
+        a = a[None]
+    assert a.ndim == 2, "memory audio is (channels, samples)"
+    if a.dtype == torch.double:
+        a = a.float()
+    path = MEMORY_PREFIX + name
+    _memory_audio[path] = (a, int(sample_rate))
+    return path
+
+
+def memory_audio(path):
+    return _memory_audio.get(str(path))
+
+
+def info(audio_path) -> Info:
+    """Sample rate and length of a source without decoding it (core/util.py:33-53)."""
+    mem = memory_audio(audio_path)
+    if mem is not None:
+        return Info(sample_rate=mem[1], num_frames=int(mem[0].shape[-1]))
+    try:
+        import soundfile
+    except ImportError as e:
+        raise RuntimeError("reading audio files needs the optional `soundfile` package") from e
+    i = soundfile.info(str(audio_path))
+    return Info(sample_rate=i.samplerate, num_frames=i.frames)
+
+
+def find_audio(folder: str, ext: typing.List[str] = AUDIO_EXTENSIONS):
+    """Audio files below ``folder`` (core/util.py:218-250)."""
+    folder = Path(folder)
+    if str(folder).endswith(tuple(ext)):
+        if "*" in str(folder):
+            return glob.glob(str(folder), recursive=("**" in str(folder)))
+        return [folder]
+    files = []
+    for x in ext:
+        files += folder.glob(f"**/*{x}")
+    return files
+
+
+def read_sources(sources: typing.List[str], remove_empty: bool = True, relative_path: str = "",
+                 ext: typing.List[str] = AUDIO_EXTENSIONS):
+    """Sources -> list of lists of ``{"path": ...}`` rows (core/util.py:253-297): a source is a
+    CSV with a ``path`` column, a folder of audio files, or -- for audio that is already decoded --
+    a list of ``mem://`` paths / row dicts."""
+    files = []
+    relative_path = Path(relative_path)
+    for source in sources:
+        _files = []
+        if isinstance(source, (list, tuple)):
+            for x in source:
+                _files.append(dict(x) if isinstance(x, dict) else {"path": str(x)})
+            files.append(sorted(_files, key=lambda x: x["path"]))
+            continue
+        source = str(source)
+        if source.endswith(".csv"):
+            with open(source, "r") as f:
+                for x in csv.DictReader(f):
+                    if remove_empty and x["path"] == "":
+                        continue
+                    if x["path"] != "":
+                        x["path"] = str(relative_path / x["path"])
+                    _files.append(x)
+        else:
+            for x in find_audio(source, ext=ext):
+                _files.append({"path": str(relative_path / x)})
+        files.append(sorted(_files, key=lambda x: x["path"]))
+    return files
+
+
+def choose_from_list_of_lists(state: np.random.RandomState, list_of_lists: list, p: float = None):
+    """One item of a list of lists: the list by ``p``, the item uniformly (core/util.py:300-322)."""
+    source_idx = state.choice(list(range(len(list_of_lists))), p=p)
+    item_idx = state.randint(len(list_of_lists[source_idx]))
+    return list_of_lists[source_idx][item_idx], source_idx, item_idx
+
+
+@contextmanager
+def chdir(newdir):
+    curdir = os.getcwd()
+    try:
+        os.chdir(newdir)
+        yield
+    finally:
+        os.chdir(curdir)

@@ -21,9 +21,11 @@ fixes the global batch); shared tables (window, twiddles, mel units, band-split 
 bank, the IR bank) are built on rank 0 and broadcast once over RCCL; no collective on the data path.
 value = global items x seconds per item / (max over ranks of the K-step time / K).
 
-The north-star step is a HIP graph replay of the captured API calls by default (``--no-graph`` for
-eager launches): at 64 items per GPU the kernels take ~0.45 ms and Python dispatch of the same
-calls ~0.15 ms, which is what limits strong scaling, not the kernels.
+Launches are eager and asynchronous: the host enqueues step k+1 while the GPU runs step k, so
+Python dispatch (~0.15 ms per step) is hidden even at 64 items per GPU (0.44 ms of kernels).
+``--graph`` replays the step from a captured HIP graph instead; measured SLOWER on this stack
+(0.475 vs 0.437 ms per step at 64 items, 2.86 vs 2.82 ms at 512: profiles/r02_notes.md), so it is
+not the default.
 
 JSON extras: "roofline" (algorithmic HBM bytes of the dominant kernel / its HIP-event duration vs
 8 TB/s) and "cpu_baseline" (the oracle's port of the reference's CPU path -- bit-equal to the
@@ -221,7 +223,8 @@ def main():
     ap.add_argument("--cpu-items", type=int, default=None)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph replay (north_star)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the north-star step from a captured HIP graph instead of eager launches")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only (process group, sharding, table broadcast; gloo on a CPU-only host): no kernels")
     args = ap.parse_args()
@@ -289,7 +292,7 @@ def main():
 
         launch = "eager"
         step = lambda ev: api_step()
-        if not args.no_graph:
+        if args.graph:
             try:
                 graph = torch.cuda.CUDAGraph()
                 s = torch.cuda.Stream()
@@ -339,7 +342,12 @@ def main():
         t0 = time.perf_counter()
         kw_cpu = chain.batch_instantiate([1000 + lo + i for i in range(n_local)], proto)
         inst_ms = (time.perf_counter() - t0) * 1e3
-        kw = A.util.prepare_batch(kw_cpu, device)
+        n_cpu = args.cpu_items or 8
+        ir_cpu = kw_cpu["Compose"]["2.RoomImpulseResponse"]["ir_signal"].audio_data[:n_cpu].clone()
+        kw = A.util.prepare_batch(kw_cpu, device)     # (moves the AudioSignals of kw_cpu in place)
+        kw_cpu = {"Compose": {k: ({kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+                                  if isinstance(v, dict) else v) for k, v in kw_cpu["Compose"].items()}}
+        kw_cpu["Compose"]["2.RoomImpulseResponse"]["ir_signal"] = A.AudioSignal(ir_cpu, sr)
         res = {}
 
         def step(ev):

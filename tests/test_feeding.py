@@ -1,0 +1,168 @@
+"""Host feeding: AudioSignal.excerpt / salient_excerpt, AudioLoader.__call__,
+AudioSignal.batch(resample=, pad_signals=) and util.collate against the UNMODIFIED reference
+(audio_signal.py:180-286, 380-470; data/datasets.py:71-136), seed for seed, with the reference's file
+I/O leaves (torchaudio.info, librosa.load) redirected to the same in-memory recordings."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import audiotools_amd as A
+from audiotools_amd import util
+from audiotools_amd.data import AudioLoader
+
+
+def _recordings():
+    g = torch.Generator().manual_seed(0)
+    recs = {
+        "a": (0.2 * torch.randn(2, 4 * 44100, generator=g), 44100),
+        "b": (0.05 * torch.randn(1, 3 * 16000, generator=g), 16000),
+        "c": (0.3 * torch.randn(1, 5 * 22050, generator=g), 22050),
+        "short": (0.1 * torch.randn(1, 8000, generator=g), 16000),
+    }
+    recs["a"][0][:, : 2 * 44100] *= 1e-4          # two quiet seconds: salient_excerpt has to retry
+    recs["c"][0][:, 22050: 3 * 22050] = 0.0
+    return recs
+
+
+@pytest.fixture()
+def memory_sources(reference, monkeypatch):
+    recs = _recordings()
+    paths = {k: util.register_memory_audio(k, v[0], v[1]) for k, v in recs.items()}
+    by_path = {paths[k]: v for k, v in recs.items()}
+
+    def fake_info(path):
+        x, sr = by_path[str(path)]
+        return types.SimpleNamespace(sample_rate=sr, num_frames=x.shape[-1])
+
+    def fake_load(path, offset=0.0, duration=None, sr=None, mono=False):
+        x, rate = by_path[str(path)]
+        start = int(offset * rate)
+        stop = x.shape[-1] if duration is None else start + int(duration * rate)
+        return x[:, start:stop].numpy(), rate
+
+    import sys
+    monkeypatch.setattr(reference.core.util.torchaudio, "info", fake_info)
+    monkeypatch.setattr(sys.modules["librosa"], "load", fake_load)
+    return paths
+
+
+def _same_state(sa, sr):
+    return sa.rand() == sr.rand()
+
+
+def test_excerpt_and_salient_excerpt(reference, memory_sources):
+    for name in ("a", "b", "c"):
+        for seed in range(4):
+            sa, sr = np.random.RandomState(seed), np.random.RandomState(seed)
+            a = A.AudioSignal.excerpt(memory_sources[name], duration=0.5, state=sa)
+            r = reference.AudioSignal.excerpt(memory_sources[name], duration=0.5, state=sr)
+            assert torch.equal(a.audio_data, r.audio_data) and a.metadata["offset"] == r.metadata["offset"]
+            a = A.AudioSignal.salient_excerpt(memory_sources[name], loudness_cutoff=-30, duration=0.75, state=sa)
+            r = reference.AudioSignal.salient_excerpt(memory_sources[name], loudness_cutoff=-30, duration=0.75, state=sr)
+            assert torch.equal(a.audio_data, r.audio_data) and a.sample_rate == r.sample_rate
+            assert _same_state(sa, sr)
+
+
+def _loaders(reference, memory_sources):
+    lists = [[{"path": memory_sources["a"], "loudness": "-16.5"}, {"path": memory_sources["b"]}],
+             [{"path": memory_sources["c"]}, {"path": memory_sources["short"]}]]
+    ours = AudioLoader(sources=[list(l) for l in lists], weights=[0.3, 0.7])
+    theirs = reference.data.datasets.AudioLoader(sources=[], weights=[0.3, 0.7])
+    theirs.audio_lists = [sorted(l, key=lambda x: x["path"]) for l in lists]
+    theirs.sources = ["src0", "src1"]
+    theirs.audio_indices = [(i, j) for i, l in enumerate(theirs.audio_lists) for j in range(len(l))]
+    np.random.RandomState(0).shuffle(theirs.audio_indices)
+    ours.sources = ["src0", "src1"]
+    return ours, theirs
+
+
+@pytest.mark.parametrize("kw", [dict(sample_rate=22050, duration=1.0, loudness_cutoff=-40, num_channels=1),
+                                dict(sample_rate=44100, duration=0.5, loudness_cutoff=None, num_channels=2),
+                                dict(sample_rate=16000, duration=1.5, offset=0.25, num_channels=1),
+                                dict(sample_rate=16000, duration=0.5, global_idx=5, num_channels=1),
+                                dict(sample_rate=16000, duration=0.5, source_idx=1, item_idx=0, num_channels=2)])
+def test_audio_loader_call(reference, memory_sources, kw):
+    ours, theirs = _loaders(reference, memory_sources)
+    assert ours.audio_lists == theirs.audio_lists and ours.audio_indices == theirs.audio_indices
+    for seed in range(6):
+        sa, sr = np.random.RandomState(seed), np.random.RandomState(seed)
+        ia, ir = ours(sa, **kw), theirs(sr, **kw)
+        assert (ia["source_idx"], ia["item_idx"], ia["path"]) == (ir["source_idx"], ir["item_idx"], ir["path"])
+        assert ia["signal"].sample_rate == ir["signal"].sample_rate
+        assert ia["signal"].audio_data.shape == ir["signal"].audio_data.shape
+        assert torch.allclose(ia["signal"].audio_data, ir["signal"].audio_data, atol=1e-6)
+        assert {k: v for k, v in ia["signal"].metadata.items()} == {k: v for k, v in ir["signal"].metadata.items()}
+        assert _same_state(sa, sr)
+
+
+def test_audio_loader_with_transform(reference, memory_sources):
+    ours, theirs = _loaders(reference, memory_sources)
+    ours.transform = A.transforms.Compose(A.transforms.VolumeChange(), A.transforms.LowPass())
+    rt = reference.data.transforms
+    theirs.transform = rt.Compose(rt.VolumeChange(), rt.LowPass())
+    sa, sr = np.random.RandomState(3), np.random.RandomState(3)
+    ia, ir = ours(sa, 22050, 1.0), theirs(sr, 22050, 1.0)
+    fa = {k: float(v) for k, v in A.transforms._flatten(ia["transform_args"]).items()}
+    fr = {k: float(v) for k, v in A.transforms._flatten(ir["transform_args"]).items()}
+    assert fa == fr
+
+
+def test_batch_with_resample_and_padding(reference, memory_sources):
+    g = torch.Generator().manual_seed(4)
+    specs = [(44100, 2, 30000), (16000, 2, 12000), (16000, 2, 12000), (22050, 2, 9000), (44100, 2, 25000), (16000, 2, 7000)]
+    data = [0.1 * torch.randn(1, c, t, generator=g) for _, c, t in specs]
+    ours = [A.AudioSignal(d.clone(), sr) for d, (sr, _, _) in zip(data, specs)]
+    theirs = [reference.AudioSignal(d.clone(), sr) for d, (sr, _, _) in zip(data, specs)]
+    with pytest.raises(RuntimeError):
+        A.AudioSignal.batch([s.clone() for s in ours])
+    with pytest.raises(RuntimeError):
+        A.AudioSignal.batch([s.clone() for s in ours], resample=True)
+    ba = A.AudioSignal.batch(ours, resample=True, pad_signals=True)
+    br = reference.AudioSignal.batch(theirs, resample=True, pad_signals=True)
+    assert ba.sample_rate == br.sample_rate == 44100 and ba.audio_data.shape == br.audio_data.shape
+    assert torch.allclose(ba.audio_data, br.audio_data, atol=1e-6)
+    for s, r in zip(ours, theirs):      # the inputs are resampled and padded in place, as in the reference
+        assert s.sample_rate == r.sample_rate and torch.allclose(s.audio_data, r.audio_data, atol=1e-6)
+    bt = A.AudioSignal.batch([A.AudioSignal(d.clone(), 8000) for d in data], truncate_signals=True)
+    assert bt.signal_length == 7000
+    # collate() -> AudioSignal.batch(pad_signals=True) (core/util.py:426-479)
+    items = [{"signal": A.AudioSignal(d.clone(), 8000), "idx": i} for i, d in enumerate(data)]
+    ritems = [{"signal": reference.AudioSignal(d.clone(), 8000), "idx": i} for i, d in enumerate(data)]
+    ca, cr = A.util.collate(items), reference.core.util.collate(ritems)
+    assert torch.equal(ca["signal"].audio_data, cr["signal"].audio_data) and torch.equal(ca["idx"], cr["idx"])
+
+
+@pytest.mark.gpu
+def test_device_resident_loader_matches_host_loader():
+    """Sources registered in HBM: excerpt by slicing, salient_excerpt with ONE batched LUFS launch
+    over all candidate windows, polyphase resampling on the device -- same excerpts, same RNG state
+    afterwards as the sequential host form."""
+    recs = _recordings()
+    host = {k: util.register_memory_audio("h_" + k, v[0], v[1]) for k, v in recs.items()}
+    dev = {k: util.register_memory_audio("d_" + k, v[0].cuda(), v[1]) for k, v in recs.items()}
+    mk = lambda p: AudioLoader(sources=[[p["a"], p["b"]], [p["c"], p["short"]]], weights=[0.3, 0.7])
+    lh, ld = mk(host), mk(dev)
+    for kw in (dict(sample_rate=22050, duration=1.0, loudness_cutoff=-40, num_channels=1),
+               dict(sample_rate=16000, duration=0.75, loudness_cutoff=-25, num_channels=1),
+               dict(sample_rate=44100, duration=0.5, loudness_cutoff=None, num_channels=2)):
+        for seed in range(8):
+            sh, sd = np.random.RandomState(seed), np.random.RandomState(seed)
+            ih, id_ = lh(sh, **kw), ld(sd, **kw)
+            assert id_["signal"].audio_data.is_cuda and (ih["item_idx"], ih["source_idx"]) == (id_["item_idx"], id_["source_idx"])
+            assert ih["signal"].audio_data.shape == id_["signal"].audio_data.shape
+            err = (id_["signal"].audio_data.cpu() - ih["signal"].audio_data).abs().max() / ih["signal"].audio_data.abs().max().clamp_min(1e-9)
+            assert float(err) < 1e-4
+            assert sh.rand() == sd.rand()
+
+
+@pytest.mark.gpu
+def test_batch_grouped_resample_on_device():
+    g = torch.Generator().manual_seed(4)
+    specs = [(44100, 2, 30000), (16000, 2, 12000), (16000, 2, 12000), (22050, 2, 9000), (16000, 2, 12000)]
+    data = [0.1 * torch.randn(1, c, t, generator=g) for _, c, t in specs]
+    ref = A.AudioSignal.batch([A.AudioSignal(d.clone(), sr) for d, (sr, _, _) in zip(data, specs)], resample=True, pad_signals=True)
+    got = A.AudioSignal.batch([A.AudioSignal(d.clone().cuda(), sr) for d, (sr, _, _) in zip(data, specs)], resample=True, pad_signals=True)
+    assert got.audio_data.is_cuda and got.audio_data.shape == ref.audio_data.shape
+    assert float((got.audio_data.cpu() - ref.audio_data).abs().max() / ref.audio_data.abs().max()) < 1e-4

@@ -756,7 +756,7 @@ def test_loader_transforms_gpu_vs_cpu(name):
     else:
         bank = 0.1 * torch.randn(5, 2, 80000, generator=g)
         t = getattr(tfm, name)(loader=tfm.TensorLoader(bank, sr))
-    kw = t.batch_instantiate([3, 4, 5, 6], sig) if name != "GlobalVolumeNorm" else t.instantiate(3, sig)
+    kw = t.batch_instantiate([3, 4, 5, 6], sig)
     ref = t(sig.clone(), **kw).audio_data
     got = t(sig.clone().to("cuda"), **A.util.prepare_batch(kw, "cuda")).audio_data
     assert rel_err(got, ref) < REL, name
@@ -868,17 +868,18 @@ def test_cfg4_full_size_chain():
     B, T, SR = 1024, 240000, 48000
     chain, kw = _chain_kwargs_cfg4(B, T, SR, 1000)
     x = _device_batch(B, 1, T, 21)
-    kwd = A.util.prepare_batch(kw, "cuda")
-    out = chain(A.AudioSignal(x.clone(), SR), **kwd).audio_data
-    assert out.shape == (B, 1, T) and torch.isfinite(out).all()
     c = kw["Compose"]
     assert c["2.RoomImpulseResponse"]["ir_signal"].audio_data.shape == (B, 1, 2 * SR)
     idx = [0, 1, 517, 1023]
+    ir_subset = c["2.RoomImpulseResponse"]["ir_signal"].audio_data[idx].clone()   # prepare_batch moves signals IN PLACE
+    kw_perm_src = _permute_kwargs(kw, torch.arange(B))                            # host copy for the permuted run
+    kwd = A.util.prepare_batch(kw, "cuda")
+    out = chain(A.AudioSignal(x.clone(), SR), **kwd).audio_data
+    assert out.shape == (B, 1, T) and torch.isfinite(out).all()
     xs = x[idx].cpu()
     ref = restate.low_pass(xs, c["0.LowPass"]["cutoff"][idx], SR)
     ref = restate.equalizer(ref, SR, c["1.Equalizer"]["eq"][idx])
-    ref = restate.apply_ir(ref, c["2.RoomImpulseResponse"]["ir_signal"].audio_data[idx], SR,
-                           c["2.RoomImpulseResponse"]["drr"][idx], c["2.RoomImpulseResponse"]["eq"][idx])
+    ref = restate.apply_ir(ref, ir_subset, SR, c["2.RoomImpulseResponse"]["drr"][idx], c["2.RoomImpulseResponse"]["eq"][idx])
     assert rel_err(out[idx], ref) < 3 * REL          # three stages of the 1e-4 budget
     # apply_ir restores the peak of ITS input (effects.py:174-177): peak(out) == peak(after EQ)
     mid = A.AudioSignal(x.clone(), SR).low_pass(c["0.LowPass"]["cutoff"].cuda()).equalizer(c["1.Equalizer"]["eq"].cuda())
@@ -886,7 +887,7 @@ def test_cfg4_full_size_chain():
     out2 = chain(A.AudioSignal(x.clone(), SR), **kwd).audio_data
     assert torch.equal(out2, out)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
-    kwp = A.util.prepare_batch(_permute_kwargs(kw, perm), "cuda")
+    kwp = A.util.prepare_batch(_permute_kwargs(kw_perm_src, perm), "cuda")
     outp = chain(A.AudioSignal(x[perm.cuda()].clone(), SR), **kwp).audio_data
     assert rel_err(outp, out[perm.cuda()]) < 1e-5
 

@@ -77,8 +77,8 @@ def test_room_impulse_response_with_tensor_loader():
     assert kw["RoomImpulseResponse"]["ir_signal"].shape == (3, 1, 44100)
     out = t(s.clone(), **kw)
     assert torch.allclose(out.audio_data.abs().amax(-1), s.audio_data.abs().amax(-1), rtol=1e-4)
-    with pytest.raises(NotImplementedError):
-        tfm.RoomImpulseResponse(sources=["irs.csv"])
+    with pytest.raises(FileNotFoundError):       # file-backed sources go through AudioLoader(sources)
+        tfm.RoomImpulseResponse(sources=["/nonexistent/irs.csv"])
     bn = tfm.BackgroundNoise(loader=tfm.TensorLoader(torch.randn(4, 1, 44100, generator=g), 44100))
     kb = bn.batch_instantiate([4, 5, 6], s)
     noisy = bn(s.clone(), **kb)
