@@ -118,6 +118,8 @@ SIGNATURES = {
     "at_roll_pad_f32": (_i32, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "at_alter_drr_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p, _p]),
     "at_resample_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "at_resample_mfma_supported": (_i32, [_i32, _i32]),
+    "at_resample_mfma_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "at_fftconv_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "at_fftconv_circ_f32": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _p]),
     "at_lufs_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32]),

@@ -192,6 +192,114 @@ __global__ __launch_bounds__(1024) void resample_kernel(const ResampleArgs A) {
   }
 }
 
+
+// ---- polyphase resampler on the matrix cores ---------------------------------------------------
+// The same sparse polyphase sum as resample_kernel, shaped as the GEMM it is:
+//     Y[frame, phase] = sum_tap  X[frame, tap] * Wt[tap, phase],   X[f, k] = xp[f old + k]
+// with v_mfma_f32_16x16x4_f32 (exact f32, fma chain): a wave accumulates a tile of 16 frames x 16
+// phases, 4 taps per instruction, over the union support window of the phase block (192 of 581
+// taps for 441 -> 160).  Why MFMA for an HBM-class kernel: the VALU form needs one LDS read of x
+// per 4 FMAs and one weight load per 16 -- LDS (40 % of its cycles bank conflicts), the texture
+// addresser and the VALU were co-limiting at 22 % of the HBM roofline.  The MFMA form needs one
+// LDS read per 16 FMAs (A operand: one f32 per lane) and one weight float4 per 64, the arithmetic
+// moves to the otherwise idle matrix pipe at the same peak rate, and the K-slot permutation
+// MFMA_KOFF = {0, 16, 8, 24} makes every A read conflict-free for odd `old`
+// (lane (i, k) reads xs[i old + off_k + c]: 32 distinct banks per 32-lane group).
+struct ResMfmaArgs {
+  const float* x;        // (rows, T)
+  const float4* W;       // (NPB, NC, 2, 64) float4: tables.resample_mfma_bank
+  const int* lo;         // (NPB): first tap of the phase block's window
+  float* out;            // (rows, out_len)
+  int64_t T, out_len, rows;
+  int old_sr, new_sr, width, NPB, NC;
+  int frames_per_tile;   // FT, a multiple of 32
+  int tiles_per_row;
+  int xs_len;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResMfmaArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const int FT = A.frames_per_tile;
+  const int64_t row = blockIdx.x / A.tiles_per_row;
+  const int tile = blockIdx.x % A.tiles_per_row;
+  const float* __restrict__ xr = A.x + row * A.T;
+  const int64_t f0 = (int64_t)tile * FT;
+  const int t = threadIdx.x;
+  {  // stage the tile: xs[m] = xp[f0 old + m], xp[m] = x[clamp(m - width)]
+    const int64_t g_lo = f0 * A.old_sr - A.width;
+    const int n4 = (A.xs_len + 3) / 4;
+    if (g_lo >= 0 && g_lo + 4 * (int64_t)n4 <= A.T) {
+      const f4u* __restrict__ src = reinterpret_cast<const f4u*>(xr + g_lo);
+      float4* __restrict__ dst = reinterpret_cast<float4*>(xs);
+#pragma unroll 4
+      for (int i = t; i < n4; i += blockDim.x) {
+        const f4u v = src[i];
+        dst[i] = make_float4(v.x, v.y, v.z, v.w);
+      }
+    } else {
+#pragma unroll 4
+      for (int m = t; m < 4 * n4; m += blockDim.x) {
+        int64_t g = g_lo + m;
+        g = g < 0 ? 0 : (g >= A.T ? A.T - 1 : g);
+        xs[m] = xr[g];
+      }
+    }
+  }
+  __syncthreads();
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int j = lane & 15, k = lane >> 4;
+  const int koff = (k & 1) * 16 + (k >> 1) * 8;     // {0, 16, 8, 24}
+  const int n_fbp = FT / 32;                        // pairs of 16-frame blocks
+  float* __restrict__ orow = A.out + row * A.out_len;
+  for (int item = wave; item < A.NPB * n_fbp; item += nwaves) {
+    const int P = item % A.NPB;
+    const int fp = item / A.NPB;
+    const float* __restrict__ a0p = xs + (fp * 32 + j) * A.old_sr + A.lo[P] + koff;   // A[i = j][k]: frame j of block 0
+    const float* __restrict__ a1p = a0p + 16 * A.old_sr;                               // frame block 1
+    const float4* __restrict__ wp = A.W + (int64_t)P * A.NC * 128 + lane;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float4 w0 = wp[0], w1 = wp[64];
+#pragma unroll 1
+    for (int c = 0; c < A.NC; ++c) {
+      const int cn = c + 1 < A.NC ? c + 1 : c;       // prefetch the next chunk's weights
+      const float4 n0 = wp[cn * 128], n1 = wp[cn * 128 + 64];
+      __builtin_amdgcn_sched_barrier(0);             // issue them HERE: 16 MFMAs (512 cycles) cover the L2 latency
+      const float* __restrict__ p0 = a0p + 32 * c;
+      const float* __restrict__ p1 = a1p + 32 * c;
+      float a0[8], a1[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) { a0[s] = p0[s]; a1[s] = p1[s]; }
+      const float b[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b[s], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      w0 = n0; w1 = n1;
+      // keep the prefetched weights in registers: without this the compiler re-materialises them by
+      // loading chunk c at the top of iteration c (the bank is const __restrict__), i.e. it waits
+      // for L2 in front of the first MFMA of every chunk
+      asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w));
+    }
+    // D: lane holds rows 4 k + r (frames), column j (phase)
+    const int ph = 16 * P + j;
+    if (ph < A.new_sr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t fa = f0 + fp * 32 + 4 * k + r;
+        const int64_t oa = fa * A.new_sr + ph, ob = oa + 16 * (int64_t)A.new_sr;
+        if (oa < A.out_len) orow[oa] = acc0[r];
+        if (ob < A.out_len) orow[ob] = acc1[r];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -247,6 +355,51 @@ int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* wg, co
   int threads = (NG * (FT / RS_FB) + 63) / 64 * 64;   // one round of work items, whole waves
   if (threads > 1024) threads = 1024;
   hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(threads), lds, reinterpret_cast<hipStream_t>(stream), A);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+
+int at_resample_mfma_supported(int old_sr, int new_sr) {
+  // conflict-free A reads need an odd (gcd-reduced) source rate; even ones keep the VALU kernel
+  return (old_sr > 0 && new_sr > 0 && (old_sr & 1)) ? 1 : 0;
+}
+
+// MFMA form of at_resample_f32 (same result up to the order of the float32 sums).
+//   W, lo, NPB, NC: tables.resample_mfma_bank(old, new);  max_lo = max(lo).
+int at_resample_mfma_f32(const float* x, int64_t rows, int64_t T, const float* W, const int* lo, int old_sr, int new_sr,
+                         int width, int NPB, int NC, int max_lo, float* out, int64_t out_len, void* stream) {
+  if (rows == 0) return AT_OK;
+  if (!x || !W || !lo || !out || rows < 0 || T <= 0 || old_sr <= 0 || new_sr <= 0 || width <= 0 || NPB <= 0 || NC <= 0 ||
+      max_lo < 0 || out_len < 0 || 16 * NPB < new_sr)
+    return AT_ERR_INVALID;
+  if (!at_resample_mfma_supported(old_sr, new_sr)) return AT_ERR_UNSUPPORTED;
+  if (out_len == 0) return AT_OK;
+  ResMfmaArgs A;
+  A.x = x; A.W = reinterpret_cast<const float4*>(W); A.lo = lo; A.out = out; A.T = T; A.out_len = out_len; A.rows = rows;
+  A.old_sr = old_sr; A.new_sr = new_sr; A.width = width; A.NPB = NPB; A.NC = NC;
+  const int64_t frames = (out_len + new_sr - 1) / new_sr;
+  // tile: ~14.5k input samples of LDS (58 KB -> 2 workgroups per CU), a multiple of 32 frames
+  int FT = 14500 / old_sr / 32 * 32;
+  if (FT < 32) FT = 32;
+  if (FT > 1024) FT = 1024;
+  if (FT > (frames + 31) / 32 * 32) FT = (int)((frames + 31) / 32 * 32);
+  A.frames_per_tile = FT;
+  A.tiles_per_row = (int)((frames + FT - 1) / FT);
+  A.xs_len = FT * old_sr + max_lo + 32 * NC + 32;
+  const size_t lds = (size_t)((A.xs_len + 3) / 4 * 4) * 4;
+  if (lds > 160 * 1024) return AT_ERR_UNSUPPORTED;
+  {
+    int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_mfma_kernel));
+    if (e != AT_OK) return e;
+  }
+  const int64_t blocks = rows * A.tiles_per_row;
+  if (blocks > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
+  int64_t items = (int64_t)NPB * (FT / 32);
+  int threads = (int)(items < 16 ? items : 16) * 64;
+  // at least 4 waves so that staging a tile is not a one-wave job
+  if (threads < 256) threads = 256;
+  hipLaunchKernelGGL(resample_mfma_kernel, dim3((unsigned)blocks), dim3(threads), lds, reinterpret_cast<hipStream_t>(stream), A);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }

@@ -127,8 +127,17 @@ def broadcast_cfg5_tables(old_sr, new_sr, n_fft, n_mels, device, window_type="ha
         wg, base = tables.resample_grouped_bank(int(old_sr), int(new_sr))[:2]
         return (wg, base)
 
+    def mfma_bank():
+        W, lo = tables.resample_mfma_bank(int(old_sr), int(new_sr))[:2]
+        return (W, lo)
+
     if old != new:
-        broadcast_table(("resample_grouped", old, new), bank, device)
+        # the bank of whichever kernel kernels.resample() dispatches to (odd reduced source rate:
+        # the MFMA form; otherwise the VALU form)
+        if old & 1:
+            broadcast_table(("resample_mfma", old, new), mfma_bank, device)
+        else:
+            broadcast_table(("resample_grouped", old, new), bank, device)
     broadcast_stft_mel_tables(int(new_sr), n_fft, window_type, n_mels, device, fmin, fmax)
 
 

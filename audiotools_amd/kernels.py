@@ -515,20 +515,34 @@ def resample_supported(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float
     return need <= RESAMPLE_LDS_LIMIT
 
 
+_RESAMPLE_MFMA = os.environ.get("AT_RESAMPLE_MFMA", "1") != "0"     # development A/B switch, read once
+
+
 def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
     _require_native_ok(audio)
-    plan = tables.resample_grouped_bank(int(old_sr), int(new_sr))
-    if plan is None:
+    g = math.gcd(int(old_sr), int(new_sr))
+    old, new = int(old_sr) // g, int(new_sr) // g
+    if old == new:
         return audio
-    wg_np, base_np, old, new, width, NG, LG = plan
     dev = audio.device
-    wg, base = tables.device_table(("resample_grouped", old, new), dev, lambda: (wg_np, base_np))
     B, C, T = audio.shape
     audio = audio.contiguous()
     out_len = int(math.floor(new * T / old))
     out = torch.empty((B, C, out_len), dtype=torch.float32, device=dev)
-    code = _native.lib().at_resample_f32(_native.ptr(audio), B * C, T, _native.ptr(wg), _native.ptr(base), old, new, width,
-                                         NG, LG, _native.ptr(out), out_len, _native.current_stream(dev))
+    lib = _native.lib()
+    if _RESAMPLE_MFMA and lib.at_resample_mfma_supported(old, new):
+        W_np, lo_np, old, new, width, NPB, NC = tables.resample_mfma_bank(old, new)
+        need = (32 * old + int(lo_np.max()) + 32 * NC + 32 + 4) * 4       # one 32-frame tile of LDS
+        if need <= RESAMPLE_LDS_LIMIT:
+            W, lo = tables.device_table(("resample_mfma", old, new), dev, lambda: (W_np, lo_np))
+            code = lib.at_resample_mfma_f32(_native.ptr(audio), B * C, T, _native.ptr(W), _native.ptr(lo), old, new, width,
+                                            NPB, NC, int(lo_np.max()), _native.ptr(out), out_len, _native.current_stream(dev))
+            _native.check(code, "at_resample_mfma_f32")
+            return out
+    wg_np, base_np, old, new, width, NG, LG = tables.resample_grouped_bank(old, new)
+    wg, base = tables.device_table(("resample_grouped", old, new), dev, lambda: (wg_np, base_np))
+    code = lib.at_resample_f32(_native.ptr(audio), B * C, T, _native.ptr(wg), _native.ptr(base), old, new, width,
+                               NG, LG, _native.ptr(out), out_len, _native.current_stream(dev))
     _native.check(code, "at_resample_f32")
     return out
 

@@ -415,3 +415,55 @@ def resample_grouped_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: fl
                 seg[np.abs(seg) <= thr] = 0.0
                 wg[G, :, p] = seg
     return np.ascontiguousarray(wg.transpose(1, 0, 2)), base, old, new, width, NG, LG
+
+
+# K-slot -> tap offset inside a 32-tap chunk of the MFMA resampler: MFMA number s (0..7) of a chunk
+# consumes taps s + MFMA_KOFF[k], k = lane // 16.  Offsets 0/16 (lanes 0-31) and 8/24 (lanes 32-63)
+# make the 32 lanes of a ds_read_b32 group hit 32 distinct banks for every odd ``old``:
+# lane (i, k) reads xs[i*old + off_k + const]; i*old mod 32 takes 16 distinct values and adding 16
+# gives the other 16.
+MFMA_KOFF = (0, 16, 8, 24)
+
+
+@functools.lru_cache(None)
+def resample_mfma_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
+    """Bank layout of ``at_resample_mfma_f32`` (v_mfma_f32_16x16x4_f32 form of the sparse polyphase
+    resampler).  Output phases are cut into blocks of 16 (one MFMA column block); block P keeps the
+    taps of the union support window of its phases, ``lo[P] .. lo[P] + LW`` (LW a common multiple
+    of 32, zero filled).  The weights are stored in the order the kernel consumes them:
+        W[P, c, h, lane, e]  =  bank[16 P + lane % 16,  lo[P] + 32 c + (4 h + e) + MFMA_KOFF[lane // 16]]
+    i.e. one float4 per lane covers the B operands of 4 consecutive MFMAs, and a wave's load is 1 KB
+    contiguous.  Returns ``(W float32 (NPB, NC, 2, 64, 4), lo int32 (NPB,), old, new, width, NPB, NC)``
+    or None for equal rates."""
+    plan = resample_bank(old_sr, new_sr, zeros, rolloff)
+    if plan is None:
+        return None
+    bank, old, new, width = plan
+    b = bank.numpy()
+    K = b.shape[1]
+    thr = 1e-12 * np.abs(b).max()
+    NPB = (new + 15) // 16
+    lo = np.zeros(NPB, dtype=np.int32)
+    span = 0
+    for P in range(NPB):
+        rows = b[16 * P: min(16 * P + 16, new)]
+        nz = np.nonzero((np.abs(rows) > thr).any(0))[0]
+        lo[P] = nz[0]
+        span = max(span, int(nz[-1]) + 1 - int(nz[0]))
+    NC = (span + 31) // 32
+    LW = 32 * NC
+    W = np.zeros((NPB, NC, 2, 64, 4), dtype=np.float32)
+    lane = np.arange(64)
+    j, k = lane % 16, lane // 16
+    koff = np.asarray(MFMA_KOFF)[k]
+    for P in range(NPB):
+        ph = 16 * P + j
+        for c in range(NC):
+            for h in range(2):
+                for e in range(4):
+                    tap = lo[P] + 32 * c + 4 * h + e + koff
+                    ok = (ph < new) & (tap < K)
+                    vals = np.where(ok, b[np.minimum(ph, new - 1), np.minimum(tap, K - 1)], 0.0)
+                    vals = np.where(np.abs(vals) > thr, vals, 0.0)
+                    W[P, c, h, :, e] = vals
+    return W, lo, old, new, width, NPB, NC

@@ -221,6 +221,15 @@ int at_alter_drr_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, co
 int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* wg, const int* base, int old_sr, int new_sr,
                     int width, int NG, int LG, float* out, int64_t out_len, void* stream);
 
+/* The same resampler on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32): frames x phases x taps
+ * as a banded GEMM, one LDS read of x per 16 FMAs instead of per 4.  Odd reduced `old_sr` only
+ * (bank-conflict-free operand reads); at_resample_mfma_supported() tells.  W (NPB, NC, 2, 64, 4),
+ * lo (NPB): tables.resample_mfma_bank; max_lo = max(lo).
+ */
+int at_resample_mfma_supported(int old_sr, int new_sr);
+int at_resample_mfma_f32(const float* x, int64_t rows, int64_t T, const float* W, const int* lo, int old_sr, int new_sr,
+                         int width, int NPB, int NC, int max_lo, float* out, int64_t out_len, void* stream);
+
 /* ---- circular FFT convolution -----------------------------------------------------------
  * Replaces  audiotools/core/effects.py:102-121  (rfft x 3, irfft x 2 at length T, rescale).
  *   x (B,C,T), ir (B,Cir,T) with Cir == 1 or C (already padded/rolled), scale (B,Cir) or NULL,

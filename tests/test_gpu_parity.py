@@ -933,3 +933,35 @@ def test_cfg5_full_size_resample_mel(B):
     # the additionally reported (512, 128) parameters
     mel2 = A.AudioSignal(y[idx].clone(), 16000).mel_spectrogram(80, window_length=512, hop_length=128)
     assert rel_err(mel2, restate.mel_spectrogram(restate.stft(yr, 512, 128), 16000, 80)) < REL
+
+
+@pytest.mark.parametrize("old,new,T", [(441, 160, 50000), (147, 160, 20011), (3, 2, 7000), (3, 1, 9001), (5, 7, 3000),
+                                       (1, 2, 4000), (441, 160, 300), (21, 16, 100000)])
+def test_resample_mfma_and_valu_kernels_agree(old, new, T):
+    """The matrix-core form (at_resample_mfma_f32, odd reduced source rates) and the VALU form
+    (at_resample_f32) of the polyphase resampler through the raw C ABI, against the oracle: several
+    tiles per row, a partial last frame, rows shorter than one tile, up- and down-sampling."""
+    import math
+    from audiotools_amd import tables
+    lib = _native.lib()
+    x = synth.audio_batch(2, 2, T, seed=old + new, gaps=False, sample_rate=old)
+    xd = x.cuda().contiguous()
+    out_len = int(math.floor(new * T / old))
+    st = _native.current_stream(xd.device)
+    ref = restate.resample(x, old, new)
+    assert ref.shape[-1] == out_len
+    assert lib.at_resample_mfma_supported(old, new) == 1
+    W, lo, o_, n_, width, NPB, NC = tables.resample_mfma_bank(old, new)
+    Wd, lod = torch.from_numpy(W).cuda(), torch.from_numpy(lo).cuda()
+    y1 = torch.full((2, 2, out_len), float("nan"), device="cuda")
+    rc = lib.at_resample_mfma_f32(_native.ptr(xd), 4, T, _native.ptr(Wd), _native.ptr(lod), old, new, width, NPB, NC,
+                                  int(lo.max()), _native.ptr(y1), out_len, st)
+    assert rc == 0 and rel_err(y1, ref) < REL
+    wg, base, o_, n_, width, NG, LG = tables.resample_grouped_bank(old, new)
+    wgd, based = torch.from_numpy(wg).cuda(), torch.from_numpy(base).cuda()
+    y2 = torch.full((2, 2, out_len), float("nan"), device="cuda")
+    rc = lib.at_resample_f32(_native.ptr(xd), 4, T, _native.ptr(wgd), _native.ptr(based), old, new, width, NG, LG,
+                             _native.ptr(y2), out_len, st)
+    assert rc == 0 and rel_err(y2, ref) < REL
+    assert rel_err(y1, y2.cpu()) < 1e-5
+    assert lib.at_resample_mfma_supported(160, 147) == 0      # even reduced source rate: VALU kernel only
