@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("AT_LIB_PATH") or os.path.join(LIB_DIR, "libaudiotools_amd.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "firfft.hip", "irtools.hip", "specedit.hip", "fftconv.hip", "vocoder.hip"]
+SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "firfft.hip", "irtools.hip", "specedit.hip", "fftconv.hip", "vocoder.hip", "stft_generic.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -25,7 +25,7 @@ class NativeError(RuntimeError):
     """Raised when the HIP library is unavailable or an entry point fails."""
 
 
-HEADERS = ["at_common.h", "fft_wave.h"]
+HEADERS = ["at_common.h", "fft_wave.h", "generic_fft.h"]
 # per-source extra flags.  stft.hip: the SLP vectoriser turns the float2 butterflies into v_pk_*_f32,
 # which issue at half rate on gfx950 (no throughput gain) and cost ~110 v_mov per frame to build the
 # operand pairs (DESIGN.md 5.1); scalar code is shorter AND needs 30 fewer registers.
@@ -99,6 +99,7 @@ _i64, _i32, _p, _f32, _f64 = (ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
 SIGNATURES = {
     "at_stft_twiddles_host": (_i32, [_i32, _p]),
     "at_stft_native_supported": (_i32, [_i32]),
+    "at_stft_fused_supported": (_i32, [_i32]),
     "at_mel_units_host": (_i32, [_p, _i32, _i32, _p, _p]),
     "at_stft_mel_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),

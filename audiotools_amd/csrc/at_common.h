@@ -129,4 +129,17 @@ __device__ __forceinline__ int64_t pad_index(int64_t v, int64_t T, int mode) {
   }
 }
 
+// sample fetch with centre reflect padding (torch.stft center=True) applied on top of the outer
+// padding F.pad(audio, (pad, pad + right_pad), mode).  s indexes the outer-padded signal of length
+// T2 and may be out of range.
+__device__ __forceinline__ float fetch_padded(const float* __restrict__ xr, int64_t s, int64_t T, int64_t T2, int pad,
+                                              int pad_mode) {
+  int64_t u = s;
+  if (u < 0) u = -u;
+  if (u >= T2) u = 2 * (T2 - 1) - u;
+  if (u < 0) u = 0;
+  int64_t v = pad_index(u - pad, T, pad_mode);
+  return v < 0 ? 0.0f : xr[v];
+}
+
 }  // namespace at

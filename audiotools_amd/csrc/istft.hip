@@ -23,6 +23,7 @@
 // torch's zero padding to `length`).
 #include "at_common.h"
 #include "fft_wave.h"
+#include "generic_fft.h"
 
 namespace {
 
@@ -495,7 +496,8 @@ extern "C" {
 // plus the (rows, n_frames, n_fft) float frame buffer when hop is not n_fft / {2,4,8,16}
 int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft, int hop) {
   if (rows < 0 || n_frames <= 0 || n_fft <= 0 || hop <= 0) return AT_ERR_INVALID;
-  if (fused_shift(n_fft, hop)) return ((n_frames - 1) * hop + n_fft) * 4;
+  const bool fused_size = n_fft >= 32 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0;
+  if (fused_size && fused_shift(n_fft, hop)) return ((n_frames - 1) * hop + n_fft) * 4;
   return rows * n_frames * (int64_t)n_fft * 4;
 }
 
@@ -511,11 +513,24 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
   if (!X || !window || !twiddles || !out || rows < 0 || n_x <= 0 || hop <= 0 || length < 0 || lead < 0 ||
       n_frames < lead + n_x)
     return AT_ERR_INVALID;
-  if (!(n_fft >= 32 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0)) return AT_ERR_UNSUPPORTED;
+  const bool fused_size = n_fft >= 32 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0;
   if (n_frames >= (1LL << 31) / (hop > n_fft ? hop : n_fft) || length >= (1LL << 31) - n_fft) return AT_ERR_UNSUPPORTED;
   if (rows == 0 || length == 0) return AT_OK;
   if (!workspace || workspace_bytes < at_istft_workspace_bytes(rows, n_frames, n_fft, hop)) return AT_ERR_INVALID;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!fused_size) {
+    // generic sizes (4096 ..., non powers of two): mixed-radix frames + the gather kernel
+    if (lead != 0 || n_frames != n_x) return AT_ERR_UNSUPPORTED;
+    int rc = at::istft_frames_generic(X, rows, n_frames, window, twiddles, n_fft, reinterpret_cast<float*>(workspace), st);
+    if (rc != AT_OK) return rc;
+    const int64_t total = rows * length;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const float*>(workspace),
+                       window, out, rows, (int)n_frames, n_fft, hop, length);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+  }
   const int M = n_fft / 2;
   const int FW = 64 / (M / 16);
   const int sh = fused_shift(n_fft, hop);

@@ -29,6 +29,7 @@
 //    dense (F x n_mels) GEMM: 2 flop/bin instead of 2*n_mels flop/bin.
 #include "at_common.h"
 #include "fft_wave.h"
+#include "generic_fft.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -76,18 +77,7 @@ struct StftArgs {
   int debug;               // development: 1 = compute but never store, 2 = store only (no FFT)
 };
 
-// sample fetch with centre reflect padding (torch.stft center=True) applied on
-// top of the outer padding (F.pad(audio, (pad, pad+right_pad), mode)).
-__device__ __forceinline__ float fetch_padded(const float* __restrict__ xr, int64_t s, int64_t T, int64_t T2, int pad,
-                                              int pad_mode) {
-  // s: index into the outer-padded signal of length T2, may be out of range
-  int64_t u = s;
-  if (u < 0) u = -u;
-  if (u >= T2) u = 2 * (T2 - 1) - u;
-  if (u < 0) u = 0;
-  int64_t v = at::pad_index(u - pad, T, pad_mode);
-  return v < 0 ? 0.0f : xr[v];
-}
+using at::fetch_padded;
 
 // ---- mel "unit" tables (built by at_mel_units_host) --------------------------------------
 // The Slaney filterbank is banded: band m is non-zero on a short run of bins.  Bins are cut
@@ -874,8 +864,18 @@ int at_stft_twiddles_host(int n_fft, float* out) {
   return AT_OK;
 }
 
-int at_stft_native_supported(int n_fft) {
+// 1 when the fused wave-FFT kernels of this file cover n_fft (powers of two, 32 ... 2048): fused mel,
+// register reuse, the adjoint kernels of istft.hip.
+int at_stft_fused_supported(int n_fft) {
   return (n_fft >= 32 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0) ? 1 : 0;
+}
+
+// 1 when SOME native kernel covers n_fft: the fused ones, or the generic mixed-radix transform
+// (even n_fft <= 16384 whose half factors into 2, 3, 5: 4096, 8192, 400, 1200, 1920 ...).
+int at_stft_native_supported(int n_fft) {
+  if (at_stft_fused_supported(n_fft)) return 1;
+  int radix[16];
+  return at::generic_fft_plan(n_fft, radix) > 0 ? 1 : 0;
 }
 
 // Host helper: compress a dense (n_mels, n_bins) float32 filterbank into the unit tables
@@ -945,6 +945,18 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   if (!at_stft_native_supported(n_fft)) return AT_ERR_UNSUPPORTED;
   const bool mel = mel_out != nullptr;
   if (!stft_out) return AT_ERR_INVALID;  // stft_data is always produced (audio_signal.py:1210)
+  if (!at_stft_fused_supported(n_fft)) {
+    // generic sizes: mixed-radix workgroup FFT (csrc/stft_generic.hip); no fused mel stage
+    if (mel) return AT_ERR_UNSUPPORTED;
+    const int64_t T2g = T + 2 * (int64_t)pad + right_pad;
+    if (n_fft / 2 >= T2g) return AT_ERR_INVALID;
+    if (pad_mode == at::PAD_REFLECT && (pad >= T || pad + right_pad >= T)) return AT_ERR_INVALID;
+    if (frame_lo + n_frames_out > 1 + T2g / hop) return AT_ERR_INVALID;
+    if (T >= (1LL << 31) || n_frames_out >= (1LL << 31) / (n_fft / 2 + 1)) return AT_ERR_UNSUPPORTED;
+    if (n_frames_out == 0) return AT_OK;
+    return at::stft_generic(x, rows, T, window, twiddles, n_fft, hop, pad, right_pad, pad_mode, frame_lo, n_frames_out,
+                            stft_out, reinterpret_cast<hipStream_t>(stream));
+  }
   if (mel && (!mel_unit_info || !mel_unit_w || (n_units != 128 && n_units != 256 && n_units != 384) || n_mels <= 0))
     return AT_ERR_INVALID;
   const int M = n_fft / 2;

@@ -38,7 +38,14 @@ def stft_frames(T: int, n_fft: int, hop: int, pad: int, right_pad: int, match_st
 
 
 def stft_native_supported(n_fft: int) -> bool:
+    """Some native kernel covers this transform size (fused wave-FFT kernels or the generic
+    mixed-radix one)."""
     return bool(_native.lib().at_stft_native_supported(int(n_fft)))
+
+
+def stft_fused_supported(n_fft: int) -> bool:
+    """The fused wave-FFT kernels cover it (powers of two up to 2048): fused mel, adjoint kernels."""
+    return bool(_native.lib().at_stft_fused_supported(int(n_fft)))
 
 
 def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *, pad: int = 0,
@@ -126,8 +133,9 @@ def _nola_ok_cached(window: torch.Tensor, n_fft: int, hop: int) -> bool:
 
 
 def istft_fused_supported(n_fft: int, hop: int) -> bool:
-    """True when at_istft_f32 takes its fused single-pass path (hop = n_fft / {2,4,8,16})."""
-    return any(hop * r == n_fft for r in (2, 4, 8, 16))
+    """True when at_istft_f32 takes its fused single-pass path (power-of-two n_fft <= 2048,
+    hop = n_fft / {2,4,8,16})."""
+    return stft_fused_supported(n_fft) and any(hop * r == n_fft for r in (2, 4, 8, 16))
 
 
 def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, length: int,
@@ -225,7 +233,7 @@ def stft_mel_adjoint(X_bcfn: torch.Tensor, gmel_bcmn: torch.Tensor, bin_table, w
 
 
 def istft_adjoint_supported(n_fft: int, hop: int) -> bool:
-    return istft_fused_supported(n_fft, hop) and (n_fft // 2) % hop == 0 and stft_native_supported(n_fft)
+    return istft_fused_supported(n_fft, hop) and (n_fft // 2) % hop == 0 and stft_fused_supported(n_fft)
 
 
 def istft_adjoint(grad_bct: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, n_frames: int) -> torch.Tensor:

@@ -103,7 +103,7 @@ class _NativeIstft(torch.autograd.Function):
 def _native_autograd_ok(audio: torch.Tensor, n_fft: int, hop: int, match_stride: bool) -> bool:
     """A HIP float32 tensor that needs gradients can use the native forward + adjoint pair."""
     return (audio.is_cuda and audio.dtype == torch.float32 and audio.requires_grad and torch.is_grad_enabled()
-            and not match_stride and kernels.stft_native_supported(n_fft) and kernels.istft_fused_supported(n_fft, hop)
+            and not match_stride and kernels.stft_fused_supported(n_fft) and kernels.istft_fused_supported(n_fft, hop)
             and audio.shape[-1] > n_fft // 2)
 
 
@@ -221,7 +221,7 @@ class SpectralMixin:
             kwargs.get("match_stride"), kwargs.get("padding_type"))
         audio = self.audio_data
         units = None
-        if kernels.stft_native_supported(n_fft) and audio.is_cuda:
+        if kernels.stft_fused_supported(n_fft) and audio.is_cuda:
             units = tables.mel_units_or_none(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, audio.device)
         if kernels.is_native(audio) and units is not None:
             dev = audio.device

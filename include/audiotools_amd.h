@@ -41,7 +41,11 @@ extern "C" {
  *
  * at_stft_twiddles_host: fills out_host[2*n_fft] with (cos, -sin)(2*pi*k/n_fft), k < n_fft
  *   (float64 math, rounded to float32).  Upload once per n_fft and pass as `twiddles`.
- * at_stft_native_supported: 1 if n_fft is a power of two in [32, 2048].
+ * at_stft_fused_supported:  1 if n_fft is a power of two in [32, 2048] (fused wave-FFT kernels: mel stage,
+ *                           register reuse, adjoint kernels).
+ * at_stft_native_supported: 1 if SOME native kernel covers n_fft: the fused ones, or the generic mixed-radix
+ *                           transform (even n_fft <= 16384 with n_fft/2 = 2^a 3^b 5^c: 4096, 8192, 400, 1200, 1920 ...;
+ *                           no fused mel: mel_out must be NULL for those sizes).
  * at_stft_mel_f32:
  *   x          (rows, T) f32
  *   window     (n_fft) f32            AudioSignal.get_window (audio_signal.py:1009-1039)
@@ -63,6 +67,7 @@ extern "C" {
  */
 int at_stft_twiddles_host(int n_fft, float* out_host);
 int at_stft_native_supported(int n_fft);
+int at_stft_fused_supported(int n_fft);
 int at_mel_units_host(const float* basis_host, int n_mels, int n_bins, int* unit_info_host, float* unit_w_host);
 int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
                     int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,

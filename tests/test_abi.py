@@ -44,8 +44,11 @@ def test_host_only_entry_points(lib):
     assert np.allclose(out[0::2], np.cos(2 * np.pi * k / 16), atol=1e-7)
     assert np.allclose(out[1::2], -np.sin(2 * np.pi * k / 16), atol=1e-7)
     assert lib.at_stft_native_supported(2048) == 1
-    assert lib.at_stft_native_supported(4096) == 0
-    assert lib.at_stft_native_supported(150) == 0
+    assert lib.at_stft_fused_supported(2048) == 1 and lib.at_stft_fused_supported(4096) == 0
+    for n in (4096, 8192, 16384, 400, 1200, 1920, 150, 6):      # generic mixed-radix sizes (n/2 = 2^a 3^b 5^c)
+        assert lib.at_stft_native_supported(n) == 1, n
+    for n in (401, 14, 2 * 77, 32768):                           # odd, or a prime factor > 5, or too long
+        assert lib.at_stft_native_supported(n) == 0, n
     assert lib.at_lufs_workspace_bytes(512, 2, 441000, 17640, 4410) >= 512 * 2 * 100 * 8
 
 

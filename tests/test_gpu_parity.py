@@ -965,3 +965,38 @@ def test_resample_mfma_and_valu_kernels_agree(old, new, T):
     assert rc == 0 and rel_err(y2, ref) < REL
     assert rel_err(y1, y2.cpu()) < 1e-5
     assert lib.at_resample_mfma_supported(160, 147) == 0      # even reduced source rate: VALU kernel only
+
+
+@pytest.mark.parametrize("n_fft,hop,wt", [(4096, 1024, "hann"), (8192, 2048, "sqrt_hann"), (16384, 4096, "hann"), (400, 160, "hann"),
+                                          (1200, 300, "sqrt_hann"), (1920, 480, "hann"), (100, 33, "hann"), (4096, 1000, "average")])
+def test_stft_generic_sizes_vs_oracle(n_fft, hop, wt):
+    """Transform sizes beyond the fused wave-FFT kernels (the default window at 96 / 192 kHz is
+    4096 / 8192, audio_signal.py:1066-1070; speech front ends use 400 / 1200 / 1920): the mixed-radix
+    workgroup FFT of csrc/stft_generic.hip, forward and inverse, against the oracle."""
+    assert kernels.stft_native_supported(n_fft) and not kernels.stft_fused_supported(n_fft)
+    T = 5 * n_fft + 137
+    x = synth.audio_batch(2, 2, T, seed=n_fft, gaps=False)
+    s = A.AudioSignal(x.clone(), 16000).to("cuda")
+    X = s.stft(n_fft, hop, wt)
+    ref = restate.stft(x, n_fft, hop, wt)
+    assert X.shape == ref.shape and X.stride()[-2] == 1
+    assert rel_err(X, ref) < REL
+    if wt != "average" or hop * 4 <= n_fft:
+        y = s.istft(n_fft, hop, wt).audio_data
+        yr = restate.istft(ref, n_fft, hop, wt, False, T)
+        assert rel_err(y, yr) < REL and float((y.cpu() - x).abs().max()) < 1e-4
+
+
+def test_stft_generic_match_stride_and_mel():
+    x = synth.audio_batch(2, 1, 40000 + 13, seed=3, gaps=False)
+    s = A.AudioSignal(x.clone(), 96000).to("cuda")
+    assert s.stft_params.window_length == 4096                      # the reference's default at 96 kHz
+    X = s.stft(match_stride=True, window_type="sqrt_hann")
+    ref = restate.stft(x, 4096, 1024, "sqrt_hann", True, "reflect")
+    assert rel_err(X, ref) < REL
+    y = s.istft(match_stride=True, window_type="sqrt_hann").audio_data
+    assert y.shape == x.shape and float((y.cpu() - x).abs().max()) < 1e-4
+    mel = s.mel_spectrogram(80)                                     # dense basis on the native spectrum
+    Xr = restate.stft(x, 4096, 1024)
+    assert rel_err(mel, restate.mel_spectrogram(Xr, 96000, 80)) < REL
+    assert rel_err(s.stft_data, Xr) < REL
