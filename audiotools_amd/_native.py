@@ -111,6 +111,7 @@ SIGNATURES = {
     "at_fir_fft_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "at_spec_mask_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _f32, _f32, _p]),
     "at_spec_phase_shift_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _p, _p]),
+    "at_spec_polar_elem_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _p, _p, _i32, _p]),
     "at_spec_maxpow_f32": (_i32, [_p, _i64, _p, _p]),
     "at_spec_mask_lowmag_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _p, _p, _f32, _i32, _f32, _p]),
     "at_phase_vocoder_frames": (_i64, [_i64, _i64, _i64]),

@@ -106,6 +106,53 @@ __global__ __launch_bounds__(256) void spec_mask_lowmag_kernel(const float2* __r
   }
 }
 
+
+// ---- per-ELEMENT polar edits: corrupt_phase / CorruptPhase, TimeNoise / FrequencyNoise --------
+// The per-element operands arrive in the LOGICAL layout (rows, F, N) (they are made by
+// torch.randn_like(phase) or come from the host as a (B, C, F, N) array), the spectrum is
+// physically (rows, N, F): a 32 x 32 tile goes through LDS so that both sides are read / written
+// with unit stride.
+//   mode 0: Y = X * e^{i shift}                          dsp.py:354-370, transforms.py:1250-1278
+//   mode 1: Y = (X == 0) ? a * e^{i b} : X               transforms.py:1456-1536 (the holes a mask left
+//           are refilled with magnitude ~ N(0,1), phase ~ N(0,1); untouched bins keep their value)
+__global__ __launch_bounds__(256) void spec_polar_elem_kernel(const float2* __restrict__ S, float2* __restrict__ Y, int N,
+                                                              int F, const float* __restrict__ a, const float* __restrict__ b,
+                                                              int mode) {
+  __shared__ float2 tile[32][33];
+  const int64_t row = blockIdx.z;
+  const int f0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float* __restrict__ ar = a ? a + row * (int64_t)F * N : nullptr;
+  const float* __restrict__ br = b + row * (int64_t)F * N;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = f0 + ty + 8 * r, n = n0 + tx;
+    float2 v = make_float2(0.f, 0.f);
+    if (f < F && n < N) {
+      float sn, cs;
+      sincosf(br[(int64_t)f * N + n], &sn, &cs);
+      const float m = mode == 1 ? ar[(int64_t)f * N + n] : 1.0f;
+      v = make_float2(m * cs, m * sn);
+    }
+    tile[ty + 8 * r][tx] = v;      // tile[f][n]
+  }
+  __syncthreads();
+  const float2* __restrict__ Sr = S + row * (int64_t)N * F;
+  float2* __restrict__ Yr = Y + row * (int64_t)N * F;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + ty + 8 * r, f = f0 + tx;
+    if (f < F && n < N) {
+      const float2 x = Sr[(int64_t)n * F + f];
+      const float2 e = tile[tx][ty + 8 * r];
+      float2 y;
+      if (mode == 0) y = make_float2(x.x * e.x - x.y * e.y, x.x * e.y + x.y * e.x);
+      else y = (x.x == 0.f && x.y == 0.f) ? e : x;
+      Yr[(int64_t)n * F + f] = y;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -181,5 +228,28 @@ int at_spec_mask_lowmag_f32(const float* src, float* X, int64_t B, int64_t C, in
   AT_LAUNCH_CHECK();
   return AT_OK;
 }
+
+// Per-element polar edits of stft_data.  src / X: (B, C, N, F) complex64 (src may equal X or be NULL
+// for in place); a, b: (B, C, F, N) float32 in the LOGICAL layout of the reference's tensors.
+//   mode 0: X = src * e^{i b}  (a unused, may be NULL)      shift_phase / corrupt_phase with a full tensor
+//   mode 1: X = (src == 0) ? a e^{i b} : src                TimeNoise / FrequencyNoise refill
+int at_spec_polar_elem_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const float* a,
+                           const float* b, int mode, void* stream) {
+  if (B == 0) return AT_OK;
+  if (!X || !b || B < 0 || C <= 0 || N <= 0 || F <= 0 || (mode != 0 && mode != 1) || (mode == 1 && !a)) return AT_ERR_INVALID;
+  const int64_t rows = B * C;
+  if (N >= (1LL << 31) || F >= (1LL << 31) || (F + 31) / 32 > 65535) return AT_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float2* S = reinterpret_cast<const float2*>(src ? src : X);
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    dim3 grid((unsigned)((N + 31) / 32), (unsigned)((F + 31) / 32), (unsigned)nr);
+    hipLaunchKernelGGL(spec_polar_elem_kernel, grid, dim3(256), 0, st, S + r0 * N * F, reinterpret_cast<float2*>(X) + r0 * N * F,
+                       (int)N, (int)F, a ? a + r0 * F * N : nullptr, b + r0 * F * N, mode);
+    AT_LAUNCH_CHECK();
+  }
+  return AT_OK;
+}
+
 
 }  // extern "C"

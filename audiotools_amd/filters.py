@@ -53,6 +53,16 @@ def resample_torch(audio: torch.Tensor, old_sr: int, new_sr: int) -> torch.Tenso
     return y[..., :out_len]
 
 
+def _broadcasts_to(t, shape) -> bool:
+    t = util.ensure_tensor(t)
+    if t.ndim == 0 or t.ndim > len(shape):
+        return False
+    try:
+        return tuple(torch.broadcast_shapes(tuple(t.shape), tuple(shape))) == tuple(shape)
+    except RuntimeError:
+        return False
+
+
 def _per_item_native(X, *params) -> bool:
     """The in-place stft_data kernels apply: native spectrum and every parameter is a scalar or
     has one value per item (shape (), (1,), (B,), (B,1,1,1))."""
@@ -221,11 +231,26 @@ class DSPMixin:
         if _per_item_native(self.stft_data, shift) and util.ensure_tensor(shift).dtype in (torch.float32, torch.int64):
             self.stft_data = kernels.spec_phase_shift(self.stft_data, util.ensure_tensor(shift, ndim=1))
             return self
+        if kernels.spec_native(self.stft_data) and _broadcasts_to(shift, self.stft_data.shape):
+            # a full (B, C, F, N) / (C, F, N) shift tensor (CorruptPhase): one tiled pass instead of
+            # angle, add, abs, exp, mul
+            sh = util.ensure_tensor(shift)
+            if sh.dtype in (torch.float32, torch.float64, torch.int64):
+                self.stft_data = kernels.spec_polar_elem(self.stft_data, sh)
+                return self
         shift = util.ensure_tensor(shift, ndim=self.phase.ndim).to(self.device)
         self.phase = self.phase + shift
         return self
 
     def corrupt_phase(self, scale):
+        if self.stft_data is None:
+            self.stft()
+        if kernels.spec_native(self.stft_data):
+            # same draws as the reference (one torch.randn_like of the phase), applied in one pass
+            scale = util.ensure_tensor(scale, ndim=4).to(self.device)
+            noise = torch.randn(self.stft_data.shape, dtype=torch.float32, device=self.device)
+            self.stft_data = kernels.spec_polar_elem(self.stft_data, scale * noise)
+            return self
         scale = util.ensure_tensor(scale, ndim=self.phase.ndim).to(self.device)
         self.phase = self.phase + scale * torch.randn_like(self.phase)
         return self

@@ -399,6 +399,19 @@ def spec_phase_shift(X: torch.Tensor, shift: torch.Tensor):
     return Y
 
 
+def spec_polar_elem(X: torch.Tensor, b: torch.Tensor, a: torch.Tensor = None):
+    """Per-element polar edit of a native spectrum: ``X * exp(1j * b)`` (``a`` None) or ``a * exp(1j * b)``
+    where ``X == 0`` and ``X`` elsewhere.  ``a`` / ``b``: float32, broadcastable to X's logical shape."""
+    Y, Yr, Xr, B, C, N, F = _spec_out(X)
+    shape = (B, C, F, N)
+    bb = b.to(X.device, torch.float32).expand(shape).contiguous()
+    aa = None if a is None else a.to(X.device, torch.float32).expand(shape).contiguous()
+    code = _native.lib().at_spec_polar_elem_f32(_native.ptr(Xr), _native.ptr(Yr), B, C, N, F, _native.ptr(aa), _native.ptr(bb),
+                                                0 if a is None else 1, _native.current_stream(X.device))
+    _native.check(code, "at_spec_polar_elem_f32")
+    return Y
+
+
 def spec_mask_lowmag(X: torch.Tensor, cutoff_db: torch.Tensor, val: float, top_db=80.0):
     Y, Yr, Xr, B, C, N, F = _spec_out(X)
     cut = cutoff_db.reshape(-1).to(X.device, torch.float64).expand(B).contiguous()

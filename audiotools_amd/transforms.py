@@ -643,6 +643,18 @@ class TimeMask(SpectralTransform):
 
 
 def _fill_masked_with_noise(signal):
+    """transforms.py:1478-1494 / 1520-1536: the bins a mask zeroed (magnitude AND phase 0) get
+    magnitude and phase drawn from N(0, 1).  On the HIP path the two torch.randn_like draws are kept
+    (same generator consumption as the reference) and everything else -- magnitude, phase, the hole
+    mask, two indexed assignments and two polar recombinations -- is one tiled kernel."""
+    from . import kernels
+
+    X = signal.stft_data
+    if kernels.spec_native(X):
+        mag_r = torch.randn(X.shape, dtype=torch.float32, device=X.device)
+        phase_r = torch.randn(X.shape, dtype=torch.float32, device=X.device)
+        signal.stft_data = kernels.spec_polar_elem(X, phase_r, mag_r)
+        return signal
     mag, phase = signal.magnitude, signal.phase
     hole = (mag == 0.0) * (phase == 0.0)
     mag = torch.where(hole, torch.randn_like(mag), mag)

@@ -181,6 +181,11 @@ int at_spec_mask_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N
                      const double* hi, const float* grid, float fill_re, float fill_im, void* stream);
 int at_spec_phase_shift_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const float* shift,
                             void* stream);
+/* per-ELEMENT polar edits (operands a, b in the reference's logical (B, C, F, N) layout):
+ *   mode 0: X = src * e^{i b}                  audiotools/core/dsp.py:354-370 corrupt_phase, data/transforms.py:1250-1278
+ *   mode 1: X = (src == 0) ? a e^{i b} : src   data/transforms.py:1456-1536 TimeNoise / FrequencyNoise refill */
+int at_spec_polar_elem_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const float* a,
+                           const float* b, int mode, void* stream);
 int at_spec_maxpow_f32(const float* X, int64_t n, float* out, void* stream);
 int at_spec_mask_lowmag_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const double* cutoff_db,
                             const float* maxpow, float top_db, int use_top_db, float val, void* stream);

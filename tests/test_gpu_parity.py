@@ -1000,3 +1000,44 @@ def test_stft_generic_match_stride_and_mel():
     Xr = restate.stft(x, 4096, 1024)
     assert rel_err(mel, restate.mel_spectrogram(Xr, 96000, 80)) < REL
     assert rel_err(s.stft_data, Xr) < REL
+
+
+@pytest.mark.parametrize("n_fft,T", [(2048, 40000), (512, 9000 + 7)])
+def test_spec_polar_elem_kernel(n_fft, T):
+    """Per-element polar edits (csrc/specedit.hip spec_polar_elem_kernel) against the torch
+    formulation of dsp.py:354-370 / transforms.py:1478-1494: phase rotation by a full tensor, and
+    the noise refill of masked holes."""
+    x = synth.audio_batch(3, 2, T, seed=n_fft, gaps=False)
+    s = A.AudioSignal(x.clone(), 44100).to("cuda")
+    X = s.stft(n_fft, n_fft // 4).clone()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sh = torch.randn(X.shape, device="cuda", generator=g)
+    ref = X.abs() * torch.exp(1j * (X.angle() + sh))
+    assert rel_err(kernels.spec_polar_elem(X, sh), ref) < REL
+    assert rel_err(kernels.spec_polar_elem(X, sh[0]), X.abs() * torch.exp(1j * (X.angle() + sh[0]))) < REL   # (C, F, N) broadcast
+    # refill: zero a time span and a band, then fill
+    Xh = X.clone()
+    Xh[..., 10:20] = 0
+    Xh[:, :, 30:60, :] = 0
+    a = torch.randn(X.shape, device="cuda", generator=g)
+    b = torch.randn(X.shape, device="cuda", generator=g)
+    got = kernels.spec_polar_elem(Xh, b, a)
+    hole = Xh == 0
+    want = torch.where(hole, a * torch.exp(1j * b), Xh)
+    assert rel_err(got, want) < 1e-6 and torch.equal(got[~hole], Xh[~hole]) and int(hole.sum()) > 0
+
+
+def test_noise_transforms_fill_holes_on_device():
+    from audiotools_amd import transforms as tfm
+    x = synth.audio_batch(4, 1, 44100, seed=12, gaps=False)
+    for t in (tfm.TimeNoise(), tfm.FrequencyNoise(), tfm.CorruptPhase()):
+        sig = A.AudioSignal(x.clone(), 44100)
+        kw = t.batch_instantiate([1, 2, 3, 4], sig)
+        out = t(sig.clone().to("cuda"), **A.util.prepare_batch(kw, "cuda"))
+        assert out.audio_data.shape == x.shape and torch.isfinite(out.audio_data).all()
+        assert float((out.audio_data.cpu() - x).abs().max()) > 1e-3          # something changed
+    # corrupt_phase() with a scalar scale keeps the magnitudes
+    s = A.AudioSignal(x.clone(), 44100).to("cuda")
+    m0 = s.magnitude.clone()
+    s.corrupt_phase(0.3)
+    assert rel_err(s.magnitude, m0) < 1e-5 and float((s.phase - torch.angle(s.stft_data)).abs().max()) == 0.0
