@@ -219,125 +219,119 @@ struct ResMfmaArgs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RM_MAX_LD = 6;   // float4 per thread of one tile held in registers while the previous tile computes
+constexpr int RM_WREG = 6;     // 32-tap chunks whose weights a wave keeps in registers (441 -> 160 needs 6)
 
-__global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResMfmaArgs A) {
+__global__ __launch_bounds__(1024, 5) void resample_mfma_kernel(const ResMfmaArgs A) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const int FT = A.frames_per_tile;
+  const int64_t row = blockIdx.x / A.tiles_per_row;
+  const int tile = blockIdx.x % A.tiles_per_row;
+  const float* __restrict__ xr = A.x + row * A.T;
+  const int64_t f0 = (int64_t)tile * FT;
   const int t = threadIdx.x;
+  // The weights of this wave's first phase block are requested BEFORE the x tile: they come from
+  // L2 while the tile comes from HBM, and both are in flight together (for 441 -> 160 a wave has
+  // exactly one item per tile, so this is all the weight traffic it has).
+  const int lane_w = t & 63;
+  const int wave_w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool wreg = A.NC <= RM_WREG;
+  float4 wr[2 * RM_WREG];
+  if (wreg) {
+    const int P0 = wave_w % A.NPB;
+    const float4* __restrict__ wp0 = A.W + (int64_t)P0 * A.NC * 128 + lane_w;
+#pragma unroll
+    for (int c = 0; c < RM_WREG; ++c) {
+      const int cc = c < A.NC ? c : A.NC - 1;
+      wr[2 * c] = wp0[cc * 128];
+      wr[2 * c + 1] = wp0[cc * 128 + 64];
+    }
+  }
+  {  // stage the tile: xs[m] = xp[f0 old + m], xp[m] = x[clamp(m - width)]
+    const int64_t g_lo = f0 * A.old_sr - A.width;
+    const int n4 = (A.xs_len + 3) / 4;
+    if (g_lo >= 0 && g_lo + 4 * (int64_t)n4 <= A.T) {
+      const f4u* __restrict__ src = reinterpret_cast<const f4u*>(xr + g_lo);
+      float4* __restrict__ dst = reinterpret_cast<float4*>(xs);
+#pragma unroll 2
+      for (int i = t; i < n4; i += blockDim.x) {
+        const f4u v = src[i];
+        dst[i] = make_float4(v.x, v.y, v.z, v.w);
+      }
+    } else {
+#pragma unroll 2
+      for (int m = t; m < 4 * n4; m += blockDim.x) {
+        int64_t g = g_lo + m;
+        g = g < 0 ? 0 : (g >= A.T ? A.T - 1 : g);
+        xs[m] = xr[g];
+      }
+    }
+  }
+  __syncthreads();
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int nwaves = blockDim.x >> 6;
   const int j = lane & 15, k = lane >> 4;
   const int koff = (k & 1) * 16 + (k >> 1) * 8;     // {0, 16, 8, 24}
   const int n_fbp = FT / 32;                        // pairs of 16-frame blocks
-  const int n4 = (A.xs_len + 3) / 4;                // the LDS allocation is rounded up to whole float4
-  const int64_t n_tiles = A.rows * (int64_t)A.tiles_per_row;
-
-  // Persistent workgroup: tiles blockIdx.x, + gridDim.x, ...  The x tile of the NEXT round is
-  // fetched into registers while this round's MFMAs run (its HBM latency and transfer hide behind
-  // them) and written to LDS between two barriers -- software pipelining without a second LDS
-  // buffer, so two workgroups still fit a CU.
-  f4u nx[RM_MAX_LD];
-  auto tile_src = [&](int64_t tile_id, int64_t& g_lo) -> const float* {
-    const int64_t row = tile_id / A.tiles_per_row;
-    const int tile = (int)(tile_id - row * A.tiles_per_row);
-    g_lo = (int64_t)tile * FT * A.old_sr - A.width;
-    return A.x + row * A.T;
-  };
-  auto interior = [&](int64_t g_lo) { return g_lo >= 0 && g_lo + 4 * (int64_t)n4 <= A.T; };
-  auto prefetch = [&](int64_t tile_id) __attribute__((always_inline)) {
-    int64_t g_lo;
-    const float* xr = tile_src(tile_id, g_lo);
-    // branch-free: clamp the address into the row; edge tiles are re-staged by stage_slow()
-    const f4u* __restrict__ src = reinterpret_cast<const f4u*>(xr + (interior(g_lo) ? g_lo : 0));
-    const bool ok = interior(g_lo);
+  float* __restrict__ orow = A.out + row * A.out_len;
+  for (int item = wave; item < A.NPB * n_fbp; item += nwaves) {
+    const int P = item % A.NPB;
+    const int fp = item / A.NPB;
+    const float* __restrict__ a0p = xs + (fp * 32 + j) * A.old_sr + A.lo[P] + koff;   // A[i = j][k]: frame j of block 0
+    const float* __restrict__ a1p = a0p + 16 * A.old_sr;                               // frame block 1
+    const float4* __restrict__ wp = A.W + (int64_t)P * A.NC * 128 + lane;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto chunk = [&](int c, const float4 w0, const float4 w1) __attribute__((always_inline)) {
+      const float* __restrict__ p0 = a0p + 32 * c;
+      const float* __restrict__ p1 = a1p + 32 * c;
+      float a0[8], a1[8];
 #pragma unroll
-    for (int u = 0; u < RM_MAX_LD; ++u) {
-      const int i = t + u * (int)blockDim.x;
-      nx[u] = src[(ok && i < n4) ? i : 0];
-    }
-  };
-  auto commit = [&](int64_t tile_id) __attribute__((always_inline)) {   // registers (or the slow path) -> LDS
-    int64_t g_lo;
-    const float* xr = tile_src(tile_id, g_lo);
-    if (interior(g_lo)) {
-      float4* __restrict__ dst = reinterpret_cast<float4*>(xs);
+      for (int s2 = 0; s2 < 8; ++s2) { a0[s2] = p0[s2]; a1[s2] = p1[s2]; }
+      const float b[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int u = 0; u < RM_MAX_LD; ++u) {
-        const int i = t + u * (int)blockDim.x;
-        if (i < n4) dst[i] = make_float4(nx[u].x, nx[u].y, nx[u].z, nx[u].w);
+      for (int s2 = 0; s2 < 8; ++s2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], b[s2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s2], b[s2], acc1, 0, 0, 0);
       }
-      for (int i = t + RM_MAX_LD * (int)blockDim.x; i < n4; i += blockDim.x) {   // tiles larger than the register stage
-        const f4u v = reinterpret_cast<const f4u*>(xr + g_lo)[i];
-        dst[i] = make_float4(v.x, v.y, v.z, v.w);
+    };
+    if (wreg) {
+      // the whole weight window of the phase block in registers (2 float4 per 32-tap chunk):
+      // nothing inside the MFMA stream waits on memory
+      if (item != wave) {      // a later item of this wave (small `old`: many frame blocks per tile)
+#pragma unroll
+        for (int c = 0; c < RM_WREG; ++c) {
+          const int cc = c < A.NC ? c : A.NC - 1;
+          wr[2 * c] = wp[cc * 128];
+          wr[2 * c + 1] = wp[cc * 128 + 64];
+        }
       }
+#pragma unroll
+      for (int c = 0; c < RM_WREG; ++c)
+        if (c < A.NC) chunk(c, wr[2 * c], wr[2 * c + 1]);
     } else {
-      for (int m = t; m < 4 * n4; m += blockDim.x) {   // xs[m] = xp[f0 old + m], xp[m] = x[clamp(m - width)]
-        int64_t g = g_lo + m;
-        g = g < 0 ? 0 : (g >= A.T ? A.T - 1 : g);
-        xs[m] = xr[g];
-      }
-    }
-  };
-
-  int64_t tile_id = blockIdx.x;
-  if (tile_id < n_tiles) prefetch(tile_id);
-  for (; tile_id < n_tiles; tile_id += gridDim.x) {
-    commit(tile_id);
-    __syncthreads();
-    const int64_t next = tile_id + gridDim.x;
-    if (next < n_tiles) prefetch(next);                // in flight during the MFMAs below
-    const int64_t row = tile_id / A.tiles_per_row;
-    const int64_t f0 = (tile_id - row * A.tiles_per_row) * FT;
-    float* __restrict__ orow = A.out + row * A.out_len;
-    for (int item = wave; item < A.NPB * n_fbp; item += nwaves) {
-      const int P = item % A.NPB;
-      const int fp = item / A.NPB;
-      const float* __restrict__ a0p = xs + (fp * 32 + j) * A.old_sr + A.lo[P] + koff;   // A[i = j][k]: frame j of block 0
-      const float* __restrict__ a1p = a0p + 16 * A.old_sr;                               // frame block 1
-      const float4* __restrict__ wp = A.W + (int64_t)P * A.NC * 128 + lane;
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      // weights two chunks ahead (a chunk is 16 MFMAs = 512 cycles; an L2 hit under load takes longer)
       float4 w0 = wp[0], w1 = wp[64];
-      const int c1 = A.NC > 1 ? 1 : 0;
-      float4 v0 = wp[c1 * 128], v1 = wp[c1 * 128 + 64];
 #pragma unroll 1
       for (int c = 0; c < A.NC; ++c) {
-        const int cn = c + 2 < A.NC ? c + 2 : A.NC - 1;
+        const int cn = c + 1 < A.NC ? c + 1 : c;       // prefetch the next chunk's weights
         const float4 n0 = wp[cn * 128], n1 = wp[cn * 128 + 64];
-        __builtin_amdgcn_sched_barrier(0);             // issue them HERE
-        const float* __restrict__ p0 = a0p + 32 * c;
-        const float* __restrict__ p1 = a1p + 32 * c;
-        float a0[8], a1[8];
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) { a0[s2] = p0[s2]; a1[s2] = p1[s2]; }
-        const float b[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], b[s2], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s2], b[s2], acc1, 0, 0, 0);
-        }
         __builtin_amdgcn_sched_barrier(0);
-        w0 = v0; w1 = v1; v0 = n0; v1 = n1;
-        // keep the prefetched weights in registers: without this the compiler re-materialises them by
-        // loading chunk c at the top of iteration c (the bank is const __restrict__), i.e. it waits
-        // for L2 in front of the first MFMA of every chunk
+        chunk(c, w0, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        w0 = n0; w1 = n1;
         asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w));
       }
-      // D: lane holds rows 4 k + r (frames), column j (phase)
-      const int ph = 16 * P + j;
-      if (ph < A.new_sr) {
+    }
+    // D: lane holds rows 4 k + r (frames), column j (phase)
+    const int ph = 16 * P + j;
+    if (ph < A.new_sr) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t fa = f0 + fp * 32 + 4 * k + r;
-          const int64_t oa = fa * A.new_sr + ph, ob = oa + 16 * (int64_t)A.new_sr;
-          if (oa < A.out_len) orow[oa] = acc0[r];
-          if (ob < A.out_len) orow[ob] = acc1[r];
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int64_t fa = f0 + fp * 32 + 4 * k + r;
+        const int64_t oa = fa * A.new_sr + ph, ob = oa + 16 * (int64_t)A.new_sr;
+        if (oa < A.out_len) orow[oa] = acc0[r];
+        if (ob < A.out_len) orow[ob] = acc1[r];
       }
     }
-    __syncthreads();          // every wave is done reading xs before the next tile overwrites it
   }
 }
 
@@ -434,17 +428,12 @@ int at_resample_mfma_f32(const float* x, int64_t rows, int64_t T, const float* W
     int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_mfma_kernel));
     if (e != AT_OK) return e;
   }
-  const int64_t tiles = rows * A.tiles_per_row;
+  const int64_t blocks = rows * A.tiles_per_row;
+  if (blocks > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
   int64_t items = (int64_t)NPB * (FT / 32);
   int threads = (int)(items < 16 ? items : 16) * 64;
   // at least 4 waves so that staging a tile is not a one-wave job
   if (threads < 256) threads = 256;
-  // persistent grid: as many workgroups as fit the chip (LDS- and wave-limited), each loops over tiles
-  int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
-  if (per_cu > 2048 / threads) per_cu = 2048 / threads;
-  if (per_cu < 1) per_cu = 1;
-  int64_t blocks = (int64_t)at::device_cu_count() * per_cu;
-  if (blocks > tiles) blocks = tiles;
   hipLaunchKernelGGL(resample_mfma_kernel, dim3((unsigned)blocks), dim3(threads), lds, reinterpret_cast<hipStream_t>(stream), A);
   AT_LAUNCH_CHECK();
   return AT_OK;

@@ -58,7 +58,6 @@ struct LufsArgs {
   // P^(2^i), i = 0..6, per stage, row-major 2x2: wave-uniform, read through s_load
   double Pp[MAX_STAGE][7][4];   // float64: used once per wave to build the per-lane matrices
   float Pf[MAX_STAGE][4][4];    // float32 P^1, P^2, P^4, P^8 for the in-row scan steps
-  float Ph[MAX_STAGE][4];       // companion^(CHUNK/2) in the same basis: joins the two half-chunk chains of a lane
 };
 
 struct M2 {  // 2x2 double matrix
@@ -112,35 +111,26 @@ template <int SI>
 __device__ __forceinline__ void biquad_stage(float (&v)[CHUNK], const LufsArgs& A, float hx1, float hx2, float& ky1,
                                              float& ky2, const LaneMats& Q, int lane) {
   const Stage s = A.st[SI];
-  // (a) FIR part in place + zero-state recursion.  The recursion is a serial fma chain (one
-  // dependent fma per sample); with 3 waves per SIMD that chain, not the VALU rate, set the pace
-  // (4.7 cycles per instruction measured).  The lane's chunk is therefore run as TWO independent
-  // half-chunk chains (samples 0..15 and 16..31, both from zero state) that the compiler
-  // interleaves, joined by Ph = companion^16:  state(32) = state_B + Ph state_A.
-  constexpr int HC = CHUNK / 2;
-  float xa1 = hx1, xa2 = hx2;
-  float xb1 = v[HC - 1], xb2 = v[HC - 2];      // ORIGINAL inputs preceding the second half
-  float ya1 = 0.f, ya2 = 0.f, yb1 = 0.f, yb2 = 0.f;
+  // (a) FIR part in place + zero-state recursion
+  float x1 = hx1, x2 = hx2;
+  float y1 = 0.f, y2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < HC; ++i) {
-    const float xna = v[i], xnb = v[HC + i];
-    float oa = s.b2 * xa2, ob = s.b2 * xb2;
-    oa = fmaf(s.b1, xa1, oa); ob = fmaf(s.b1, xb1, ob);
-    oa = fmaf(s.b0, xna, oa); ob = fmaf(s.b0, xnb, ob);
-    v[i] = oa; v[HC + i] = ob;
-    xa2 = xa1; xa1 = xna; xb2 = xb1; xb1 = xnb;
-    const float ya = fmaf(-s.a1, ya1, fmaf(-s.a2, ya2, oa));
-    const float yb = fmaf(-s.a1, yb1, fmaf(-s.a2, yb2, ob));
-    ya2 = ya1; ya1 = ya; yb2 = yb1; yb1 = yb;
+  for (int i = 0; i < CHUNK; ++i) {
+    const float xn = v[i];
+    float o = s.b2 * x2;
+    o = fmaf(s.b1, x1, o);
+    o = fmaf(s.b0, xn, o);
+    v[i] = o;
+    x2 = x1;
+    x1 = xn;
+    const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, o));
+    y2 = y1;
+    y1 = y;
   }
-  const float ha1 = ya1, ha2 = ya1 - ya2;      // zero-state response of the first half, basis (y1, y1 - y2)
-  float y1, y2;
   // (b) wave scan of the state recursion F_c = z_c + P F_{c-1}:
   //     Hillis-Steele inside each 16-lane row (row_shr 1,2,4,8 with P, P^2, P^4, P^8),
   //     then row_bcast15 / row_bcast31 fold the previous rows in with per-lane powers of P.
-  // zero-state response of the whole chunk: second half + Ph * first half
-  float g1 = fmaf(A.Ph[SI][0], ha1, fmaf(A.Ph[SI][1], ha2, yb1));
-  float g2 = fmaf(A.Ph[SI][2], ha1, fmaf(A.Ph[SI][3], ha2, yb1 - yb2));
+  float g1 = y1, g2 = y1 - y2;  // state in the basis (y1, y1 - y2)
 #pragma unroll
   for (int step = 0; step < 4; ++step) {
     float u1, u2;
@@ -167,31 +157,26 @@ __device__ __forceinline__ void biquad_stage(float (&v)[CHUNK], const LufsArgs& 
   // F_c = G_c + P^(c+1) K ; entering state of lane c = F_{c-1} (lane 0: K)
   const float f1 = fmaf(Q.q64.a, ky1, fmaf(Q.q64.b, ky2, g1));
   const float f2 = fmaf(Q.q64.c, ky1, fmaf(Q.q64.d, ky2, g2));
-  const float e1 = wave_shr1(f1, ky1), e2 = wave_shr1(f2, ky2);   // state entering the lane's chunk
-  y1 = e1;
-  y2 = e1 - e2;                   // back to (y[-1], y[-2])
-  // state entering the second half = zero-state response of the first half + Ph * entering state
-  const float m1 = fmaf(A.Ph[SI][0], e1, fmaf(A.Ph[SI][1], e2, ha1));
-  const float m2 = fmaf(A.Ph[SI][2], e1, fmaf(A.Ph[SI][3], e2, ha2));
-  float z1 = m1, z2 = m1 - m2;
+  y1 = wave_shr1(f1, ky1);
+  y2 = y1 - wave_shr1(f2, ky2);   // back to (y[-1], y[-2])
   ky1 = lane63(f1);
   ky2 = lane63(f2);               // carried in the (y1, y1 - y2) basis
-  // (c) true recursion from the entering states, the two halves as independent chains
+  // (c) true recursion from the entering state
   if (s.g == 1.0f) {  // wave-uniform; every BS.1770 weighting stage has unit pass-band gain (loudness.py:259)
 #pragma unroll
-    for (int i = 0; i < HC; ++i) {
-      const float ya = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
-      const float yb = fmaf(-s.a1, z1, fmaf(-s.a2, z2, v[HC + i]));
-      v[i] = ya; v[HC + i] = yb;
-      y2 = y1; y1 = ya; z2 = z1; z1 = yb;
+    for (int i = 0; i < CHUNK; ++i) {
+      const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
+      v[i] = y;
+      y2 = y1;
+      y1 = y;
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < HC; ++i) {
-      const float ya = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
-      const float yb = fmaf(-s.a1, z1, fmaf(-s.a2, z2, v[HC + i]));
-      v[i] = s.g * ya; v[HC + i] = s.g * yb;
-      y2 = y1; y1 = ya; z2 = z1; z1 = yb;
+    for (int i = 0; i < CHUNK; ++i) {
+      const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
+      v[i] = s.g * y;
+      y2 = y1;
+      y1 = y;
     }
   }
 }
@@ -506,16 +491,6 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
     for (int i = 0; i < CHUNK; ++i) {
       const double pn = -a1 * p1 - a2 * p2; p2 = p1; p1 = pn;
       const double qn = -a1 * q1 - a2 * q2; q2 = q1; q1 = qn;
-    }
-    {  // companion^(CHUNK/2) in the basis (y1, y1 - y2), float32
-      double hp1 = 1.0, hp2 = 0.0, hq1 = 0.0, hq2 = 1.0;
-      for (int i = 0; i < CHUNK / 2; ++i) {
-        const double pn = -a1 * hp1 - a2 * hp2; hp2 = hp1; hp1 = pn;
-        const double qn = -a1 * hq1 - a2 * hq2; hq2 = hq1; hq1 = qn;
-      }
-      const double H[4] = {hp1, hq1, hp2, hq2};
-      const double Ht[4] = {H[0] + H[1], -H[1], H[0] - H[2] + H[1] - H[3], -(H[1] - H[3])};
-      for (int e = 0; e < 4; ++e) A.Ph[s][e] = (float)Ht[e];
     }
     double P[4] = {p1, q1, p2, q2};  // (y[31],y[30]) = P (y[-1],y[-2])
     for (int i = 0; i < 7; ++i) {

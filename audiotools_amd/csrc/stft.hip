@@ -75,6 +75,7 @@ struct StftArgs {
   int reuse_shift;         // hop / (2 L) when consecutive frames of a wave can reuse registers, else 0
   int run;                 // consecutive frame groups a wave handles before jumping ahead (<= AT_STFT_RUN)
   int debug;               // development: 1 = compute but never store, 2 = store only (no FFT)
+  int flags;               // development experiments (AT_STFT_FLAGS, read once): bit 0 = v2 writes 16-B stores (WRONG bin order: timing only)
 };
 
 using at::fetch_padded;
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
 //    ~145 v_mov per frame on the shift);
 //  * window and pass-2 twiddles are read as ds_read_b128 rows (the stride-64 float2 reads were
 //    merged by the compiler into half-rate ds_read2st64_b64).
-template <int NR /* mel rounds of 64 units; 0 = no mel */>
+template <int NR /* mel rounds of 64 units; 0 = no mel */, bool ST16 = false /* timing experiment: 16-B stores, wrong bin order */>
 __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   constexpr bool MEL = NR > 0;
   constexpr int M = 1024, L = 64, N = 2048, NW = 4, SH = 4;
@@ -661,10 +662,21 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int k0 = 256 * m + t;
-      orow[k0] = ascA[m];
-      orow[k0 + 64] = xaB[m];
-      orow[k0 + 128] = rcB[m];
-      orow[k0 + 192] = rcA[m];
+      if constexpr (ST16) {
+        // EXPERIMENT (timing only, bins land in the wrong order): the same bytes as 8 x 16-B stores
+        // per frame instead of 16 x 8-B -- does halving the store instructions pay?
+        struct __attribute__((packed, aligned(8))) f4a8 { float x, y, z, w; };
+        f4a8 u, v;
+        u.x = ascA[m].x; u.y = ascA[m].y; u.z = xaB[m].x; u.w = xaB[m].y;
+        v.x = rcB[m].x; v.y = rcB[m].y; v.z = rcA[m].x; v.w = rcA[m].y;
+        reinterpret_cast<f4a8*>(orow + 256 * m)[t] = u;
+        reinterpret_cast<f4a8*>(orow + 256 * m + 128)[t] = v;
+      } else {
+        orow[k0] = ascA[m];
+        orow[k0 + 64] = xaB[m];
+        orow[k0 + 128] = rcB[m];
+        orow[k0 + 192] = rcA[m];
+      }
       if constexpr (MEL) {
         magbuf[k0 + 4 * (k0 >> 4)] = cabs_fast(ascA[m]);
         magbuf[k0 + 64 + 4 * ((k0 + 64) >> 4)] = cabs_fast(xaB[m]);
@@ -783,9 +795,9 @@ static int balanced_run(int64_t total_groups, int64_t blocks, int nw) {
   return (int)run;
 }
 
-template <int NR>
+template <int NR, bool ST16 = false>
 int launch_v2(const StftArgs& A, int n_cu, hipStream_t stream) {
-  auto kern = stft_mel_kernel_v2<NR>;
+  auto kern = stft_mel_kernel_v2<NR, ST16>;
   const size_t bytes = v2_lds_floats(A.n_units) * 4;
   if (bytes > 160 * 1024) return AT_ERR_UNSUPPORTED;
   int e = at::allow_big_lds(reinterpret_cast<const void*>(kern));
@@ -982,6 +994,8 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   static const int dbg_mode = AT_STFT_DEBUGMODES ? env_int_once("AT_STFT_DEBUG", 0) : 0;
   static const int allow_reuse = env_int_once("AT_STFT_REUSE", 1);
   static const int use_v2 = env_int_once("AT_STFT_V2", 1);
+  static const int exp_flags = env_int_once("AT_STFT_FLAGS", 0);
+  A.flags = exp_flags;
   A.debug = dbg_mode;
   A.reuse_shift = (FW == 1 && hop % (2 * (M / 16)) == 0 && pad == 0) ? hop / (2 * (M / 16)) : 0;
   if (!allow_reuse) A.reuse_shift = 0;
@@ -991,9 +1005,9 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   if (use_v2 && M == 1024 && vec2 && A.reuse_shift == 4 && A.debug == 0 && T >= 2 * 2048) {
     // the reference's default transform at 44.1 / 48 kHz: n_fft 2048, hop 512, no match_stride
     switch (A.n_units / 64) {
-      case 0: return launch_v2<0>(A, n_cu, s);
+      case 0: return (A.flags & 1) ? launch_v2<0, true>(A, n_cu, s) : launch_v2<0>(A, n_cu, s);
       case 2: return launch_v2<2>(A, n_cu, s);
-      case 4: return launch_v2<4>(A, n_cu, s);
+      case 4: return (A.flags & 1) ? launch_v2<4, true>(A, n_cu, s) : launch_v2<4>(A, n_cu, s);
       case 6: return launch_v2<6>(A, n_cu, s);
     }
   }

@@ -995,7 +995,8 @@ def test_stft_generic_match_stride_and_mel():
     ref = restate.stft(x, 4096, 1024, "sqrt_hann", True, "reflect")
     assert rel_err(X, ref) < REL
     y = s.istft(match_stride=True, window_type="sqrt_hann").audio_data
-    assert y.shape == x.shape and float((y.cpu() - x).abs().max()) < 1e-4
+    yr = restate.istft(ref, 4096, 1024, "sqrt_hann", True, x.shape[-1])
+    assert y.shape == x.shape == yr.shape and rel_err(y, yr) < REL      # (edges are not x: 2 frames were dropped)
     mel = s.mel_spectrogram(80)                                     # dense basis on the native spectrum
     Xr = restate.stft(x, 4096, 1024)
     assert rel_err(mel, restate.mel_spectrogram(Xr, 96000, 80)) < REL
