@@ -219,9 +219,7 @@ struct ResMfmaArgs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RM_WREG = 6;     // 32-tap chunks whose weights a wave keeps in registers (441 -> 160 needs 6)
-
-__global__ __launch_bounds__(1024, 5) void resample_mfma_kernel(const ResMfmaArgs A) {
+__global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResMfmaArgs A) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const int FT = A.frames_per_tile;
   const int64_t row = blockIdx.x / A.tiles_per_row;
@@ -229,36 +227,19 @@ __global__ __launch_bounds__(1024, 5) void resample_mfma_kernel(const ResMfmaArg
   const float* __restrict__ xr = A.x + row * A.T;
   const int64_t f0 = (int64_t)tile * FT;
   const int t = threadIdx.x;
-  // The weights of this wave's first phase block are requested BEFORE the x tile: they come from
-  // L2 while the tile comes from HBM, and both are in flight together (for 441 -> 160 a wave has
-  // exactly one item per tile, so this is all the weight traffic it has).
-  const int lane_w = t & 63;
-  const int wave_w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool wreg = A.NC <= RM_WREG;
-  float4 wr[2 * RM_WREG];
-  if (wreg) {
-    const int P0 = wave_w % A.NPB;
-    const float4* __restrict__ wp0 = A.W + (int64_t)P0 * A.NC * 128 + lane_w;
-#pragma unroll
-    for (int c = 0; c < RM_WREG; ++c) {
-      const int cc = c < A.NC ? c : A.NC - 1;
-      wr[2 * c] = wp0[cc * 128];
-      wr[2 * c + 1] = wp0[cc * 128 + 64];
-    }
-  }
   {  // stage the tile: xs[m] = xp[f0 old + m], xp[m] = x[clamp(m - width)]
     const int64_t g_lo = f0 * A.old_sr - A.width;
     const int n4 = (A.xs_len + 3) / 4;
     if (g_lo >= 0 && g_lo + 4 * (int64_t)n4 <= A.T) {
       const f4u* __restrict__ src = reinterpret_cast<const f4u*>(xr + g_lo);
       float4* __restrict__ dst = reinterpret_cast<float4*>(xs);
-#pragma unroll 2
+#pragma unroll 4
       for (int i = t; i < n4; i += blockDim.x) {
         const f4u v = src[i];
         dst[i] = make_float4(v.x, v.y, v.z, v.w);
       }
     } else {
-#pragma unroll 2
+#pragma unroll 4
       for (int m = t; m < 4 * n4; m += blockDim.x) {
         int64_t g = g_lo + m;
         g = g < 0 ? 0 : (g >= A.T ? A.T - 1 : g);
@@ -281,45 +262,29 @@ __global__ __launch_bounds__(1024, 5) void resample_mfma_kernel(const ResMfmaArg
     const float* __restrict__ a1p = a0p + 16 * A.old_sr;                               // frame block 1
     const float4* __restrict__ wp = A.W + (int64_t)P * A.NC * 128 + lane;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    auto chunk = [&](int c, const float4 w0, const float4 w1) __attribute__((always_inline)) {
+    float4 w0 = wp[0], w1 = wp[64];
+#pragma unroll 1
+    for (int c = 0; c < A.NC; ++c) {
+      const int cn = c + 1 < A.NC ? c + 1 : c;       // prefetch the next chunk's weights
+      const float4 n0 = wp[cn * 128], n1 = wp[cn * 128 + 64];
+      __builtin_amdgcn_sched_barrier(0);             // issue them HERE: 16 MFMAs (512 cycles) cover the L2 latency
       const float* __restrict__ p0 = a0p + 32 * c;
       const float* __restrict__ p1 = a1p + 32 * c;
       float a0[8], a1[8];
 #pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2) { a0[s2] = p0[s2]; a1[s2] = p1[s2]; }
+      for (int s = 0; s < 8; ++s) { a0[s] = p0[s]; a1[s] = p1[s]; }
       const float b[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], b[s2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s2], b[s2], acc1, 0, 0, 0);
+      for (int s = 0; s < 8; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b[s], acc1, 0, 0, 0);
       }
-    };
-    if (wreg) {
-      // the whole weight window of the phase block in registers (2 float4 per 32-tap chunk):
-      // nothing inside the MFMA stream waits on memory
-      if (item != wave) {      // a later item of this wave (small `old`: many frame blocks per tile)
-#pragma unroll
-        for (int c = 0; c < RM_WREG; ++c) {
-          const int cc = c < A.NC ? c : A.NC - 1;
-          wr[2 * c] = wp[cc * 128];
-          wr[2 * c + 1] = wp[cc * 128 + 64];
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < RM_WREG; ++c)
-        if (c < A.NC) chunk(c, wr[2 * c], wr[2 * c + 1]);
-    } else {
-      float4 w0 = wp[0], w1 = wp[64];
-#pragma unroll 1
-      for (int c = 0; c < A.NC; ++c) {
-        const int cn = c + 1 < A.NC ? c + 1 : c;       // prefetch the next chunk's weights
-        const float4 n0 = wp[cn * 128], n1 = wp[cn * 128 + 64];
-        __builtin_amdgcn_sched_barrier(0);
-        chunk(c, w0, w1);
-        __builtin_amdgcn_sched_barrier(0);
-        w0 = n0; w1 = n1;
-        asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w));
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      w0 = n0; w1 = n1;
+      // keep the prefetched weights in registers: without this the compiler re-materialises them by
+      // loading chunk c at the top of iteration c (the bank is const __restrict__), i.e. it waits
+      // for L2 in front of the first MFMA of every chunk
+      asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w));
     }
     // D: lane holds rows 4 k + r (frames), column j (phase)
     const int ph = 16 * P + j;

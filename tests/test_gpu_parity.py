@@ -440,8 +440,10 @@ def test_c_abi_error_codes_and_degenerate_inputs():
     assert lib.at_stft_mel_f32(*args(hop=0)) == -1
     assert lib.at_stft_mel_f32(*args(n_out=34)) == -1                   # more frames than the signal has
     assert lib.at_stft_mel_f32(*args(T=200)) == -1                      # reflect padding needs n_fft/2 < T
-    assert lib.at_stft_mel_f32(*args(n_fft=500)) == -2                  # not a power of two: no kernel
-    assert lib.at_stft_mel_f32(*args(n_fft=4096)) == -2
+    assert lib.at_stft_mel_f32(*args(n_fft=502)) == -2                  # n_fft / 2 = 251 is prime: no kernel
+    assert lib.at_stft_mel_f32(*args(n_fft=501)) == -2                  # odd
+    assert lib.at_stft_mel_f32(*args(n_fft=32768)) == -2                # longer than any kernel
+    assert lib.at_stft_mel_f32(*args(n_fft=500)) == 0                   # 2 * 2 * 5^3: the generic mixed-radix kernel
     assert lib.at_lufs_f32(None, 1, 1, 100, None, None, 2, 4, 1, 1.0, -70.0, 0, None, None, 0, st) == -1
     assert lib.at_fir_fft_f32(p(x), 2, 1, 4096, p(win), 1, 512, 255, 0, None, p(x), st) == -1      # x aliases out / no twiddles
     assert lib.at_istft_workspace_bytes(2, 0, 512, 128) == -1
