@@ -300,6 +300,109 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResMfmaArgs A
   }
 }
 
+
+// ---- the same, wave-specialised and persistent ("ws") ----------------------------------------------
+// resample_mfma_kernel alternates "stage a tile" and "compute it" per workgroup, and its MFMA pipe
+// is busy ~46 % of the launch.  Here the roles are separate waves of a persistent workgroup:
+//   * wave p < NPB owns phase block p for the whole launch: its weight window (2 float4 per 32-tap
+//     chunk) is loaded ONCE into registers, so its instruction stream is LDS reads + MFMAs only;
+//   * one LOADER wave moves the next 16-frame tile HBM -> registers -> the other LDS buffer while the
+//     MFMA waves work on the current one (its vmcnt is its own: no in-order coupling with the
+//     weight loads, which is what sank the single-role persistent variant);
+//   * one __syncthreads() per tile swaps the buffers.
+// Tiles are 16 frames (one MFMA row block): two buffers of ~30 KB, two workgroups per CU, and
+// 2 x NPB MFMA waves per CU spread evenly over the four SIMDs.
+constexpr int WS_NC = 6;          // 32-tap chunks a wave keeps in registers (441 -> 160 needs 6)
+
+template <int NC>
+__global__ __launch_bounds__(1024, 6) void resample_mfma_ws_kernel(const ResMfmaArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = wave == A.NPB;
+  const int n4 = (A.xs_len + 3) / 4;
+  const int n4s = (n4 + 63) / 64 * 64;          // whole 1 KB DMA pieces
+  float* buf[2] = {xs, xs + 4 * n4s};
+  const int64_t n_tiles = A.rows * (int64_t)A.tiles_per_row;
+  const int j = lane & 15, k = lane >> 4;
+  const int koff = (k & 1) * 16 + (k >> 1) * 8;
+
+  // LDS-DMA (global_load_lds_dwordx4): 1 KB per wave instruction straight into the LDS buffer, no
+  // staging registers -- the loader wave keeps a whole tile in flight with a handful of VGPRs
+  // (a register-staged tile needs ~30 float4 per lane and pushed the kernel past 5 waves per SIMD).
+  auto load_tile = [&](int64_t tile_id, float* __restrict__ dst) __attribute__((always_inline)) {
+    const int64_t row = tile_id / A.tiles_per_row;
+    const int tile = (int)(tile_id - row * A.tiles_per_row);
+    const float* __restrict__ xr = A.x + row * A.T;
+    const int64_t g_lo = (int64_t)tile * 16 * A.old_sr - A.width;
+    if (g_lo >= 0 && g_lo + 4 * (int64_t)n4 <= A.T) {
+      const float* __restrict__ src = xr + g_lo;
+      for (int i0 = 0; i0 < n4; i0 += 64) {
+        const int i = i0 + lane;
+        const float* g = src + 4 * (i < n4 ? i : 0);       // lanes past the end re-read element 0 into the slack
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(dst + 4 * i0), 16, 0, 0);
+      }
+    } else {
+      for (int m = lane; m < 4 * n4; m += 64) {
+        int64_t g = g_lo + m;
+        g = g < 0 ? 0 : (g >= A.T ? A.T - 1 : g);
+        dst[m] = xr[g];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // LDS-DMA is ordered by the issuing wave's vmcnt only
+  };
+
+  // weights of this wave's phase block: registers for the whole launch
+  float4 wr[2 * NC];
+  if (!loader) {
+    const float4* __restrict__ wp = A.W + (int64_t)wave * NC * 128 + lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { wr[2 * c] = wp[c * 128]; wr[2 * c + 1] = wp[c * 128 + 64]; }
+  }
+  int cur = 0;
+  int64_t tile_id = blockIdx.x;
+  if (loader && tile_id < n_tiles) load_tile(tile_id, buf[0]);
+  __syncthreads();
+  const int lo_p = loader ? 0 : A.lo[wave];
+  for (; tile_id < n_tiles; tile_id += gridDim.x) {
+    if (loader) {
+      const int64_t next = tile_id + gridDim.x;
+      if (next < n_tiles) load_tile(next, buf[cur ^ 1]);
+    } else {
+      const float* __restrict__ ap = buf[cur] + j * A.old_sr + lo_p + koff;   // A[i = j][k]
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // even / odd MFMAs: two dependency chains
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float a[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) a[s2] = ap[32 * c + s2];
+        const float b[8] = {wr[2 * c].x, wr[2 * c].y, wr[2 * c].z, wr[2 * c].w,
+                            wr[2 * c + 1].x, wr[2 * c + 1].y, wr[2 * c + 1].z, wr[2 * c + 1].w};
+#pragma unroll
+        for (int s2 = 0; s2 < 8; s2 += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2], b[s2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2 + 1], b[s2 + 1], acc1, 0, 0, 0);
+        }
+      }
+      const int64_t row = tile_id / A.tiles_per_row;
+      const int64_t f0 = (tile_id - row * A.tiles_per_row) * 16;
+      float* __restrict__ orow = A.out + row * A.out_len;
+      const int ph = 16 * wave + j;
+      if (ph < A.new_sr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t o = (f0 + 4 * k + r) * A.new_sr + ph;
+          if (o < A.out_len) orow[o] = acc0[r] + acc1[r];
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -379,6 +482,39 @@ int at_resample_mfma_f32(const float* x, int64_t rows, int64_t T, const float* W
   A.x = x; A.W = reinterpret_cast<const float4*>(W); A.lo = lo; A.out = out; A.T = T; A.out_len = out_len; A.rows = rows;
   A.old_sr = old_sr; A.new_sr = new_sr; A.width = width; A.NPB = NPB; A.NC = NC;
   const int64_t frames = (out_len + new_sr - 1) / new_sr;
+  static const int use_ws = at::env_int_once("AT_RESAMPLE_WS", 1);
+  if (use_ws && NPB <= 15 && NC <= WS_NC) {
+    // wave-specialised persistent form: 16-frame tiles, two LDS buffers
+    A.frames_per_tile = 16;
+    A.tiles_per_row = (int)((frames + 15) / 16);
+    A.xs_len = 16 * old_sr + max_lo + 32 * NC + 32;
+    const size_t lds1 = (size_t)(((A.xs_len + 3) / 4 + 63) / 64 * 64) * 16;   // whole 1 KB LDS-DMA pieces
+    if (2 * lds1 <= 80 * 1024) {
+      const int threads = (NPB + 1) * 64;
+      const int64_t tiles = rows * A.tiles_per_row;
+      int per_cu = (int)((160 * 1024) / (2 * lds1));
+      if (per_cu > 2048 / threads) per_cu = 2048 / threads;
+      if (per_cu > 2) per_cu = 2;
+      if (per_cu < 1) per_cu = 1;
+      int64_t blocks = (int64_t)at::device_cu_count() * per_cu;
+      if (blocks > tiles) blocks = tiles;
+      hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define AT_WS_LAUNCH(NCV)                                                                                  \
+  case NCV: {                                                                                              \
+    int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_mfma_ws_kernel<NCV>));                \
+    if (e != AT_OK) return e;                                                                              \
+    hipLaunchKernelGGL(resample_mfma_ws_kernel<NCV>, dim3((unsigned)blocks), dim3(threads), 2 * lds1, st, A); \
+    break;                                                                                                 \
+  }
+      switch (NC) {
+        AT_WS_LAUNCH(1) AT_WS_LAUNCH(2) AT_WS_LAUNCH(3) AT_WS_LAUNCH(4) AT_WS_LAUNCH(5) AT_WS_LAUNCH(6)
+        default: return AT_ERR_UNSUPPORTED;
+      }
+#undef AT_WS_LAUNCH
+      AT_LAUNCH_CHECK();
+      return AT_OK;
+    }
+  }
   // tile: ~14.5k input samples of LDS (58 KB -> 2 workgroups per CU), a multiple of 32 frames
   int FT = 14500 / old_sr / 32 * 32;
   if (FT < 32) FT = 32;
