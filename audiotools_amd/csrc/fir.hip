@@ -323,7 +323,9 @@ __global__ __launch_bounds__(1024, 6) void resample_mfma_ws_kernel(const ResMfma
   const bool loader = wave == A.NPB;
   const int n4 = (A.xs_len + 3) / 4;
   const int n4s = (n4 + 63) / 64 * 64;          // whole 1 KB DMA pieces
-  float* buf[2] = {xs, xs + 4 * n4s};
+  // the two tile buffers are addressed as xs + cur * buf_stride: an array of pointers indexed by a
+  // run-time value decays to generic (flat) pointers and the MFMA operand reads became flat loads
+  const int buf_stride = 4 * n4s;
   const int64_t n_tiles = A.rows * (int64_t)A.tiles_per_row;
   const int j = lane & 15, k = lane >> 4;
   const int koff = (k & 1) * 16 + (k >> 1) * 8;
@@ -363,15 +365,15 @@ __global__ __launch_bounds__(1024, 6) void resample_mfma_ws_kernel(const ResMfma
   }
   int cur = 0;
   int64_t tile_id = blockIdx.x;
-  if (loader && tile_id < n_tiles) load_tile(tile_id, buf[0]);
+  if (loader && tile_id < n_tiles) load_tile(tile_id, xs);
   __syncthreads();
   const int lo_p = loader ? 0 : A.lo[wave];
   for (; tile_id < n_tiles; tile_id += gridDim.x) {
     if (loader) {
       const int64_t next = tile_id + gridDim.x;
-      if (next < n_tiles) load_tile(next, buf[cur ^ 1]);
+      if (next < n_tiles) load_tile(next, xs + (cur ^ 1) * buf_stride);
     } else {
-      const float* __restrict__ ap = buf[cur] + j * A.old_sr + lo_p + koff;   // A[i = j][k]
+      const float* __restrict__ ap = xs + cur * buf_stride + j * A.old_sr + lo_p + koff;   // A[i = j][k]
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // even / odd MFMAs: two dependency chains
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
