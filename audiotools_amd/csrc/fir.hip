@@ -372,6 +372,7 @@ __global__ __launch_bounds__(1024, 6) void resample_mfma_ws_kernel(const ResMfma
     if (loader) {
       const int64_t next = tile_id + gridDim.x;
       if (next < n_tiles) load_tile(next, xs + (cur ^ 1) * buf_stride);
+      __syncthreads();
     } else {
       const float* __restrict__ ap = xs + cur * buf_stride + j * A.old_sr + lo_p + koff;   // A[i = j][k]
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // even / odd MFMAs: two dependency chains
@@ -388,6 +389,10 @@ __global__ __launch_bounds__(1024, 6) void resample_mfma_ws_kernel(const ResMfma
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2 + 1], b[s2 + 1], acc1, 0, 0, 0);
         }
       }
+      // the tile buffer is free once the operands are in registers: rendezvous FIRST, store the
+      // results afterwards (the stores of this tile then overlap the next tile's operand reads of
+      // the other waves instead of holding everybody at the barrier)
+      __syncthreads();
       const int64_t row = tile_id / A.tiles_per_row;
       const int64_t f0 = (tile_id - row * A.tiles_per_row) * 16;
       float* __restrict__ orow = A.out + row * A.out_len;
@@ -400,7 +405,6 @@ __global__ __launch_bounds__(1024, 6) void resample_mfma_ws_kernel(const ResMfma
         }
       }
     }
-    __syncthreads();
     cur ^= 1;
   }
 }
