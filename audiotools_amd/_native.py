@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("AT_LIB_PATH") or os.path.join(LIB_DIR, "libaudiotools_amd.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "firfft.hip", "irtools.hip", "specedit.hip", "fftconv.hip", "vocoder.hip", "stft_generic.hip"]
+SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "firfft.hip", "irtools.hip", "specedit.hip", "fftconv.hip", "vocoder.hip", "stft_generic.hip", "longconv.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -42,6 +42,8 @@ def compile_command(src, obj):
     per_file = FILE_FLAGS.get(os.path.basename(src), [])
     if os.environ.get("AT_STFT_SLP") == "1" and os.path.basename(src) == "stft.hip":
         per_file = []
+    if os.environ.get("AT_NOSLP_ALL") == "1":          # A/B builds: every source without SLP packing
+        per_file = ["-fno-slp-vectorize"]
     return [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + per_file + extra + ["-o", obj, src]
 
 
@@ -65,7 +67,7 @@ def build(force: bool = False, verbose: bool = False, out: str = None) -> str:
     hdrs = [os.path.join(CSRC_DIR, h) for h in HEADERS]
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
     flag_stamp = os.path.join(obj_dir, "flags.txt")
-    flags_now = repr((os.environ.get("AT_HIPCC_FLAGS", ""), os.environ.get("AT_STFT_SLP", ""), FILE_FLAGS))
+    flags_now = repr((os.environ.get("AT_HIPCC_FLAGS", ""), os.environ.get("AT_STFT_SLP", ""), os.environ.get("AT_NOSLP_ALL", ""), FILE_FLAGS))
     flags_same = os.path.exists(flag_stamp) and open(flag_stamp).read() == flags_now
     jobs, objs = [], []
     for s in SOURCES:
@@ -124,6 +126,12 @@ SIGNATURES = {
     "at_resample_mfma_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "at_fftconv_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "at_fftconv_circ_f32": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _p]),
+    "at_longconv_supported": (_i32, [_i64]),
+    "at_longconv_plan": (_i32, [_i64, _p, _p]),
+    "at_longconv_table_floats": (_i64, [_i64]),
+    "at_longconv_tables_host": (_i32, [_i64, _p, _i64]),
+    "at_longconv_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
+    "at_longconv_circ_f32": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _i64, _p]),
     "at_lufs_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32]),
     "at_lufs_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _i32, _i32, _i32, _f64, _f32,
                            _i32, _p, _p, _i64, _p]),

@@ -1,0 +1,483 @@
+// Circular convolution of long signals by a four-step FFT, hand-written for gfx950 (no rocFFT).
+//
+// Replaces reference audiotools/core/effects.py:102-121 (EffectMixin.convolve):
+//     rfft(ir, T), rfft(x, T), product, irfft(., T), scale by 1/clamp(max|ir|, 1e-5)
+// -- a CIRCULAR convolution of length T (the reverb tail wraps to the head), kept as is.
+//
+// rocFFT needs 5 kernels per forward transform at T = 240000 (two transposes, two strided FFTs, the
+// real post-processing), 13 launches and ~20 GB of traffic for one convolution (profiles/
+// r02_cfg4_cfg5_kernel_stats.csv: 7 ms of the 12.8 ms cfg4 chain).  Here the real signal is read
+// as M = T/2 complex points z[n] = x[2n] + i x[2n+1], i.e. as an N1 x N2 row-major matrix
+// (n = N2 n1 + n2), and
+//
+//   colfft   FFT of every column (over n1): a 64-column tile sits in LDS, 512-byte segments in
+//            and out.  Run on x (into `out`) and on the IR (into the workspace).
+//   rowconv  one workgroup per row PAIR (k1, N1 - k1) of one signal: twiddle W_M^{k1 n2} and row
+//            FFT (over n2) of x and of the IR in LDS -> the spectrum Z[k1 + N1 k2]; bins k and
+//            M - k live in the two rows of the pair, so the real-FFT split, the product X H s / M,
+//            the inverse split, the (conjugated) row FFT back and the twiddle all happen before
+//            anything is written: the row pair is overwritten in place.
+//   colfft   again on the result with a conjugated store: y.
+//
+// 4 launches, 4 reads + 3 writes of one signal-sized array (8.8 GB at cfg4 against 20 GB).
+// The sub-FFTs are in-place mixed-radix (4, 2, 3, 5, 7) passes: every thread holds its butterflies
+// in registers across the barrier, so a tile needs one LDS buffer, not two.
+// T must be even with T/2 = N1 N2, N1 <= 512, N2 <= 2048, both {2,3,5,7}-smooth
+// (at_longconv_supported); other lengths keep the rocFFT path (fftconv.hip).
+#include "at_common.h"
+#include "generic_fft.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+using at::gfft::cmulf;
+using at::gfft::dft_r;
+using at::gfft::MAX_RADIX;
+
+constexpr int THREADS = 256;
+constexpr int MAX_N1 = 512;
+constexpr int MAX_N2 = 2048;
+constexpr int TILE_POINTS = 4096;   // complex points of one LDS tile (colfft) / one row pair (rowconv)
+constexpr int MAX_PASSES = 12;
+
+struct PassList {
+  int n;
+  int radix[MAX_PASSES];
+  int ns[MAX_PASSES];       // product of the radices before this pass
+};
+
+struct Plan {
+  int N1, N2;
+  int cw, lcw;              // columns per colfft tile (power of two), log2
+  int nhi;                  // ceil(N2 / 64): entries of the coarse row-twiddle table
+  PassList p1, p2;
+};
+
+bool factor(int n, PassList* p) {
+  p->n = 0;
+  int ns = 1;
+  auto take = [&](int r) {
+    while (n % r == 0) {
+      if (p->n == MAX_PASSES) return false;
+      p->radix[p->n] = r; p->ns[p->n] = ns; ++p->n;
+      ns *= r; n /= r;
+    }
+    return true;
+  };
+  return take(4) && take(2) && take(3) && take(5) && take(7) && n == 1;
+}
+
+bool make_plan(int64_t T, Plan* P) {
+  if (T < 2 || (T & 1) || T / 2 > (int64_t)MAX_N1 * MAX_N2) return false;
+  const int64_t M = T / 2;
+  {  // smooth?
+    int64_t m = M;
+    for (int r : {2, 3, 5, 7}) while (m % r == 0) m /= r;
+    if (m != 1) return false;
+  }
+  for (int64_t n2 = M < MAX_N2 ? M : MAX_N2; n2 >= 1; --n2) {
+    if (M % n2) continue;
+    const int64_t n1 = M / n2;
+    if (n1 > MAX_N1) return false;       // n1 only grows from here
+    P->N1 = (int)n1; P->N2 = (int)n2;
+    if (!factor(P->N1, &P->p1) || !factor(P->N2, &P->p2)) continue;
+    int cw = 64;
+    while (cw > 1 && P->N1 * cw > TILE_POINTS) cw >>= 1;
+    P->cw = cw; P->lcw = 0;
+    while ((1 << P->lcw) < cw) ++P->lcw;
+    P->nhi = (P->N2 + 63) / 64;
+    return true;
+  }
+  return false;
+}
+
+// table layout (float2 units)
+struct TableOffsets { int64_t tw1, tw2, rowtw, sp_lo, sp_hi, total; int rt; };
+TableOffsets table_offsets(const Plan& P) {
+  TableOffsets o;
+  o.rt = 64 + P.nhi;
+  o.tw1 = 0;
+  o.tw2 = o.tw1 + P.N1;
+  o.rowtw = o.tw2 + P.N2;
+  o.sp_lo = o.rowtw + (int64_t)P.N1 * o.rt;
+  o.sp_hi = o.sp_lo + P.N1;
+  o.total = o.sp_hi + P.N2;
+  return o;
+}
+
+// ---------------------------------------------------------------- in-place mixed-radix passes
+struct ColLayout {          // tile[point][column]
+  int lcw, cmask;
+  __device__ __forceinline__ void split(int id, int nb, int& batch, int& j) const { batch = id & cmask; j = id >> lcw; (void)nb; }
+  __device__ __forceinline__ int addr(int batch, int p) const { return (p << lcw) + batch; }
+  __device__ __forceinline__ int step(int ns) const { return ns << lcw; }
+};
+struct RowLayout {          // buf[row slot][point]
+  int N;
+  __device__ __forceinline__ void split(int id, int nb, int& batch, int& j) const { batch = id >= nb ? 1 : 0; j = id - (batch ? nb : 0); }
+  __device__ __forceinline__ int addr(int batch, int p) const { return batch * N + p; }
+  __device__ __forceinline__ int step(int ns) const { return ns; }
+};
+
+// One Stockham pass of radix R over `total` butterflies (all batches), in place: every thread reads
+// its butterflies, the workgroup meets, every thread writes.  tw = w_N^t, t < N.
+template <int R, class L>
+__device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const float2* __restrict__ tw, int N, int NS,
+                                             int total, const L lay) {
+  constexpr int MAXB = (TILE_POINTS / R + THREADS - 1) / THREADS;
+  const int nb = N / R;
+  const int tstep = nb / NS;                 // w_{NS R}^k = w_N^{k tstep}
+  const float inv_ns = 1.0f / (float)NS;
+  float2 v[MAXB][MAX_RADIX];
+  int o[MAXB];
+  // opaque copy of the thread index: keeps the per-butterfly index arithmetic of every pass variant
+  // from being hoisted out of the pass loop (that cost > 128 live registers and spills)
+  int tid = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid));
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int id = tid + THREADS * b;
+    if (id < total) {
+      int batch, j;
+      lay.split(id, nb, batch, j);
+      const int jd = (int)(((float)j + 0.5f) * inv_ns);     // j / NS (exact: j < 2048)
+      const int k = j - jd * NS;
+#pragma unroll
+      for (int q = 0; q < R; ++q) v[b][q] = buf[lay.addr(batch, j + nb * q)];
+      if (NS > 1) {
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[b][q] = cmulf(v[b][q], tw[k * q * tstep]);
+      }
+      dft_r<R>(v[b]);
+      o[b] = lay.addr(batch, jd * NS * R + k);
+    }
+  }
+  __syncthreads();
+  const int st = lay.step(NS);
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int id = tid + THREADS * b;
+    if (id < total) {
+#pragma unroll
+      for (int q = 0; q < R; ++q) buf[o[b] + st * q] = v[b][q];
+    }
+  }
+  __syncthreads();
+}
+
+template <class L>
+__device__ __forceinline__ void run_passes(float2* buf, const float2* tw, int N, const PassList& pl, int batches, const L lay) {
+  for (int p = 0; p < pl.n; ++p) {
+    const int R = pl.radix[p];
+    const int total = (N / R) * batches;
+    if (R == 4) pass_inplace<4>(buf, tw, N, pl.ns[p], total, lay);
+    else if (R == 2) pass_inplace<2>(buf, tw, N, pl.ns[p], total, lay);
+    else if (R == 3) pass_inplace<3>(buf, tw, N, pl.ns[p], total, lay);
+    else if (R == 5) pass_inplace<5>(buf, tw, N, pl.ns[p], total, lay);
+    else pass_inplace<7>(buf, tw, N, pl.ns[p], total, lay);
+  }
+}
+
+// ---------------------------------------------------------------- column FFT
+struct ColArgs {
+  const float2* src;        // (rows, N1, N2)
+  float2* dst;              // (rows, N1, N2); may alias src (a workgroup owns its columns)
+  const float2* tw1;        // w_N1^t
+  int64_t rows;
+  int N1, N2, cw, lcw, tiles;
+  PassList pl;
+};
+
+template <bool CONJ_OUT>
+__global__ __launch_bounds__(THREADS, 4) void colfft_kernel(const ColArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float2 smem[];
+  float2* tile = smem;                       // [N1][cw]
+  float2* tw = smem + (A.N1 << A.lcw);       // [N1]
+  const int64_t row = blockIdx.x / A.tiles;
+  const int t = (int)(blockIdx.x - row * A.tiles);
+  const int n2_0 = t << A.lcw;
+  const int cmask = A.cw - 1;
+  const int npts = A.N1 << A.lcw;
+  const float2* __restrict__ src = A.src + row * (int64_t)A.N1 * A.N2;
+  float2* __restrict__ dst = A.dst + row * (int64_t)A.N1 * A.N2;
+  for (int i = threadIdx.x; i < A.N1; i += THREADS) tw[i] = A.tw1[i];
+#pragma unroll 4
+  for (int e = threadIdx.x; e < npts; e += THREADS) {
+    const int n1 = e >> A.lcw, n2 = n2_0 + (e & cmask);
+    tile[e] = n2 < A.N2 ? src[(int64_t)n1 * A.N2 + n2] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  run_passes(tile, tw, A.N1, A.pl, A.cw, ColLayout{A.lcw, cmask});
+#pragma unroll 4
+  for (int e = threadIdx.x; e < npts; e += THREADS) {
+    const int k1 = e >> A.lcw, n2 = n2_0 + (e & cmask);
+    if (n2 < A.N2) {
+      float2 v = tile[e];
+      if (CONJ_OUT) v.y = -v.y;
+      dst[(int64_t)k1 * A.N2 + n2] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- row FFTs + spectrum product
+struct RowArgs {
+  float2* ax;               // (B*C, N1, N2): column-transformed signal, overwritten with the result
+  const float2* ah;         // (B*Cir, N1, N2): column-transformed impulse response
+  const float* scale;       // (B*Cir) or null
+  const float2* tw2;        // w_N2^t
+  const float2* rowtw;      // (N1, 64 + nhi): w_M^{k1 b}, b < 64; w_M^{64 k1 a}, a < nhi
+  const float2* sp_lo;      // w_T^{k1}
+  const float2* sp_hi;      // w_T^{N1 k2}
+  int C, Cir;
+  int N1, N2, rt, npairs;
+  float inv_m;
+  PassList pl;
+};
+
+constexpr int ROW_LOADS = TILE_POINTS / THREADS;      // 16: points of a row pair per thread
+constexpr int SPEC_ITERS = MAX_N2 / THREADS;          // 8: bins of one row per thread
+
+// X[k], X[M-k] of the real signal from Z[k], Z[M-k] of its half-length complex transform; w = w_T^k.
+__device__ __forceinline__ void real_split(float2 zk, float2 zm, float2 w, float2& xk, float2& xm) {
+  // X[k] = (zk + conj zm)/2 - i w (zk - conj zm)/2;  X[M-k] = conj(the same with +)
+  const float sr = zk.x + zm.x, si = zk.y - zm.y;      // zk + conj zm
+  const float dr = zk.x - zm.x, di = zk.y + zm.y;      // zk - conj zm
+  // -i w d = -i (wx + i wy)(dr + i di) = (wx di + wy dr) + i (wy di - wx dr)
+  const float pr = fmaf(w.x, di, w.y * dr), pi = fmaf(w.y, di, -w.x * dr);
+  xk = make_float2(0.5f * (sr + pr), 0.5f * (si + pi));
+  xm = make_float2(0.5f * (sr - pr), 0.5f * (-si + pi));
+}
+
+// the inverse: Z'[k], Z'[M-k] of the half-length inverse transform from Y[k], Y[M-k]
+__device__ __forceinline__ void real_merge(float2 yk, float2 ym, float2 w, float2& zk, float2& zm) {
+  // Z'[k] = (yk + conj ym)/2 + i conj(w) (yk - conj ym)/2;  Z'[M-k] = conj of the same with -
+  const float sr = yk.x + ym.x, si = yk.y - ym.y;
+  const float dr = yk.x - ym.x, di = yk.y + ym.y;
+  // i conj(w) d = i (wx - i wy)(dr + i di) = (wy dr - wx di) + i (wx dr + wy di)
+  const float pr = fmaf(w.y, dr, -w.x * di), pi = fmaf(w.x, dr, w.y * di);
+  zk = make_float2(0.5f * (sr + pr), 0.5f * (si + pi));
+  zm = make_float2(0.5f * (sr - pr), 0.5f * (-si + pi));
+}
+
+__global__ __launch_bounds__(THREADS, 2) void rowconv_kernel(const RowArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float2 smem[];
+  const int N2 = A.N2;
+  float2* buf = smem;                       // [2][N2]
+  float2* tw = smem + 2 * N2;               // [N2]
+  float2* rt = tw + N2;                     // [2][rt]
+  const int64_t xrow = blockIdx.x / A.npairs;
+  const int p = (int)(blockIdx.x - xrow * A.npairs);
+  const int k1a = p, k1b = (A.N1 - p) % A.N1;
+  const bool self = k1a == k1b;
+  const int nrow = self ? 1 : 2;
+  const int64_t b = xrow / A.C;
+  const int c = (int)(xrow - b * A.C);
+  const int64_t hrow = b * A.Cir + (A.Cir == 1 ? 0 : c);
+  const int64_t MM = (int64_t)A.N1 * N2;
+  float2* __restrict__ gx = A.ax + xrow * MM;
+  const float2* __restrict__ gh = A.ah + hrow * MM;
+  const int npts = nrow * N2;
+
+  float2 r[ROW_LOADS];
+  auto fetch = [&](const float2* __restrict__ g) {
+#pragma unroll
+    for (int i = 0; i < ROW_LOADS; ++i) {
+      const int e = (int)threadIdx.x + THREADS * i;
+      if (e < npts) {
+        const int s = e >= N2 ? 1 : 0;
+        r[i] = g[(int64_t)(s ? k1b : k1a) * N2 + (e - s * N2)];
+      }
+    }
+  };
+  fetch(gx);
+  for (int i = threadIdx.x; i < N2; i += THREADS) tw[i] = A.tw2[i];
+  for (int i = threadIdx.x; i < nrow * A.rt; i += THREADS) {
+    const int s = i >= A.rt ? 1 : 0;
+    rt[i] = A.rowtw[(int64_t)(s ? k1b : k1a) * A.rt + (i - s * A.rt)];
+  }
+  __syncthreads();
+
+  const RowLayout lay{N2};
+  const float2 wlo = A.sp_lo[k1a];
+  const int slot_b = self ? 0 : N2;
+  const float sc = (A.scale ? A.scale[hrow] : 1.0f) * A.inv_m;
+  float2 Xk[SPEC_ITERS], Xm[SPEC_ITERS];
+
+  // phase 0: signal rows -> X;  phase 1: IR rows -> H, Y = X H, Z' (conjugated) back into the
+  // slots;  phase 2: the transform back.  One copy of the pass code serves all three.
+  for (int ph = 0; ph < 3; ++ph) {
+    int tid = (int)threadIdx.x;             // opaque per phase: nothing below is hoisted out of the loop
+    asm volatile("" : "+v"(tid));
+    if (ph < 2) {                           // twiddle w_M^{k1 n2} and into LDS
+#pragma unroll
+      for (int i = 0; i < ROW_LOADS; ++i) {
+        const int e = tid + THREADS * i;
+        if (e < npts) {
+          const int s = e >= N2 ? 1 : 0;
+          const int n2 = e - s * N2;
+          const float2 w = cmulf(rt[s * A.rt + (n2 & 63)], rt[s * A.rt + 64 + (n2 >> 6)]);
+          buf[e] = cmulf(r[i], w);
+        }
+      }
+      __syncthreads();
+      if (ph == 0) fetch(gh);               // the IR rows arrive while the signal rows are transformed
+    }
+    run_passes(buf, tw, N2, A.pl, nrow, lay);
+    if (ph == 2) break;
+    // Every bin pair (k, M - k) is read (and in phase 1 rewritten) by exactly one thread, so the
+    // product spectrum goes straight back into the slots it came from.  The inverse transform
+    // runs as a forward one on conj(Z'); colfft<true> conjugates at the end.
+#pragma unroll
+    for (int i = 0; i < SPEC_ITERS; ++i) {
+      const int k2 = tid + THREADS * i;
+      const int k2m = k1a == 0 ? (k2 == 0 ? 0 : N2 - k2) : N2 - 1 - k2;
+      if (k2 < N2 && (!self || k2 <= k2m)) {
+        const float2 zk = buf[k2], zm = buf[slot_b + k2m];
+        const bool dc = k1a == 0 && k2 == 0;            // DC and Nyquist, both real, packed in Z[0]
+        const float2 w = cmulf(wlo, A.sp_hi[k2]);
+        float2 sk, sm;
+        if (dc) { sk = make_float2(zk.x + zk.y, 0.f); sm = make_float2(zk.x - zk.y, 0.f); }
+        else real_split(zk, zm, w, sk, sm);
+        if (ph == 0) { Xk[i] = sk; Xm[i] = sm; }
+        else {
+          float2 ok, om;
+          if (dc) {
+            const float y0 = Xk[i].x * sk.x * sc, ym = Xm[i].x * sm.x * sc;
+            ok = make_float2(0.5f * (y0 + ym), 0.5f * (y0 - ym));
+            om = ok;
+          } else {
+            float2 yk = cmulf(Xk[i], sk), ym = cmulf(Xm[i], sm);
+            yk.x *= sc; yk.y *= sc; ym.x *= sc; ym.y *= sc;
+            real_merge(yk, ym, w, ok, om);
+          }
+          buf[k2] = make_float2(ok.x, -ok.y);
+          if (!(self && k2 == k2m)) buf[slot_b + k2m] = make_float2(om.x, -om.y);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < ROW_LOADS; ++i) {
+    const int e = (int)threadIdx.x + THREADS * i;
+    if (e < npts) {
+      const int s = e >= N2 ? 1 : 0;
+      const int n2 = e - s * N2;
+      const float2 w = cmulf(rt[s * A.rt + (n2 & 63)], rt[s * A.rt + 64 + (n2 >> 6)]);
+      gx[(int64_t)(s ? k1b : k1a) * N2 + n2] = cmulf(buf[e], w);
+    }
+  }
+}
+
+inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" {
+
+// 1 when T has a four-step plan (even, T/2 = N1 N2 with N1 <= 512, N2 <= 2048, {2,3,5,7}-smooth)
+int at_longconv_supported(int64_t T) {
+  Plan P;
+  return make_plan(T, &P) ? 1 : 0;
+}
+
+// the split chosen for T (for tests and documentation)
+int at_longconv_plan(int64_t T, int* n1, int* n2) {
+  Plan P;
+  if (!make_plan(T, &P)) return AT_ERR_UNSUPPORTED;
+  if (n1) *n1 = P.N1;
+  if (n2) *n2 = P.N2;
+  return AT_OK;
+}
+
+// floats of the twiddle tables of length T
+int64_t at_longconv_table_floats(int64_t T) {
+  Plan P;
+  if (!make_plan(T, &P)) return AT_ERR_UNSUPPORTED;
+  return 2 * table_offsets(P).total;
+}
+
+// fills the tables (host memory, `n` floats as at_longconv_table_floats says), evaluated in double
+int at_longconv_tables_host(int64_t T, float* out, int64_t n) {
+  Plan P;
+  if (!out || !make_plan(T, &P)) return out ? AT_ERR_UNSUPPORTED : AT_ERR_INVALID;
+  const TableOffsets o = table_offsets(P);
+  if (n != 2 * o.total) return AT_ERR_INVALID;
+  const int64_t M = T / 2;
+  auto put = [&](int64_t at, int64_t num, int64_t den) {    // (cos, -sin)(2 pi num / den)
+    num %= den;
+    const double a = 2.0 * M_PI * (double)num / (double)den;
+    out[2 * at] = (float)std::cos(a);
+    out[2 * at + 1] = (float)(-std::sin(a));
+  };
+  for (int t = 0; t < P.N1; ++t) put(o.tw1 + t, t, P.N1);
+  for (int t = 0; t < P.N2; ++t) put(o.tw2 + t, t, P.N2);
+  for (int k1 = 0; k1 < P.N1; ++k1) {
+    for (int b = 0; b < 64; ++b) put(o.rowtw + (int64_t)k1 * o.rt + b, (int64_t)k1 * b, M);
+    for (int a = 0; a < P.nhi; ++a) put(o.rowtw + (int64_t)k1 * o.rt + 64 + a, (int64_t)k1 * 64 * a, M);
+  }
+  for (int k1 = 0; k1 < P.N1; ++k1) put(o.sp_lo + k1, k1, T);
+  for (int k2 = 0; k2 < P.N2; ++k2) put(o.sp_hi + k2, (int64_t)P.N1 * k2, T);
+  return AT_OK;
+}
+
+// scratch: the column-transformed impulse responses
+int64_t at_longconv_workspace_bytes(int64_t B, int64_t C, int64_t Cir, int64_t T) {
+  if (B < 0 || C <= 0 || Cir <= 0 || T <= 0) return AT_ERR_INVALID;
+  return align256(B * Cir * T * 4);
+}
+
+// x (B,C,T), ir (B,Cir,T) with Cir == 1 or Cir == C, scale (B,Cir) or NULL, tables (device copy of
+// at_longconv_tables_host), out (B,C,T): out = irfft(rfft(x) rfft(ir)) * scale.
+int at_longconv_circ_f32(const float* x, const float* ir, const float* scale, int64_t B, int64_t C, int64_t Cir, int64_t T,
+                         const float* tables, float* out, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (B == 0) return AT_OK;
+  if (!x || !ir || !out || !tables || B < 0 || C <= 0 || T <= 0 || (Cir != 1 && Cir != C)) return AT_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ir) | reinterpret_cast<uintptr_t>(out)) & 7)
+    return AT_ERR_INVALID;
+  Plan P;
+  if (!make_plan(T, &P)) return AT_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < at_longconv_workspace_bytes(B, C, Cir, T)) return AT_ERR_INVALID;
+  const TableOffsets o = table_offsets(P);
+  const float2* tb = reinterpret_cast<const float2*>(tables);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int tiles = (P.N2 + P.cw - 1) / P.cw;
+  const int64_t rows_x = B * C, rows_h = B * Cir;
+  if (rows_x * tiles > 0x7fffffffLL || rows_x * (P.N1 / 2 + 1) > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
+
+  ColArgs ca;
+  ca.tw1 = tb + o.tw1; ca.N1 = P.N1; ca.N2 = P.N2; ca.cw = P.cw; ca.lcw = P.lcw; ca.tiles = tiles; ca.pl = P.p1;
+  const size_t col_lds = ((size_t)P.N1 * P.cw + P.N1) * sizeof(float2);
+  int e = at::allow_big_lds(reinterpret_cast<const void*>(colfft_kernel<false>));
+  if (e != AT_OK) return e;
+  e = at::allow_big_lds(reinterpret_cast<const void*>(colfft_kernel<true>));
+  if (e != AT_OK) return e;
+  e = at::allow_big_lds(reinterpret_cast<const void*>(rowconv_kernel));
+  if (e != AT_OK) return e;
+
+  float2* ah = reinterpret_cast<float2*>(workspace);
+  float2* ax = reinterpret_cast<float2*>(out);
+  ca.src = reinterpret_cast<const float2*>(ir); ca.dst = ah; ca.rows = rows_h;
+  hipLaunchKernelGGL(colfft_kernel<false>, dim3((unsigned)(rows_h * tiles)), dim3(THREADS), col_lds, st, ca);
+  AT_LAUNCH_CHECK();
+  ca.src = reinterpret_cast<const float2*>(x); ca.dst = ax; ca.rows = rows_x;
+  hipLaunchKernelGGL(colfft_kernel<false>, dim3((unsigned)(rows_x * tiles)), dim3(THREADS), col_lds, st, ca);
+  AT_LAUNCH_CHECK();
+
+  RowArgs ra;
+  ra.ax = ax; ra.ah = ah; ra.scale = scale; ra.tw2 = tb + o.tw2; ra.rowtw = tb + o.rowtw; ra.sp_lo = tb + o.sp_lo;
+  ra.sp_hi = tb + o.sp_hi; ra.C = (int)C; ra.Cir = (int)Cir; ra.N1 = P.N1; ra.N2 = P.N2; ra.rt = o.rt;
+  ra.npairs = P.N1 / 2 + 1; ra.inv_m = 1.0f / (float)(T / 2); ra.pl = P.p2;
+  const size_t row_lds = ((size_t)3 * P.N2 + 2 * o.rt) * sizeof(float2);
+  hipLaunchKernelGGL(rowconv_kernel, dim3((unsigned)(rows_x * ra.npairs)), dim3(THREADS), row_lds, st, ra);
+  AT_LAUNCH_CHECK();
+
+  ca.src = ax; ca.dst = ax; ca.rows = rows_x;
+  hipLaunchKernelGGL(colfft_kernel<true>, dim3((unsigned)(rows_x * tiles)), dim3(THREADS), col_lds, st, ca);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+}  // extern "C"

@@ -1,4 +1,4 @@
-// Generic-size STFT / inverse-STFT frames for gfx950: n_fft even, n_fft / 2 = 2^a 3^b 5^c, up to 16384.
+// Generic-size STFT / inverse-STFT frames for gfx950: n_fft even, n_fft / 2 = 2^a 3^b 5^c 7^d, up to 16384.
 //
 // Covers what the wave-FFT kernels (csrc/stft.hip, csrc/istft.hip: powers of two up to 2048) do
 // not: the reference's default window for 96 / 192 kHz audio (audio_signal.py:1066-1070 gives
@@ -7,7 +7,7 @@
 //
 // One workgroup transforms one frame at a time.  The real FFT of length N is a complex FFT of
 // length M = N / 2 on z[n] = x[2n] + i x[2n+1] plus the split step (as in stft.hip); the complex
-// FFT is a Stockham autosort with mixed radices 4 / 2 / 3 / 5 between two LDS buffers, one
+// FFT is a Stockham autosort with mixed radices 4 / 2 / 3 / 5 / 7 between two LDS buffers, one
 // __syncthreads() per pass.  Twiddles come from the (cos, -sin)(2 pi k / N) table the fast
 // kernels use (w_M^k = table[2 k]).  It is a correct, HBM-class path (LDS traffic per frame is
 // ~6 passes x 16 B per point), not a tuned one: these sizes are not on BASELINE.json's configs.
@@ -36,57 +36,8 @@ struct GenInvArgs {
   int radix[16];
 };
 
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
-  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
-}
-
-// forward DFT of R points in place
-template <int R>
-__device__ __forceinline__ void dft_r(float2 (&v)[5]);
-template <>
-__device__ __forceinline__ void dft_r<2>(float2 (&v)[5]) {
-  const float2 a = v[0], b = v[1];
-  v[0] = make_float2(a.x + b.x, a.y + b.y);
-  v[1] = make_float2(a.x - b.x, a.y - b.y);
-}
-template <>
-__device__ __forceinline__ void dft_r<4>(float2 (&v)[5]) {
-  const float2 t0 = make_float2(v[0].x + v[2].x, v[0].y + v[2].y), t1 = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
-  const float2 t2 = make_float2(v[1].x + v[3].x, v[1].y + v[3].y), t3 = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
-  v[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
-  v[2] = make_float2(t0.x - t2.x, t0.y - t2.y);
-  v[1] = make_float2(t1.x + t3.y, t1.y - t3.x);   // t1 - i t3
-  v[3] = make_float2(t1.x - t3.y, t1.y + t3.x);   // t1 + i t3
-}
-template <>
-__device__ __forceinline__ void dft_r<3>(float2 (&v)[5]) {
-  const float S3 = 0.86602540378443864676f;       // sin(2 pi / 3)
-  const float2 s = make_float2(v[1].x + v[2].x, v[1].y + v[2].y);
-  const float2 d = make_float2(v[1].x - v[2].x, v[1].y - v[2].y);
-  const float2 m = make_float2(v[0].x - 0.5f * s.x, v[0].y - 0.5f * s.y);
-  v[0] = make_float2(v[0].x + s.x, v[0].y + s.y);
-  // X1 = m - i S3 d,  X2 = m + i S3 d
-  v[1] = make_float2(m.x + S3 * d.y, m.y - S3 * d.x);
-  v[2] = make_float2(m.x - S3 * d.y, m.y + S3 * d.x);
-}
-template <>
-__device__ __forceinline__ void dft_r<5>(float2 (&v)[5]) {
-  const float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;   // cos(2 pi/5), cos(4 pi/5)
-  const float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;    // sin(2 pi/5), sin(4 pi/5)
-  const float2 a1 = make_float2(v[1].x + v[4].x, v[1].y + v[4].y), b1 = make_float2(v[1].x - v[4].x, v[1].y - v[4].y);
-  const float2 a2 = make_float2(v[2].x + v[3].x, v[2].y + v[3].y), b2 = make_float2(v[2].x - v[3].x, v[2].y - v[3].y);
-  const float2 x0 = v[0];
-  v[0] = make_float2(x0.x + a1.x + a2.x, x0.y + a1.y + a2.y);
-  const float2 p1 = make_float2(x0.x + C1 * a1.x + C2 * a2.x, x0.y + C1 * a1.y + C2 * a2.y);
-  const float2 p2 = make_float2(x0.x + C2 * a1.x + C1 * a2.x, x0.y + C2 * a1.y + C1 * a2.y);
-  const float2 q1 = make_float2(S1 * b1.x + S2 * b2.x, S1 * b1.y + S2 * b2.y);
-  const float2 q2 = make_float2(S2 * b1.x - S1 * b2.x, S2 * b1.y - S1 * b2.y);
-  // X_k = p - i q  (k = 1, 2),  X_{5-k} = p + i q
-  v[1] = make_float2(p1.x + q1.y, p1.y - q1.x);
-  v[4] = make_float2(p1.x - q1.y, p1.y + q1.x);
-  v[2] = make_float2(p2.x + q2.y, p2.y - q2.x);
-  v[3] = make_float2(p2.x - q2.y, p2.y + q2.x);
-}
+using at::gfft::cmulf;
+using at::gfft::dft_r;
 
 template <int R>
 __device__ __forceinline__ void stockham_pass(const float2* __restrict__ src, float2* __restrict__ dst,
@@ -95,7 +46,7 @@ __device__ __forceinline__ void stockham_pass(const float2* __restrict__ src, fl
   const int tstep = M / (NS * R);          // w_{NS R}^k = w_M^{k tstep}
   for (int j = threadIdx.x; j < nb; j += blockDim.x) {
     const int k = j % NS;
-    float2 v[5];
+    float2 v[at::gfft::MAX_RADIX];
 #pragma unroll
     for (int q = 0; q < R; ++q) v[q] = src[j + nb * q];
 #pragma unroll
@@ -115,7 +66,8 @@ __device__ __forceinline__ float2* run_passes(float2* a, float2* b, const float2
     if (R == 4) stockham_pass<4>(a, b, tw, M, NS);
     else if (R == 2) stockham_pass<2>(a, b, tw, M, NS);
     else if (R == 3) stockham_pass<3>(a, b, tw, M, NS);
-    else stockham_pass<5>(a, b, tw, M, NS);
+    else if (R == 5) stockham_pass<5>(a, b, tw, M, NS);
+    else stockham_pass<7>(a, b, tw, M, NS);
     __syncthreads();
     float2* t = a; a = b; b = t;
     NS *= R;
@@ -213,6 +165,7 @@ int generic_fft_plan(int n_fft, int* radix) {
   while (m % 2 == 0 && n < 16) { radix[n++] = 2; m /= 2; }
   while (m % 3 == 0 && n < 16) { radix[n++] = 3; m /= 3; }
   while (m % 5 == 0 && n < 16) { radix[n++] = 5; m /= 5; }
+  while (m % 7 == 0 && n < 16) { radix[n++] = 7; m /= 7; }
   if (m != 1) return 0;
   if (n == 0) { radix[0] = 1; return 0; }     // n_fft == 2: not worth a kernel
   return n;

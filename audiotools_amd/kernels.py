@@ -568,8 +568,15 @@ def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
     return out
 
 
-def fftconv(x: torch.Tensor, ir: torch.Tensor, scale: torch.Tensor = None):
-    """Circular convolution of x (B,C,T) with ir (B,1|C,T) at length T, times scale (B,1|C,1)."""
+def longconv_supported(T: int) -> bool:
+    """True when the hand-written four-step FFT has a plan for the length (``at_longconv_supported``)."""
+    return bool(_native.lib().at_longconv_supported(int(T)))
+
+
+def fftconv(x: torch.Tensor, ir: torch.Tensor, scale: torch.Tensor = None, engine: str = None):
+    """Circular convolution of x (B,C,T) with ir (B,1|C,T) at length T, times scale (B,1|C,1).
+    ``engine``: "fourstep" (csrc/longconv.hip), "rocfft" (csrc/fftconv.hip) or None = four-step
+    when the length has a plan (``AT_LONGCONV=0`` forces rocFFT for A/B runs)."""
     _require_native_ok(x)
     B, C, T = x.shape
     Cir = ir.shape[1]
@@ -578,6 +585,19 @@ def fftconv(x: torch.Tensor, ir: torch.Tensor, scale: torch.Tensor = None):
     if scale is not None:
         scale = scale.reshape(B, Cir).to(torch.float32).contiguous()
     lib = _native.lib()
+    if engine is None:
+        engine = "fourstep" if (os.environ.get("AT_LONGCONV", "1") != "0" and longconv_supported(T)) else "rocfft"
+    if engine == "fourstep":
+        tb = tables.longconv_tables(T, x.device)
+        need = int(lib.at_longconv_workspace_bytes(B, C, Cir, T))
+        if need < 0:
+            _native.check(need, "at_longconv_workspace_bytes")
+        ws = _workspace(need, x.device)
+        out = torch.empty_like(x)
+        code = lib.at_longconv_circ_f32(_native.ptr(x), _native.ptr(ir), _native.ptr(scale), B, C, Cir, T, _native.ptr(tb),
+                                        _native.ptr(out), _native.ptr(ws), ws.numel(), _native.current_stream(x.device))
+        _native.check(code, "at_longconv_circ_f32")
+        return out
     need = int(lib.at_fftconv_workspace_bytes(B, C, Cir, T))
     if need < 0:
         _native.check(need, "at_fftconv_workspace_bytes")

@@ -7,6 +7,7 @@ reference obtains from scipy / librosa / pyloudnorm / julius at
 (device, parameters) in ``_device_cache`` -- the counterpart of the
 reference's ``functools.lru_cache`` on ``get_window`` / ``get_mel_filters``.
 """
+import collections
 import functools
 import math
 
@@ -204,6 +205,32 @@ def stft_twiddles(n_fft: int, device):
         return out
 
     return device_table(("stft_tw", n_fft), device, make)
+
+
+_LONGCONV_LRU = collections.OrderedDict()
+_LONGCONV_MAX = 16
+
+
+def longconv_tables(T: int, device):
+    """Twiddle tables of the four-step convolution of length ``T`` (``at_longconv_tables_host``,
+    evaluated in double), on ``device``.  Signal lengths vary from batch to batch, so this cache
+    is a bounded LRU (each entry is ~100 KB), unlike the parameter-keyed tables above."""
+    k = (int(T), _dev_key(device))
+    hit = _LONGCONV_LRU.get(k)
+    if hit is None:
+        lib = _native.lib()
+        n = int(lib.at_longconv_table_floats(int(T)))
+        if n < 0:
+            _native.check(n, "at_longconv_table_floats")
+        host = np.empty(n, dtype=np.float32)
+        _native.check(lib.at_longconv_tables_host(int(T), host.ctypes.data, n), "at_longconv_tables_host")
+        hit = torch.from_numpy(host).to(device)
+        _LONGCONV_LRU[k] = hit
+        while len(_LONGCONV_LRU) > _LONGCONV_MAX:
+            _LONGCONV_LRU.popitem(last=False)
+    else:
+        _LONGCONV_LRU.move_to_end(k)
+    return hit
 
 
 def window(window_type: str, window_length: int, device):

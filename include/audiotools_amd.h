@@ -249,6 +249,25 @@ int64_t at_fftconv_workspace_bytes(int64_t B, int64_t C, int64_t Cir, int64_t T)
 int at_fftconv_circ_f32(const float* x, const float* ir, const float* scale, int64_t B, int64_t C, int64_t Cir,
                         int64_t T, float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- the same convolution by a hand-written four-step FFT (no rocFFT) --------------------
+ * Replaces  audiotools/core/effects.py:102-121  for the lengths it has a plan for: T even,
+ * T/2 = N1 N2 with N1 <= 512, N2 <= 2048 and only the prime factors 2, 3, 5, 7 (every whole number
+ * of seconds at 8 / 16 / 22.05 / 24 / 32 / 44.1 / 48 kHz up to ~40 s; at_longconv_supported tells).
+ * Four launches: column FFTs of x and of the IR, one kernel that does the row FFTs, the real-FFT
+ * split, the product, the inverse split and the row FFTs back, and the column FFTs back.
+ *   tables: device copy of at_longconv_tables_host(T, buf, at_longconv_table_floats(T)) -- the
+ *   twiddles, evaluated in double on the host; arguments otherwise as at_fftconv_circ_f32.
+ *   x, ir and out must be 8-byte aligned; out doubles as the signal's work array.
+ */
+int at_longconv_supported(int64_t T);
+int at_longconv_plan(int64_t T, int* n1, int* n2);
+int64_t at_longconv_table_floats(int64_t T);
+int at_longconv_tables_host(int64_t T, float* out, int64_t n);
+int64_t at_longconv_workspace_bytes(int64_t B, int64_t C, int64_t Cir, int64_t T);
+int at_longconv_circ_f32(const float* x, const float* ir, const float* scale, int64_t B, int64_t C, int64_t Cir,
+                         int64_t T, const float* tables, float* out, void* workspace, int64_t workspace_bytes,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

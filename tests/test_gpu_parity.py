@@ -287,6 +287,50 @@ def test_equalizer_and_filterbank_properties():
     assert float((fb.sum(-1).cpu() - x).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("T", [16, 126, 4096, 8192, 12288, 9600, 44100, 24000, 2 * 81 * 1225, 240000])
+def test_fourstep_convolution_vs_float64(T):
+    """csrc/longconv.hip (column FFTs, row-pair kernel, column FFTs back) against a float64 FFT
+    convolution and against the rocFFT engine: N1 = 1 (one row, self-paired), even and odd N1
+    (self-paired middle row or not), radix 7, partial column tiles, per-item scale, Cir = 1 / C."""
+    from audiotools_amd import kernels
+    assert kernels.longconv_supported(T)
+    B, C = (2, 2) if T > 50000 else (3, 2)
+    g = torch.Generator().manual_seed(T % 97)
+    x = torch.randn(B, C, T, generator=g)
+    for Cir in (1, C):
+        ir = torch.randn(B, Cir, T, generator=g) * torch.exp(-torch.arange(T) / (0.2 * T))
+        scale = torch.rand(B, Cir, 1, generator=g) + 0.5
+        ref = torch.fft.irfft(torch.fft.rfft(x.double()) * torch.fft.rfft(ir.double()), n=T) * scale.double()
+        got = kernels.fftconv(x.cuda(), ir.cuda(), scale.cuda(), engine="fourstep")
+        roc = kernels.fftconv(x.cuda(), ir.cuda(), scale.cuda(), engine="rocfft")
+        e4, er = rel_err(got.double(), ref), rel_err(roc.double(), ref)
+        assert e4 < 2e-6, (T, Cir, e4, er)
+        assert e4 < 4 * er + 2e-7, (T, Cir, e4, er)       # as accurate as the library transform
+    # unit impulse at an odd delay: a circular shift, exactly representable
+    imp = torch.zeros(B, 1, T)
+    imp[..., 7 % T] = 1
+    back = kernels.fftconv(x.cuda(), imp.cuda(), None, engine="fourstep")
+    assert float((back.cpu() - torch.roll(x, 7 % T, -1)).abs().max()) < 2e-5
+
+
+def test_fourstep_is_the_default_engine(monkeypatch):
+    from audiotools_amd import kernels
+    x = torch.randn(2, 1, 48000, device="cuda")
+    ir = torch.randn(2, 1, 48000, device="cuda")
+    called = []
+    lib = _native.lib()
+    orig = lib.at_longconv_circ_f32
+    class Spy:
+        def __call__(self, *a):
+            called.append(1)
+            return orig(*a)
+    monkeypatch.setattr(lib, "at_longconv_circ_f32", Spy(), raising=False)
+    kernels.fftconv(x, ir)
+    assert called
+    assert not kernels.longconv_supported(10007) and not kernels.longconv_supported(2 * 11 * 64)
+    kernels.fftconv(torch.randn(1, 1, 10007, device="cuda"), torch.randn(1, 1, 10007, device="cuda"))   # rocFFT path still there
+
+
 @pytest.mark.parametrize("T,Lir", [(24000, 9600), (16000, 16000), (10007, 20000)])
 def test_convolve_vs_oracle(T, Lir):
     """Circular FFT convolution incl. a prime length (Bluestein in rocFFT) and IR longer than the signal."""
@@ -970,10 +1014,12 @@ def test_resample_mfma_and_valu_kernels_agree(old, new, T):
 
 
 @pytest.mark.parametrize("n_fft,hop,wt", [(4096, 1024, "hann"), (8192, 2048, "sqrt_hann"), (16384, 4096, "hann"), (400, 160, "hann"),
-                                          (1200, 300, "sqrt_hann"), (1920, 480, "hann"), (100, 33, "hann"), (4096, 1000, "average")])
+                                          (1200, 300, "sqrt_hann"), (1920, 480, "hann"), (100, 33, "hann"), (4096, 1000, "average"),
+                                          (882, 441, "hann"), (1764, 441, "hann")])
 def test_stft_generic_sizes_vs_oracle(n_fft, hop, wt):
     """Transform sizes beyond the fused wave-FFT kernels (the default window at 96 / 192 kHz is
-    4096 / 8192, audio_signal.py:1066-1070; speech front ends use 400 / 1200 / 1920): the mixed-radix
+    4096 / 8192, audio_signal.py:1066-1070; speech front ends use 400 / 1200 / 1920; 20 / 40 ms at
+    44.1 kHz are 882 / 1764 = 2 * 3^2 * 7^2 (* 2)): the mixed-radix
     workgroup FFT of csrc/stft_generic.hip, forward and inverse, against the oracle."""
     assert kernels.stft_native_supported(n_fft) and not kernels.stft_fused_supported(n_fft)
     T = 5 * n_fft + 137
