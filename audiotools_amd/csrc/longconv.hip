@@ -77,7 +77,11 @@ bool make_plan(int64_t T, Plan* P) {
     for (int r : {2, 3, 5, 7}) while (m % r == 0) m /= r;
     if (m != 1) return false;
   }
-  for (int64_t n2 = M < MAX_N2 ? M : MAX_N2; n2 >= 1; --n2) {
+  // AT_LONGCONV_N2MAX (development aid): cap on the row length, to move work between the two kernels
+  static const int n2_cap_env = at::env_int_once("AT_LONGCONV_N2MAX", MAX_N2);
+  int64_t n2_cap = n2_cap_env;
+  if (n2_cap < 1 || n2_cap > MAX_N2) n2_cap = MAX_N2;
+  for (int64_t n2 = M < n2_cap ? M : n2_cap; n2 >= 1; --n2) {
     if (M % n2) continue;
     const int64_t n1 = M / n2;
     if (n1 > MAX_N1) return false;       // n1 only grows from here
@@ -122,49 +126,63 @@ struct RowLayout {          // buf[row slot][point]
 };
 
 // One Stockham pass of radix R over `total` butterflies (all batches), in place: every thread reads
-// its butterflies, the workgroup meets, every thread writes.  tw = w_N^t, t < N.
-template <int R, class L>
+// its NB butterflies, the workgroup meets, every thread writes.  tw = w_N^t, t < N.
+// The loop is branch-free: a thread index past the last butterfly is clamped to it, so the surplus
+// lanes repeat that butterfly and store the same values to the same slots.  With predicated
+// iterations every butterfly was its own basic block and its LDS reads were not issued before the
+// previous butterfly had finished (the kernel ran at 46 % VALU and 26 % LDS utilisation).
+template <int R, int NB, class L>
 __device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const float2* __restrict__ tw, int N, int NS,
                                              int total, const L lay) {
-  constexpr int MAXB = (TILE_POINTS / R + THREADS - 1) / THREADS;
   const int nb = N / R;
   const int tstep = nb / NS;                 // w_{NS R}^k = w_N^{k tstep}
   const float inv_ns = 1.0f / (float)NS;
-  float2 v[MAXB][MAX_RADIX];
-  int o[MAXB];
+  float2 v[NB][MAX_RADIX];
+  int o[NB];
   // opaque copy of the thread index: keeps the per-butterfly index arithmetic of every pass variant
   // from being hoisted out of the pass loop (that cost > 128 live registers and spills)
   int tid = (int)threadIdx.x;
   asm volatile("" : "+v"(tid));
+  const int last = total - 1;
 #pragma unroll
-  for (int b = 0; b < MAXB; ++b) {
-    const int id = tid + THREADS * b;
-    if (id < total) {
-      int batch, j;
-      lay.split(id, nb, batch, j);
-      const int jd = (int)(((float)j + 0.5f) * inv_ns);     // j / NS (exact: j < 2048)
-      const int k = j - jd * NS;
+  for (int b = 0; b < NB; ++b) {
+    const int id = min(tid + THREADS * b, last);
+    int batch, j;
+    lay.split(id, nb, batch, j);
+    const int jd = (int)(((float)j + 0.5f) * inv_ns);     // j / NS (exact: j < 2048)
+    const int k = j - jd * NS;
 #pragma unroll
-      for (int q = 0; q < R; ++q) v[b][q] = buf[lay.addr(batch, j + nb * q)];
-      if (NS > 1) {
+    for (int q = 0; q < R; ++q) v[b][q] = buf[lay.addr(batch, j + nb * q)];
+    if (NS > 1) {
+      const int kt = k * tstep;
 #pragma unroll
-        for (int q = 1; q < R; ++q) v[b][q] = cmulf(v[b][q], tw[k * q * tstep]);
-      }
-      dft_r<R>(v[b]);
-      o[b] = lay.addr(batch, jd * NS * R + k);
+      for (int q = 1; q < R; ++q) v[b][q] = cmulf(v[b][q], tw[kt * q]);
     }
+    o[b] = lay.addr(batch, jd * NS * R + k);
   }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) dft_r<R>(v[b]);
   __syncthreads();
   const int st = lay.step(NS);
 #pragma unroll
-  for (int b = 0; b < MAXB; ++b) {
-    const int id = tid + THREADS * b;
-    if (id < total) {
+  for (int b = 0; b < NB; ++b) {
 #pragma unroll
-      for (int q = 0; q < R; ++q) buf[o[b] + st * q] = v[b][q];
-    }
+    for (int q = 0; q < R; ++q) buf[o[b] + st * q] = v[b][q];
   }
   __syncthreads();
+}
+
+// the variant for the iteration count of this launch (uniform): NB = ceil(total / THREADS)
+template <int R, class L>
+__device__ __forceinline__ void pass_dispatch(float2* buf, const float2* tw, int N, int NS, int total, const L lay) {
+  constexpr int MAXB = (TILE_POINTS / R + THREADS - 1) / THREADS;
+  const int nbi = (total + THREADS - 1) / THREADS;
+  if (nbi <= 1) pass_inplace<R, 1>(buf, tw, N, NS, total, lay);
+  else if (nbi == 2) pass_inplace<R, 2>(buf, tw, N, NS, total, lay);
+  else if (nbi == 3) pass_inplace<R, 3>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 4 && nbi == 4) pass_inplace<R, (MAXB >= 4 ? 4 : 1)>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 6 && nbi <= 6) pass_inplace<R, (MAXB >= 6 ? 6 : 1)>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 8) pass_inplace<R, (MAXB >= 8 ? 8 : 1)>(buf, tw, N, NS, total, lay);
 }
 
 template <class L>
@@ -172,11 +190,11 @@ __device__ __forceinline__ void run_passes(float2* buf, const float2* tw, int N,
   for (int p = 0; p < pl.n; ++p) {
     const int R = pl.radix[p];
     const int total = (N / R) * batches;
-    if (R == 4) pass_inplace<4>(buf, tw, N, pl.ns[p], total, lay);
-    else if (R == 2) pass_inplace<2>(buf, tw, N, pl.ns[p], total, lay);
-    else if (R == 3) pass_inplace<3>(buf, tw, N, pl.ns[p], total, lay);
-    else if (R == 5) pass_inplace<5>(buf, tw, N, pl.ns[p], total, lay);
-    else pass_inplace<7>(buf, tw, N, pl.ns[p], total, lay);
+    if (R == 4) pass_dispatch<4>(buf, tw, N, pl.ns[p], total, lay);
+    else if (R == 2) pass_dispatch<2>(buf, tw, N, pl.ns[p], total, lay);
+    else if (R == 3) pass_dispatch<3>(buf, tw, N, pl.ns[p], total, lay);
+    else if (R == 5) pass_dispatch<5>(buf, tw, N, pl.ns[p], total, lay);
+    else pass_dispatch<7>(buf, tw, N, pl.ns[p], total, lay);
   }
 }
 
@@ -261,7 +279,10 @@ __device__ __forceinline__ void real_merge(float2 yk, float2 ym, float2 w, float
   zm = make_float2(0.5f * (sr - pr), 0.5f * (-si + pi));
 }
 
-__global__ __launch_bounds__(THREADS, 2) void rowconv_kernel(const RowArgs A) {
+// 3 workgroups per CU (LDS: 49.5 KB each at N2 = 2000): 168 registers, 8 dwords spilled.  Measured at
+// cfg4: 2 per CU (176 registers, no spill) 2.7 ms, 3 per CU 2.15 ms -- the kernel is bound by barrier
+// and LDS latency, not by issue slots (profiles/r02_notes.md).
+__global__ __launch_bounds__(THREADS, 3) void rowconv_kernel(const RowArgs A) {
   extern __shared__ __attribute__((aligned(16))) float2 smem[];
   const int N2 = A.N2;
   float2* buf = smem;                       // [2][N2]
@@ -284,8 +305,8 @@ __global__ __launch_bounds__(THREADS, 2) void rowconv_kernel(const RowArgs A) {
   auto fetch = [&](const float2* __restrict__ g) {
 #pragma unroll
     for (int i = 0; i < ROW_LOADS; ++i) {
-      const int e = (int)threadIdx.x + THREADS * i;
-      if (e < npts) {
+      if (THREADS * i < npts) {             // uniform; lanes past the end repeat the last point
+        const int e = min((int)threadIdx.x + THREADS * i, npts - 1);
         const int s = e >= N2 ? 1 : 0;
         r[i] = g[(int64_t)(s ? k1b : k1a) * N2 + (e - s * N2)];
       }
@@ -313,8 +334,8 @@ __global__ __launch_bounds__(THREADS, 2) void rowconv_kernel(const RowArgs A) {
     if (ph < 2) {                           // twiddle w_M^{k1 n2} and into LDS
 #pragma unroll
       for (int i = 0; i < ROW_LOADS; ++i) {
-        const int e = tid + THREADS * i;
-        if (e < npts) {
+        if (THREADS * i < npts) {
+          const int e = min(tid + THREADS * i, npts - 1);
           const int s = e >= N2 ? 1 : 0;
           const int n2 = e - s * N2;
           const float2 w = cmulf(rt[s * A.rt + (n2 & 63)], rt[s * A.rt + 64 + (n2 >> 6)]);
@@ -361,8 +382,8 @@ __global__ __launch_bounds__(THREADS, 2) void rowconv_kernel(const RowArgs A) {
   }
 #pragma unroll
   for (int i = 0; i < ROW_LOADS; ++i) {
-    const int e = (int)threadIdx.x + THREADS * i;
-    if (e < npts) {
+    if (THREADS * i < npts) {
+      const int e = min((int)threadIdx.x + THREADS * i, npts - 1);
       const int s = e >= N2 ? 1 : 0;
       const int n2 = e - s * N2;
       const float2 w = cmulf(rt[s * A.rt + (n2 & 63)], rt[s * A.rt + 64 + (n2 >> 6)]);
