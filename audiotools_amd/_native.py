@@ -134,6 +134,7 @@ SIGNATURES = {
     "at_longconv_tables_host": (_i32, [_i64, _p, _i64]),
     "at_longconv_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "at_longconv_circ_f32": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _i64, _p]),
+    "at_longconv_room_f32": (_i32, [_p, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _i64, _p]),
     "at_lufs_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32]),
     "at_lufs_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _i32, _i32, _i32, _f64, _f32,
                            _i32, _p, _p, _i64, _p]),

@@ -205,10 +205,33 @@ struct ColArgs {
   const float2* tw1;        // w_N1^t
   int64_t rows;
   int N1, N2, cw, lcw, tiles;
+  // ROLLED source (the impulse response as the caller holds it): real rows of `src_pitch` floats
+  // whose first `src_len` samples are valid and the rest of the period T = 2 N1 N2 is zero, read
+  // rotated by shift[row] (effects.py:94-100: roll so that the peak sits at sample 0)
+  const float* rsrc;
+  const int64_t* shift;     // (rows) or null
+  int64_t src_pitch, src_len;
+  unsigned* peak;           // (rows) max |sample| as float bits (PEAK variants), zeroed by the caller
   PassList pl;
 };
 
-template <bool CONJ_OUT>
+constexpr int COL_CONJ = 1, COL_ROLLED = 2, COL_PEAK = 4;
+
+// max over the wave, then one atomic per wave.  |x| of a float compares like its bit pattern, and a
+// NaN (>= 0x7f800001) wins the integer max: the peak propagates NaN as at_absmax_f32 does.
+__device__ __forceinline__ void peak_commit(float m, unsigned* slot) {
+  unsigned u = __float_as_uint(m) & 0x7fffffffu;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)u, d, 64);
+    u = o > u ? o : u;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(slot, u);
+}
+
+__device__ __forceinline__ unsigned absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+template <int MODE>
 __global__ __launch_bounds__(THREADS, 4) void colfft_kernel(const ColArgs A) {
   extern __shared__ __attribute__((aligned(16))) float2 smem[];
   float2* tile = smem;                       // [N1][cw]
@@ -218,13 +241,37 @@ __global__ __launch_bounds__(THREADS, 4) void colfft_kernel(const ColArgs A) {
   const int n2_0 = t << A.lcw;
   const int cmask = A.cw - 1;
   const int npts = A.N1 << A.lcw;
-  const float2* __restrict__ src = A.src + row * (int64_t)A.N1 * A.N2;
   float2* __restrict__ dst = A.dst + row * (int64_t)A.N1 * A.N2;
+  unsigned pk = 0;
   for (int i = threadIdx.x; i < A.N1; i += THREADS) tw[i] = A.tw1[i];
+  if constexpr (MODE & COL_ROLLED) {
+    const float* __restrict__ rs = A.rsrc + row * A.src_pitch;
+    const int64_t T = 2 * (int64_t)A.N1 * A.N2;
+    int64_t sh = A.shift ? A.shift[row] % T : 0;
+    if (sh < 0) sh += T;
 #pragma unroll 4
-  for (int e = threadIdx.x; e < npts; e += THREADS) {
-    const int n1 = e >> A.lcw, n2 = n2_0 + (e & cmask);
-    tile[e] = n2 < A.N2 ? src[(int64_t)n1 * A.N2 + n2] : make_float2(0.f, 0.f);
+    for (int e = threadIdx.x; e < npts; e += THREADS) {
+      const int n1 = e >> A.lcw, n2 = n2_0 + (e & cmask);
+      float2 v = make_float2(0.f, 0.f);
+      if (n2 < A.N2) {
+        int64_t i0 = 2 * ((int64_t)n1 * A.N2 + n2) + sh;
+        if (i0 >= T) i0 -= T;
+        int64_t i1 = i0 + 1;
+        if (i1 >= T) i1 -= T;
+        if (i0 < A.src_len) v.x = rs[i0];
+        if (i1 < A.src_len) v.y = rs[i1];
+      }
+      tile[e] = v;
+    }
+  } else {
+    const float2* __restrict__ src = A.src + row * (int64_t)A.N1 * A.N2;
+#pragma unroll 4
+    for (int e = threadIdx.x; e < npts; e += THREADS) {
+      const int n1 = e >> A.lcw, n2 = n2_0 + (e & cmask);
+      const float2 v = n2 < A.N2 ? src[(int64_t)n1 * A.N2 + n2] : make_float2(0.f, 0.f);
+      if constexpr ((MODE & COL_PEAK) && !(MODE & COL_CONJ)) { pk = max(pk, max(absbits(v.x), absbits(v.y))); }
+      tile[e] = v;
+    }
   }
   __syncthreads();
   run_passes(tile, tw, A.N1, A.pl, A.cw, ColLayout{A.lcw, cmask});
@@ -233,10 +280,12 @@ __global__ __launch_bounds__(THREADS, 4) void colfft_kernel(const ColArgs A) {
     const int k1 = e >> A.lcw, n2 = n2_0 + (e & cmask);
     if (n2 < A.N2) {
       float2 v = tile[e];
-      if (CONJ_OUT) v.y = -v.y;
+      if constexpr (MODE & COL_CONJ) v.y = -v.y;
+      if constexpr ((MODE & COL_PEAK) && (MODE & COL_CONJ)) { pk = max(pk, max(absbits(v.x), absbits(v.y))); }
       dst[(int64_t)k1 * A.N2 + n2] = v;
     }
   }
+  if constexpr (MODE & COL_PEAK) peak_commit(__uint_as_float(pk), A.peak + row);
 }
 
 // ---------------------------------------------------------------- row FFTs + spectrum product
@@ -450,6 +499,79 @@ int64_t at_longconv_workspace_bytes(int64_t B, int64_t C, int64_t Cir, int64_t T
   return align256(B * Cir * T * 4);
 }
 
+}  // extern "C"
+
+namespace {
+
+struct IrSource {           // how the impulse response is held by the caller
+  const float* ptr;         // (B*Cir, pitch)
+  int64_t pitch, len;       // row pitch and valid prefix (samples at and after `len` count as zero)
+  const int64_t* shift;     // (B*Cir) rotation to apply while reading, or null
+  bool rolled;              // false: plain (B*Cir, T) rows, read as float2
+};
+
+int run_longconv(const float* x, const IrSource& ir, const float* scale, int64_t B, int64_t C, int64_t Cir, int64_t T,
+                 const float* tables, float* out, float* x_peak, float* y_peak, void* workspace, int64_t workspace_bytes,
+                 hipStream_t st) {
+  Plan P;
+  if (!make_plan(T, &P)) return AT_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < at_longconv_workspace_bytes(B, C, Cir, T)) return AT_ERR_INVALID;
+  const TableOffsets o = table_offsets(P);
+  const float2* tb = reinterpret_cast<const float2*>(tables);
+  const int tiles = (P.N2 + P.cw - 1) / P.cw;
+  const int64_t rows_x = B * C, rows_h = B * Cir;
+  if (rows_x * tiles > 0x7fffffffLL || rows_x * (P.N1 / 2 + 1) > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
+
+  ColArgs ca;
+  ca.tw1 = tb + o.tw1; ca.N1 = P.N1; ca.N2 = P.N2; ca.cw = P.cw; ca.lcw = P.lcw; ca.tiles = tiles; ca.pl = P.p1;
+  ca.rsrc = nullptr; ca.shift = nullptr; ca.src_pitch = 0; ca.src_len = 0; ca.peak = nullptr;
+  const size_t col_lds = ((size_t)P.N1 * P.cw + P.N1) * sizeof(float2);
+  const size_t row_lds = ((size_t)3 * P.N2 + 2 * o.rt) * sizeof(float2);
+  int e;
+  if ((e = at::allow_big_lds(reinterpret_cast<const void*>(rowconv_kernel))) != AT_OK) return e;
+  for (float* pkbuf : {x_peak, y_peak}) {
+    if (!pkbuf) continue;
+    const hipError_t he = hipMemsetAsync(pkbuf, 0, rows_x * sizeof(float), st);
+    if (he != hipSuccess) return AT_ERR_HIP(he);
+  }
+
+  float2* ah = reinterpret_cast<float2*>(workspace);
+  float2* ax = reinterpret_cast<float2*>(out);
+  const dim3 grid_h((unsigned)(rows_h * tiles)), grid_x((unsigned)(rows_x * tiles));
+  ca.dst = ah; ca.rows = rows_h;
+  if (ir.rolled) {
+    ca.src = nullptr; ca.rsrc = ir.ptr; ca.shift = ir.shift; ca.src_pitch = ir.pitch; ca.src_len = ir.len;
+    hipLaunchKernelGGL(colfft_kernel<COL_ROLLED>, grid_h, dim3(THREADS), col_lds, st, ca);
+  } else {
+    ca.src = reinterpret_cast<const float2*>(ir.ptr);
+    hipLaunchKernelGGL(colfft_kernel<0>, grid_h, dim3(THREADS), col_lds, st, ca);
+  }
+  AT_LAUNCH_CHECK();
+  ca.src = reinterpret_cast<const float2*>(x); ca.dst = ax; ca.rows = rows_x;
+  ca.peak = reinterpret_cast<unsigned*>(x_peak);
+  if (x_peak) hipLaunchKernelGGL(colfft_kernel<COL_PEAK>, grid_x, dim3(THREADS), col_lds, st, ca);
+  else hipLaunchKernelGGL(colfft_kernel<0>, grid_x, dim3(THREADS), col_lds, st, ca);
+  AT_LAUNCH_CHECK();
+
+  RowArgs ra;
+  ra.ax = ax; ra.ah = ah; ra.scale = scale; ra.tw2 = tb + o.tw2; ra.rowtw = tb + o.rowtw; ra.sp_lo = tb + o.sp_lo;
+  ra.sp_hi = tb + o.sp_hi; ra.C = (int)C; ra.Cir = (int)Cir; ra.N1 = P.N1; ra.N2 = P.N2; ra.rt = o.rt;
+  ra.npairs = P.N1 / 2 + 1; ra.inv_m = 1.0f / (float)(T / 2); ra.pl = P.p2;
+  hipLaunchKernelGGL(rowconv_kernel, dim3((unsigned)(rows_x * ra.npairs)), dim3(THREADS), row_lds, st, ra);
+  AT_LAUNCH_CHECK();
+
+  ca.src = ax; ca.dst = ax; ca.rows = rows_x;
+  ca.peak = reinterpret_cast<unsigned*>(y_peak);
+  if (y_peak) hipLaunchKernelGGL(colfft_kernel<COL_CONJ | COL_PEAK>, grid_x, dim3(THREADS), col_lds, st, ca);
+  else hipLaunchKernelGGL(colfft_kernel<COL_CONJ>, grid_x, dim3(THREADS), col_lds, st, ca);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 // x (B,C,T), ir (B,Cir,T) with Cir == 1 or Cir == C, scale (B,Cir) or NULL, tables (device copy of
 // at_longconv_tables_host), out (B,C,T): out = irfft(rfft(x) rfft(ir)) * scale.
 int at_longconv_circ_f32(const float* x, const float* ir, const float* scale, int64_t B, int64_t C, int64_t Cir, int64_t T,
@@ -458,47 +580,28 @@ int at_longconv_circ_f32(const float* x, const float* ir, const float* scale, in
   if (!x || !ir || !out || !tables || B < 0 || C <= 0 || T <= 0 || (Cir != 1 && Cir != C)) return AT_ERR_INVALID;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ir) | reinterpret_cast<uintptr_t>(out)) & 7)
     return AT_ERR_INVALID;
-  Plan P;
-  if (!make_plan(T, &P)) return AT_ERR_UNSUPPORTED;
-  if (!workspace || workspace_bytes < at_longconv_workspace_bytes(B, C, Cir, T)) return AT_ERR_INVALID;
-  const TableOffsets o = table_offsets(P);
-  const float2* tb = reinterpret_cast<const float2*>(tables);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int tiles = (P.N2 + P.cw - 1) / P.cw;
-  const int64_t rows_x = B * C, rows_h = B * Cir;
-  if (rows_x * tiles > 0x7fffffffLL || rows_x * (P.N1 / 2 + 1) > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
+  const IrSource src{ir, T, T, nullptr, false};
+  return run_longconv(x, src, scale, B, C, Cir, T, tables, out, nullptr, nullptr, workspace, workspace_bytes,
+                      reinterpret_cast<hipStream_t>(stream));
+}
 
-  ColArgs ca;
-  ca.tw1 = tb + o.tw1; ca.N1 = P.N1; ca.N2 = P.N2; ca.cw = P.cw; ca.lcw = P.lcw; ca.tiles = tiles; ca.pl = P.p1;
-  const size_t col_lds = ((size_t)P.N1 * P.cw + P.N1) * sizeof(float2);
-  int e = at::allow_big_lds(reinterpret_cast<const void*>(colfft_kernel<false>));
-  if (e != AT_OK) return e;
-  e = at::allow_big_lds(reinterpret_cast<const void*>(colfft_kernel<true>));
-  if (e != AT_OK) return e;
-  e = at::allow_big_lds(reinterpret_cast<const void*>(rowconv_kernel));
-  if (e != AT_OK) return e;
-
-  float2* ah = reinterpret_cast<float2*>(workspace);
-  float2* ax = reinterpret_cast<float2*>(out);
-  ca.src = reinterpret_cast<const float2*>(ir); ca.dst = ah; ca.rows = rows_h;
-  hipLaunchKernelGGL(colfft_kernel<false>, dim3((unsigned)(rows_h * tiles)), dim3(THREADS), col_lds, st, ca);
-  AT_LAUNCH_CHECK();
-  ca.src = reinterpret_cast<const float2*>(x); ca.dst = ax; ca.rows = rows_x;
-  hipLaunchKernelGGL(colfft_kernel<false>, dim3((unsigned)(rows_x * tiles)), dim3(THREADS), col_lds, st, ca);
-  AT_LAUNCH_CHECK();
-
-  RowArgs ra;
-  ra.ax = ax; ra.ah = ah; ra.scale = scale; ra.tw2 = tb + o.tw2; ra.rowtw = tb + o.rowtw; ra.sp_lo = tb + o.sp_lo;
-  ra.sp_hi = tb + o.sp_hi; ra.C = (int)C; ra.Cir = (int)Cir; ra.N1 = P.N1; ra.N2 = P.N2; ra.rt = o.rt;
-  ra.npairs = P.N1 / 2 + 1; ra.inv_m = 1.0f / (float)(T / 2); ra.pl = P.p2;
-  const size_t row_lds = ((size_t)3 * P.N2 + 2 * o.rt) * sizeof(float2);
-  hipLaunchKernelGGL(rowconv_kernel, dim3((unsigned)(rows_x * ra.npairs)), dim3(THREADS), row_lds, st, ra);
-  AT_LAUNCH_CHECK();
-
-  ca.src = ax; ca.dst = ax; ca.rows = rows_x;
-  hipLaunchKernelGGL(colfft_kernel<true>, dim3((unsigned)(rows_x * tiles)), dim3(THREADS), col_lds, st, ca);
-  AT_LAUNCH_CHECK();
-  return AT_OK;
+// The convolution as EffectMixin.apply_ir needs it (effects.py:92-121 with :160 and :175 folded in):
+//   ir (B*Cir, ir_pitch): the impulse responses as they are, `ir_len` <= T valid samples per row (the
+//     zero padding to T of effects.py:86-90 is implied, not read) and ir_shift (B*Cir) int64 or NULL:
+//     the rotation that puts the peak at sample 0 (effects.py:94-100), applied while reading;
+//   x_peak, y_peak (B*C) or NULL: max |x| and max |out| per row, found while the column transforms
+//     stream x in and the result out (NaN propagates, as in at_absmax_f32).
+int at_longconv_room_f32(const float* x, const float* ir, int64_t ir_pitch, int64_t ir_len, const int64_t* ir_shift,
+                         const float* scale, int64_t B, int64_t C, int64_t Cir, int64_t T, const float* tables, float* out,
+                         float* x_peak, float* y_peak, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (B == 0) return AT_OK;
+  if (!x || !ir || !out || !tables || B < 0 || C <= 0 || T <= 0 || (Cir != 1 && Cir != C) || ir_len < 0 || ir_len > T ||
+      ir_pitch < ir_len)
+    return AT_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 7) return AT_ERR_INVALID;
+  const IrSource src{ir, ir_pitch, ir_len, ir_shift, true};
+  return run_longconv(x, src, scale, B, C, Cir, T, tables, out, x_peak, y_peak, workspace, workspace_bytes,
+                      reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -152,13 +152,46 @@ class EffectMixin:
     def convolve(self, other, start_at_max: bool = True):
         """Circular FFT convolution with ``other`` (padded/truncated in place
         to this signal's length), rescaled by 1/max|ir| (effects.py:66-123)."""
-        pad_len = self.signal_length - other.signal_length
-        if pad_len > 0:
-            other.zero_pad(0, pad_len)
-        else:
-            other.truncate_samples(self.signal_length)
-        ir = other.audio_data
+        self._convolve(other, start_at_max, want_peaks=False)
+        return self
+
+    def _convolve(self, other, start_at_max: bool, want_peaks: bool):
+        """``convolve``; with ``want_peaks`` returns (max|x|, max|y|) per (B, C, 1) when the native
+        four-step path found them inside the transforms (apply_ir needs both), else None."""
+        T = self.signal_length
         x = self.audio_data
+        ir0 = other.audio_data
+        room = (kernels.is_native(x) and kernels.is_native(ir0) and _conv_shapes_ok(x, ir0) and kernels.longconv_enabled(T)
+                and ir0.shape[1] in (1, x.shape[1]))
+        peaks = None
+        if room:
+            # csrc/longconv.hip reads the impulse response as it is: the zero padding to T and the
+            # rotation to the peak (effects.py:86-100) happen in the load of its first kernel.  The peak
+            # value / position come from the un-padded samples (padding zeros never win the max).
+            L = min(ir0.shape[-1], T)
+            raw = ir0[..., :L].contiguous()
+            peak, idx = kernels.absmax(raw, want_index=True)
+            if start_at_max and raw.shape[1] != 1:
+                raise RuntimeError("start_at_max requires a single-channel impulse response")
+        pad_len = T - other.signal_length
+        if pad_len > 0:
+            other.zero_pad(0, pad_len)          # the reference pads / truncates its argument in place
+        else:
+            other.truncate_samples(T)
+        if room:
+            scale = 1 / peak[..., None].clamp(1e-5)
+            if raw.shape[0] != x.shape[0]:      # one impulse response for the whole batch (effects.py:106-111)
+                B = x.shape[0]
+                raw, scale, idx = raw.expand(B, -1, -1), scale.expand(B, -1, -1), idx.expand(B, -1)
+            res = kernels.room_convolve(x, raw, idx if start_at_max else None, scale, want_peaks=want_peaks)
+            if want_peaks:
+                y, xpk, ypk = res
+                peaks = (xpk[..., None], ypk[..., None])
+            else:
+                y = res
+            self.audio_data = y
+            return peaks
+        ir = other.audio_data
         if kernels.is_native(x) and kernels.is_native(ir) and _conv_shapes_ok(x, ir):
             # one pass for the peak value + position, one for the rotation (instead of abs, argmax,
             # arange, mod, gather, abs, max over (B, C, T) tensors)
@@ -182,7 +215,7 @@ class EffectMixin:
             scale = 1 / ir.abs().max(dim=-1, keepdim=True)[0].clamp(1e-5)
             y = fftconv_torch(x, ir) * scale
         self.audio_data = y
-        return self
+        return None
 
     def __matmul__(self, other):
         return self.convolve(other)
@@ -194,18 +227,22 @@ class EffectMixin:
             ir = ir.equalizer(ir_eq)
         if drr is not None:
             ir = ir.alter_drr(drr)
-        max_spk = _peak(self.audio_data)
         # The reference evaluates ``self.phase`` here unconditionally (effects.py:165): a full
         # STFT + angle whose result is unused unless ``use_original_phase``, leaving a STALE
         # ``stft_data`` behind.  Deliberate deviation (DESIGN.md "Deviations"): the phase is only
         # computed when it is used, and ``stft_data`` is left untouched otherwise.
         phase = self.phase if use_original_phase else None
-        self.convolve(ir)
+        x_in = self.audio_data
+        peaks = self._convolve(ir, True, want_peaks=True)
+        # max|input| (effects.py:160) and max|output| (:175): from inside the convolution when the
+        # native path ran, otherwise by their own passes
+        max_spk = peaks[0] if peaks is not None else _peak(x_in)
         if use_original_phase:
             self.stft()
             self.stft_data = self.magnitude * torch.exp(1j * phase)
             self.istft()
-        max_transformed = _peak(self.audio_data)
+            peaks = None
+        max_transformed = peaks[1] if peaks is not None else _peak(self.audio_data)
         scale_factor = max_spk.clamp(1e-8) / max_transformed.clamp(1e-8)
         self = self * scale_factor
         return self

@@ -568,9 +568,16 @@ def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
     return out
 
 
+_LONGCONV = os.environ.get("AT_LONGCONV", "1") != "0"       # development A/B switch, read once
+
+
 def longconv_supported(T: int) -> bool:
     """True when the hand-written four-step FFT has a plan for the length (``at_longconv_supported``)."""
     return bool(_native.lib().at_longconv_supported(int(T)))
+
+
+def longconv_enabled(T: int) -> bool:
+    return _LONGCONV and longconv_supported(T)
 
 
 def fftconv(x: torch.Tensor, ir: torch.Tensor, scale: torch.Tensor = None, engine: str = None):
@@ -586,7 +593,7 @@ def fftconv(x: torch.Tensor, ir: torch.Tensor, scale: torch.Tensor = None, engin
         scale = scale.reshape(B, Cir).to(torch.float32).contiguous()
     lib = _native.lib()
     if engine is None:
-        engine = "fourstep" if (os.environ.get("AT_LONGCONV", "1") != "0" and longconv_supported(T)) else "rocfft"
+        engine = "fourstep" if longconv_enabled(T) else "rocfft"
     if engine == "fourstep":
         tb = tables.longconv_tables(T, x.device)
         need = int(lib.at_longconv_workspace_bytes(B, C, Cir, T))
@@ -607,6 +614,37 @@ def fftconv(x: torch.Tensor, ir: torch.Tensor, scale: torch.Tensor = None, engin
                                    _native.ptr(ws), ws.numel(), _native.current_stream(x.device))
     _native.check(code, "at_fftconv_circ_f32")
     return out
+
+
+def room_convolve(x: torch.Tensor, ir: torch.Tensor, shift: torch.Tensor = None, scale: torch.Tensor = None,
+                  want_peaks: bool = False):
+    """``at_longconv_room_f32``: circular convolution of x (B,C,T) with the impulse responses ir
+    (B,1|C,L), L <= T, implicitly zero-padded to T and read rotated left by ``shift`` (B,1|C) --
+    the padding and roll of effects.py:86-100 are not materialised.  With ``want_peaks`` also
+    returns max|x| and max|out| per (B,C) row, found inside the transforms (effects.py:160, :175).
+    The length must have a four-step plan (``longconv_supported``)."""
+    _require_native_ok(x)
+    B, C, T = x.shape
+    Cir, L = ir.shape[1], ir.shape[2]
+    x = x.contiguous()
+    ir = ir.contiguous()
+    if scale is not None:
+        scale = scale.reshape(B, Cir).to(torch.float32).contiguous()
+    sh = None if shift is None else shift.reshape(B, Cir).to(torch.int64).contiguous()
+    lib = _native.lib()
+    tb = tables.longconv_tables(T, x.device)
+    need = int(lib.at_longconv_workspace_bytes(B, C, Cir, T))
+    if need < 0:
+        _native.check(need, "at_longconv_workspace_bytes")
+    ws = _workspace(need, x.device)
+    out = torch.empty_like(x)
+    xpk = torch.empty((B, C), dtype=torch.float32, device=x.device) if want_peaks else None
+    ypk = torch.empty((B, C), dtype=torch.float32, device=x.device) if want_peaks else None
+    code = lib.at_longconv_room_f32(_native.ptr(x), _native.ptr(ir), L, L, _native.ptr(sh), _native.ptr(scale), B, C, Cir, T,
+                                    _native.ptr(tb), _native.ptr(out), _native.ptr(xpk), _native.ptr(ypk), _native.ptr(ws),
+                                    ws.numel(), _native.current_stream(x.device))
+    _native.check(code, "at_longconv_room_f32")
+    return (out, xpk, ypk) if want_peaks else out
 
 
 # ----------------------------------------------------------- phase vocoder

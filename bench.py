@@ -51,12 +51,12 @@ N_MELS = 80
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 CONFIGS = {
-    "north_star": dict(batch=512, ch=2, sr=44100, dur=10.0,
-                       metric="audio-seconds/sec (STFT+mel+LUFS pipeline), batch 512x2chx10s@44.1kHz"),
-    "cfg4": dict(batch=1024, ch=1, sr=48000, dur=5.0,
-                 metric="audio-seconds/sec (LowPass->Equalizer->RoomImpulseResponse chain), batch 1024xmonox5s@48kHz"),
-    "cfg5": dict(batch=2048, ch=2, sr=44100, dur=30.0,
-                 metric="audio-seconds/sec (resample 44.1k->16k + STFT + mel), batch 2048x2chx30s@44.1kHz"),
+    "north_star": dict(batch=512, ch=2, sr=44100, dur=10.0, chdesc="2ch", durdesc="10s@44.1kHz",
+                       metric="audio-seconds/sec (STFT+mel+LUFS pipeline)"),
+    "cfg4": dict(batch=1024, ch=1, sr=48000, dur=5.0, chdesc="mono", durdesc="5s@48kHz",
+                 metric="audio-seconds/sec (LowPass->Equalizer->RoomImpulseResponse chain)"),
+    "cfg5": dict(batch=2048, ch=2, sr=44100, dur=30.0, chdesc="2ch", durdesc="30s@44.1kHz",
+                 metric="audio-seconds/sec (resample 44.1k->16k + STFT + mel)"),
 }
 
 
@@ -256,7 +256,7 @@ def main():
     n_local = hi - lo
     x = make_batch(n_local, ch, T, sr, device, 1234 + rank)
     rows = n_local * ch
-    out = {"metric": cfg["metric"], "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+    out = {"metric": f"{cfg['metric']}, batch {batch}x{cfg['chdesc']}x{cfg['durdesc']}", "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
     kw_cpu = None
 
@@ -368,7 +368,7 @@ def main():
                          "items_per_gpu": n_local, "parallelism": f"batch-shard x{world} + RCCL broadcast of the IR bank / tables",
                          "inputs": "device-resident; transform parameters drawn before the timed region",
                          "host_instantiate_ms": inst_ms, "host_enqueue_ms": enq_ms}
-        out["roofline"] = {"bound": "hbm", "kernel": "whole chain (fir_fft x2, alter_drr, absmax, roll_pad, FFT convolution)",
+        out["roofline"] = {"bound": "hbm", "kernel": "whole chain (fir_fft x3, alter_drr, absmax, roll_pad, four-step FFT convolution: colfft x3 + rowconv)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": None, "algorithmic_bytes_per_launch": chain_bytes,
                            "avg_launch_ms": 1e3 * elapsed / args.steps}
@@ -402,7 +402,10 @@ def main():
                                      f"[STFT 2048/512 as the signal keeps its stft_params]", "global_batch": batch,
                          "items_per_gpu": n_local, "parallelism": f"batch-shard x{world} + RCCL broadcast of the resample bank / tables",
                          "inputs": "device-resident (H2D excluded)"}
-        out["roofline"] = {"bound": "hbm", "kernel": "resample_kernel (sparse polyphase 441->160)", "achieved": achieved,
+        rs_kernel = ("resample_mfma_ws_kernel (banded-GEMM polyphase 441->160 on v_mfma_f32_16x16x4_f32)"
+                     if _native.lib().at_resample_mfma_supported(441, 160) and os.environ.get("AT_RESAMPLE_MFMA", "1") != "0"
+                     else "resample_kernel (sparse polyphase 441->160)")
+        out["roofline"] = {"bound": "hbm", "kernel": rs_kernel, "achieved": achieved,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                            "algorithmic_bytes_per_launch": rs_bytes, "avg_launch_ms": rs_ms}
         out["kernels_ms"] = {"resample": rs_ms, "stft_mel": mel_ms, "stft_mel_GBps": mel_bytes / (mel_ms * 1e-3) / 1e9}

@@ -267,6 +267,17 @@ int64_t at_longconv_workspace_bytes(int64_t B, int64_t C, int64_t Cir, int64_t T
 int at_longconv_circ_f32(const float* x, const float* ir, const float* scale, int64_t B, int64_t C, int64_t Cir,
                          int64_t T, const float* tables, float* out, void* workspace, int64_t workspace_bytes,
                          void* stream);
+/* The same with the neighbouring passes of EffectMixin.apply_ir folded in.  Replaces
+ * audiotools/core/effects.py:86-121 (zero padding of the IR to T, roll to its peak, convolution) and
+ * the two abs().max() of :160 / :175:
+ *   ir (B*Cir, ir_pitch) with ir_len <= T valid samples per row (the rest of the period counts as
+ *   zero and is not read), ir_shift (B*Cir) int64 or NULL = rotation applied while reading
+ *   (h[n] = ir[(n + shift) mod T]); x_peak / y_peak (B*C) or NULL receive max|x| and max|out| per
+ *   row (NaN propagates), found while the column transforms stream the data.
+ */
+int at_longconv_room_f32(const float* x, const float* ir, int64_t ir_pitch, int64_t ir_len, const int64_t* ir_shift,
+                         const float* scale, int64_t B, int64_t C, int64_t Cir, int64_t T, const float* tables, float* out,
+                         float* x_peak, float* y_peak, void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

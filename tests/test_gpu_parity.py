@@ -313,6 +313,49 @@ def test_fourstep_convolution_vs_float64(T):
     assert float((back.cpu() - torch.roll(x, 7 % T, -1)).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("T,L", [(24000, 9601), (9600, 9600), (12288, 20000), (44100, 1)])
+def test_room_convolution_fused_roll_and_peaks(T, L):
+    """at_longconv_room_f32: zero padding + roll to the peak inside the load of the IR transform (odd
+    shifts, IR shorter / equal / longer than the signal, one-sample IR), and the two peaks of
+    apply_ir found inside the transforms -- against the unfused path (absmax, roll_pad, rocFFT)."""
+    g = torch.Generator().manual_seed(L % 31)
+    B, C = 3, 2
+    x = torch.randn(B, C, T, generator=g)
+    ir = torch.randn(B, 1, L, generator=g) * torch.exp(-torch.arange(L) / (0.3 * L + 1))
+    for b in range(B):                                  # distinct, odd and even peak positions
+        ir[b, 0, (37 * b + 5) % L] = 9.0 + b
+    Lc = min(L, T)
+    raw = ir[..., :Lc].contiguous().cuda()
+    peak, idx = kernels.absmax(raw, want_index=True)
+    scale = 1 / peak[..., None].clamp(1e-5)
+    got, xpk, ypk = kernels.room_convolve(x.cuda(), raw, idx, scale, want_peaks=True)
+    rolled = kernels.roll_pad(raw, idx, T)
+    ref = kernels.fftconv(x.cuda(), rolled, scale, engine="rocfft")
+    ref64 = torch.fft.irfft(torch.fft.rfft(x.double()) * torch.fft.rfft(rolled.cpu().double()), n=T) * scale.cpu().double()
+    assert rel_err(got.double(), ref64) < 2e-6 and rel_err(got, ref) < 5e-6
+    assert torch.equal(xpk.cpu(), x.abs().amax(-1))
+    assert torch.equal(ypk, got.abs().amax(-1))
+    # no shift, no peaks, multi-channel IR
+    ir2 = torch.randn(B, C, Lc, generator=g)
+    got2 = kernels.room_convolve(x.cuda(), ir2.cuda(), None, None)
+    ref2 = torch.fft.irfft(torch.fft.rfft(x.double()) * torch.fft.rfft(torch.nn.functional.pad(ir2, (0, T - Lc)).double()), n=T)
+    assert rel_err(got2.double(), ref2) < 2e-6
+    # the AudioSignal methods: convolve / apply_ir through the fused path == the CPU formulation
+    mk = lambda dev: (A.AudioSignal(x.clone(), 16000).to(dev), A.AudioSignal(ir.clone(), 16000).to(dev))
+    sg, ig = mk("cuda")
+    sc, ic = mk("cpu")
+    assert rel_err(sg.clone().convolve(ig.clone()).audio_data, sc.clone().convolve(ic.clone()).audio_data) < REL
+    yg = sg.clone().apply_ir(ig, drr=torch.tensor([3.0, 8.0, 12.0]))
+    yc = sc.clone().apply_ir(ic, drr=torch.tensor([3.0, 8.0, 12.0]))
+    assert rel_err(yg.audio_data, yc.audio_data) < 2e-4
+    assert ig.signal_length == ic.signal_length                       # the in-place pad / truncate of the argument
+    # NaN in the input reaches both peaks (as at_absmax_f32 propagates it)
+    xn = x.clone()
+    xn[1, 0, 5] = float("nan")
+    _, xpk, ypk = kernels.room_convolve(xn.cuda(), raw, idx, scale, want_peaks=True)
+    assert torch.isnan(xpk[1, 0]) and torch.isnan(ypk[1, 0]) and not torch.isnan(xpk[0]).any()
+
+
 def test_fourstep_is_the_default_engine(monkeypatch):
     from audiotools_amd import kernels
     x = torch.randn(2, 1, 48000, device="cuda")
