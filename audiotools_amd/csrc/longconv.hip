@@ -66,7 +66,11 @@ bool factor(int n, PassList* p) {
     }
     return true;
   };
-  return take(4) && take(2) && take(3) && take(5) && take(7) && n == 1;
+  // Odd radices first: a Stockham pass writes runs of NS consecutive points at a stride of NS R, and
+  // with NS = 1, 4, 16 and R = 4 that is an 8-way LDS bank conflict in the row layout (36 % of the
+  // LDS cycles of rowconv_kernel); strides of 3, 5, 7 points are conflict-free, and once the odd part
+  // is done NS is large enough for the radix-4 / 2 passes.
+  return take(5) && take(3) && take(7) && take(4) && take(2) && n == 1;
 }
 
 bool make_plan(int64_t T, Plan* P) {
@@ -131,7 +135,7 @@ struct RowLayout {          // buf[row slot][point]
 // lanes repeat that butterfly and store the same values to the same slots.  With predicated
 // iterations every butterfly was its own basic block and its LDS reads were not issued before the
 // previous butterfly had finished (the kernel ran at 46 % VALU and 26 % LDS utilisation).
-template <int R, int NB, class L>
+template <int R, int NB, int NT, class L>
 __device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const float2* __restrict__ tw, int N, int NS,
                                              int total, const L lay) {
   const int nb = N / R;
@@ -144,9 +148,10 @@ __device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const flo
   int tid = (int)threadIdx.x;
   asm volatile("" : "+v"(tid));
   const int last = total - 1;
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int id = min(tid + THREADS * b, last);
+  // the last iteration is skipped by the waves that lie entirely past the end (wave-uniform branch)
+  const bool tail = __builtin_amdgcn_readfirstlane(tid & ~63) + NT * (NB - 1) < total;
+  auto load_one = [&](int b) __attribute__((always_inline)) {
+    const int id = min(tid + NT * b, last);
     int batch, j;
     lay.split(id, nb, batch, j);
     const int jd = (int)(((float)j + 0.5f) * inv_ns);     // j / NS (exact: j < 2048)
@@ -159,42 +164,50 @@ __device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const flo
       for (int q = 1; q < R; ++q) v[b][q] = cmulf(v[b][q], tw[kt * q]);
     }
     o[b] = lay.addr(batch, jd * NS * R + k);
-  }
+  };
 #pragma unroll
-  for (int b = 0; b < NB; ++b) dft_r<R>(v[b]);
+  for (int b = 0; b < NB - 1; ++b) load_one(b);
+  if (tail) load_one(NB - 1);
+#pragma unroll
+  for (int b = 0; b < NB - 1; ++b) dft_r<R>(v[b]);
+  if (tail) dft_r<R>(v[NB - 1]);
   __syncthreads();
   const int st = lay.step(NS);
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
+  for (int b = 0; b < NB - 1; ++b) {
 #pragma unroll
     for (int q = 0; q < R; ++q) buf[o[b] + st * q] = v[b][q];
+  }
+  if (tail) {
+#pragma unroll
+    for (int q = 0; q < R; ++q) buf[o[NB - 1] + st * q] = v[NB - 1][q];
   }
   __syncthreads();
 }
 
-// the variant for the iteration count of this launch (uniform): NB = ceil(total / THREADS)
-template <int R, class L>
+// the variant for the iteration count of this launch (uniform): NB = ceil(total / NT)
+template <int R, int NT, class L>
 __device__ __forceinline__ void pass_dispatch(float2* buf, const float2* tw, int N, int NS, int total, const L lay) {
-  constexpr int MAXB = (TILE_POINTS / R + THREADS - 1) / THREADS;
-  const int nbi = (total + THREADS - 1) / THREADS;
-  if (nbi <= 1) pass_inplace<R, 1>(buf, tw, N, NS, total, lay);
-  else if (nbi == 2) pass_inplace<R, 2>(buf, tw, N, NS, total, lay);
-  else if (nbi == 3) pass_inplace<R, 3>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 4 && nbi == 4) pass_inplace<R, (MAXB >= 4 ? 4 : 1)>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 6 && nbi <= 6) pass_inplace<R, (MAXB >= 6 ? 6 : 1)>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 8) pass_inplace<R, (MAXB >= 8 ? 8 : 1)>(buf, tw, N, NS, total, lay);
+  constexpr int MAXB = (TILE_POINTS / R + NT - 1) / NT;
+  const int nbi = (total + NT - 1) / NT;
+  if (nbi <= 1) pass_inplace<R, 1, NT>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 2 && nbi == 2) pass_inplace<R, (MAXB >= 2 ? 2 : 1), NT>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 3 && nbi == 3) pass_inplace<R, (MAXB >= 3 ? 3 : 1), NT>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 4 && nbi == 4) pass_inplace<R, (MAXB >= 4 ? 4 : 1), NT>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 6 && nbi <= 6) pass_inplace<R, (MAXB >= 6 ? 6 : 1), NT>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 8) pass_inplace<R, (MAXB >= 8 ? 8 : 1), NT>(buf, tw, N, NS, total, lay);
 }
 
-template <class L>
+template <int NT, class L>
 __device__ __forceinline__ void run_passes(float2* buf, const float2* tw, int N, const PassList& pl, int batches, const L lay) {
   for (int p = 0; p < pl.n; ++p) {
     const int R = pl.radix[p];
     const int total = (N / R) * batches;
-    if (R == 4) pass_dispatch<4>(buf, tw, N, pl.ns[p], total, lay);
-    else if (R == 2) pass_dispatch<2>(buf, tw, N, pl.ns[p], total, lay);
-    else if (R == 3) pass_dispatch<3>(buf, tw, N, pl.ns[p], total, lay);
-    else if (R == 5) pass_dispatch<5>(buf, tw, N, pl.ns[p], total, lay);
-    else pass_dispatch<7>(buf, tw, N, pl.ns[p], total, lay);
+    if (R == 4) pass_dispatch<4, NT>(buf, tw, N, pl.ns[p], total, lay);
+    else if (R == 2) pass_dispatch<2, NT>(buf, tw, N, pl.ns[p], total, lay);
+    else if (R == 3) pass_dispatch<3, NT>(buf, tw, N, pl.ns[p], total, lay);
+    else if (R == 5) pass_dispatch<5, NT>(buf, tw, N, pl.ns[p], total, lay);
+    else pass_dispatch<7, NT>(buf, tw, N, pl.ns[p], total, lay);
   }
 }
 
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(THREADS, 4) void colfft_kernel(const ColArgs A) {
     }
   }
   __syncthreads();
-  run_passes(tile, tw, A.N1, A.pl, A.cw, ColLayout{A.lcw, cmask});
+  run_passes<THREADS>(tile, tw, A.N1, A.pl, A.cw, ColLayout{A.lcw, cmask});
 #pragma unroll 4
   for (int e = threadIdx.x; e < npts; e += THREADS) {
     const int k1 = e >> A.lcw, n2 = n2_0 + (e & cmask);
@@ -303,8 +316,14 @@ struct RowArgs {
   PassList pl;
 };
 
-constexpr int ROW_LOADS = TILE_POINTS / THREADS;      // 16: points of a row pair per thread
-constexpr int SPEC_ITERS = MAX_N2 / THREADS;          // 8: bins of one row per thread
+// Threads per row-pair workgroup and workgroups per CU.  Measured at cfg4 (rowconv_kernel alone):
+// 256 x 2 (176 registers) 2.7 ms, 256 x 3 (168 registers, 8 dwords spilled) 2.0 ms, 512 x 2 (98
+// registers) 2.0 ms, 1024 x 2 (59 registers) 2.2 ms: past three independent workgroups per CU the
+// wave organisation does not matter (profiles/r02_notes.md).
+constexpr int RTHREADS = 256;
+constexpr int ROW_WGS = 3;
+constexpr int ROW_LOADS = TILE_POINTS / RTHREADS;     // points of a row pair per thread
+constexpr int SPEC_ITERS = MAX_N2 / RTHREADS;         // bins of one row per thread
 
 // X[k], X[M-k] of the real signal from Z[k], Z[M-k] of its half-length complex transform; w = w_T^k.
 __device__ __forceinline__ void real_split(float2 zk, float2 zm, float2 w, float2& xk, float2& xm) {
@@ -328,10 +347,10 @@ __device__ __forceinline__ void real_merge(float2 yk, float2 ym, float2 w, float
   zm = make_float2(0.5f * (sr - pr), 0.5f * (-si + pi));
 }
 
-// 3 workgroups per CU (LDS: 49.5 KB each at N2 = 2000): 168 registers, 8 dwords spilled.  Measured at
-// cfg4: 2 per CU (176 registers, no spill) 2.7 ms, 3 per CU 2.15 ms -- the kernel is bound by barrier
-// and LDS latency, not by issue slots (profiles/r02_notes.md).
-__global__ __launch_bounds__(THREADS, 3) void rowconv_kernel(const RowArgs A) {
+// LDS: 49.5 KB per workgroup at N2 = 2000.  VALU (~0.75 ms of issue), LDS (~0.7 ms) and HBM (~0.75 ms)
+// time add up rather than overlap: the four waves of a workgroup move in lockstep between barriers
+// and only three workgroups share a CU.
+__global__ __launch_bounds__(RTHREADS, ROW_WGS * RTHREADS / 256) void rowconv_kernel(const RowArgs A) {
   extern __shared__ __attribute__((aligned(16))) float2 smem[];
   const int N2 = A.N2;
   float2* buf = smem;                       // [2][N2]
@@ -354,16 +373,16 @@ __global__ __launch_bounds__(THREADS, 3) void rowconv_kernel(const RowArgs A) {
   auto fetch = [&](const float2* __restrict__ g) {
 #pragma unroll
     for (int i = 0; i < ROW_LOADS; ++i) {
-      if (THREADS * i < npts) {             // uniform; lanes past the end repeat the last point
-        const int e = min((int)threadIdx.x + THREADS * i, npts - 1);
+      if (RTHREADS * i < npts) {             // uniform; lanes past the end repeat the last point
+        const int e = min((int)threadIdx.x + RTHREADS * i, npts - 1);
         const int s = e >= N2 ? 1 : 0;
         r[i] = g[(int64_t)(s ? k1b : k1a) * N2 + (e - s * N2)];
       }
     }
   };
   fetch(gx);
-  for (int i = threadIdx.x; i < N2; i += THREADS) tw[i] = A.tw2[i];
-  for (int i = threadIdx.x; i < nrow * A.rt; i += THREADS) {
+  for (int i = threadIdx.x; i < N2; i += RTHREADS) tw[i] = A.tw2[i];
+  for (int i = threadIdx.x; i < nrow * A.rt; i += RTHREADS) {
     const int s = i >= A.rt ? 1 : 0;
     rt[i] = A.rowtw[(int64_t)(s ? k1b : k1a) * A.rt + (i - s * A.rt)];
   }
@@ -383,8 +402,8 @@ __global__ __launch_bounds__(THREADS, 3) void rowconv_kernel(const RowArgs A) {
     if (ph < 2) {                           // twiddle w_M^{k1 n2} and into LDS
 #pragma unroll
       for (int i = 0; i < ROW_LOADS; ++i) {
-        if (THREADS * i < npts) {
-          const int e = min(tid + THREADS * i, npts - 1);
+        if (RTHREADS * i < npts) {
+          const int e = min(tid + RTHREADS * i, npts - 1);
           const int s = e >= N2 ? 1 : 0;
           const int n2 = e - s * N2;
           const float2 w = cmulf(rt[s * A.rt + (n2 & 63)], rt[s * A.rt + 64 + (n2 >> 6)]);
@@ -394,14 +413,14 @@ __global__ __launch_bounds__(THREADS, 3) void rowconv_kernel(const RowArgs A) {
       __syncthreads();
       if (ph == 0) fetch(gh);               // the IR rows arrive while the signal rows are transformed
     }
-    run_passes(buf, tw, N2, A.pl, nrow, lay);
+    run_passes<RTHREADS>(buf, tw, N2, A.pl, nrow, lay);
     if (ph == 2) break;
     // Every bin pair (k, M - k) is read (and in phase 1 rewritten) by exactly one thread, so the
     // product spectrum goes straight back into the slots it came from.  The inverse transform
     // runs as a forward one on conj(Z'); colfft<true> conjugates at the end.
 #pragma unroll
     for (int i = 0; i < SPEC_ITERS; ++i) {
-      const int k2 = tid + THREADS * i;
+      const int k2 = tid + RTHREADS * i;
       const int k2m = k1a == 0 ? (k2 == 0 ? 0 : N2 - k2) : N2 - 1 - k2;
       if (k2 < N2 && (!self || k2 <= k2m)) {
         const float2 zk = buf[k2], zm = buf[slot_b + k2m];
@@ -431,8 +450,8 @@ __global__ __launch_bounds__(THREADS, 3) void rowconv_kernel(const RowArgs A) {
   }
 #pragma unroll
   for (int i = 0; i < ROW_LOADS; ++i) {
-    if (THREADS * i < npts) {
-      const int e = min((int)threadIdx.x + THREADS * i, npts - 1);
+    if (RTHREADS * i < npts) {
+      const int e = min((int)threadIdx.x + RTHREADS * i, npts - 1);
       const int s = e >= N2 ? 1 : 0;
       const int n2 = e - s * N2;
       const float2 w = cmulf(rt[s * A.rt + (n2 & 63)], rt[s * A.rt + 64 + (n2 >> 6)]);
@@ -557,7 +576,7 @@ int run_longconv(const float* x, const IrSource& ir, const float* scale, int64_t
   ra.ax = ax; ra.ah = ah; ra.scale = scale; ra.tw2 = tb + o.tw2; ra.rowtw = tb + o.rowtw; ra.sp_lo = tb + o.sp_lo;
   ra.sp_hi = tb + o.sp_hi; ra.C = (int)C; ra.Cir = (int)Cir; ra.N1 = P.N1; ra.N2 = P.N2; ra.rt = o.rt;
   ra.npairs = P.N1 / 2 + 1; ra.inv_m = 1.0f / (float)(T / 2); ra.pl = P.p2;
-  hipLaunchKernelGGL(rowconv_kernel, dim3((unsigned)(rows_x * ra.npairs)), dim3(THREADS), row_lds, st, ra);
+  hipLaunchKernelGGL(rowconv_kernel, dim3((unsigned)(rows_x * ra.npairs)), dim3(RTHREADS), row_lds, st, ra);
   AT_LAUNCH_CHECK();
 
   ca.src = ax; ca.dst = ax; ca.rows = rows_x;

@@ -15,7 +15,7 @@ from audiotools_amd import _native  # noqa: E402
 
 def factor(n):
     radix, ns, s = [], [], 1
-    for r in (4, 2, 3, 5, 7):
+    for r in (5, 3, 7, 4, 2):
         while n % r == 0:
             radix.append(r); ns.append(s); s *= r; n //= r
     assert n == 1
