@@ -1,10 +1,11 @@
 #!/bin/bash
 # Per-row measurements of DESIGN.md section 7 in one go (GPU box).  usage: tools/rows.sh > gpurun_out/rows.txt
 cd "$(dirname "$0")/.."
-run() { echo "### $*"; "$@" 2>&1 | grep -v -e amdgpu.ids -e "^$"; }
+run() { echo "### $*"; timeout 300 "$@" 2>&1 < /dev/null | grep -v -e amdgpu.ids -e "^$"; }
 run python tools/kbench.py --what stft,stftmel,lufs,istft --iters 20
 run python tools/kbench.py --what stftmel,lufs --iters 50 --batch 64
 run python tools/cfgbench.py
+run python tools/convbench.py
 run python tools/firbench.py 153
 run python tools/firbench.py 677
 run python tools/firbench.py 1047
