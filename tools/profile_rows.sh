@@ -5,8 +5,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/rows_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/k512 -o k -- python $R/tools/kbench.py --what stft,stftmel,lufs,istft --iters 20 --batch 512 > $O/k512.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg -o c -- python $R/tools/cfgbench.py > $O/cfg.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k512 -o k -- python $R/tools/kbench.py --what stft,stftmel,lufs,istft --iters 20 --batch 512 > $O/k512.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg -o c -- python $R/tools/cfgbench.py > $O/cfg.log 2>&1
 for d in k512 cfg; do
   f=$(find $O/$d -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" $O/${d}_kernel_stats.csv
