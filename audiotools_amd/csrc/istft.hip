@@ -463,7 +463,8 @@ void plan_runs(IstftFusedArgs& F, int64_t rows, int n_fft, int hop) {
   F.n_seg = F.n_frames - 1 + R;
   // runs: >= ~16k frame-slot units so the chip is filled a few times over, but long enough that
   // the R-1 warm-up frames of a run stay a small fraction
-  int64_t want = (16384 + rows - 1) / rows;
+  static const int want_units = at::env_int_once("AT_ISTFT_UNITS", 16384);   // measurement knob
+  int64_t want = ((want_units > 0 ? want_units : 16384) + rows - 1) / rows;
   int run = (int)((F.n_seg + want - 1) / want);
   if (run < 8 * R) run = 8 * R;
   if (run > F.n_seg) run = F.n_seg;

@@ -46,6 +46,9 @@
 #ifndef AT_STFT_STAGGER
 #define AT_STFT_STAGGER 0       // start-up stagger per wave slot, in units of 64 cycles (0 = off)
 #endif
+#ifndef AT_STFT_PRIO
+#define AT_STFT_PRIO 0          // v2 kernel: 1 = raised wave priority while the loads + stores of a frame are issued; 2 = during the transform
+#endif
 #ifndef AT_STFT_RUN
 #define AT_STFT_RUN 16          // consecutive frame groups a wave handles before jumping ahead
 #endif
@@ -75,7 +78,9 @@ struct StftArgs {
   int reuse_shift;         // hop / (2 L) when consecutive frames of a wave can reuse registers, else 0
   int run;                 // consecutive frame groups a wave handles before jumping ahead (<= AT_STFT_RUN)
   int debug;               // development: 1 = compute but never store, 2 = store only (no FFT)
-  int flags;               // development experiments (AT_STFT_FLAGS, read once): bit 0 = v2 writes 16-B stores (WRONG bin order: timing only)
+  int flags;               // measurement knob AT_STFT_FLAGS (read once): cache policy of the v2 kernel's streaming traffic (POL)
+  int run_max;             // upper bound of `run` for the v2 kernel (AT_STFT_RUNMAX, read once)
+  int n_xcd;               // XCDs the v2 schedule cuts the frame range into (AT_STFT_NX, read once; 8)
 };
 
 using at::fetch_padded;
@@ -466,10 +471,39 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
 //    ~145 v_mov per frame on the shift);
 //  * window and pass-2 twiddles are read as ds_read_b128 rows (the stride-64 float2 reads were
 //    merged by the compiler into half-rate ds_read2st64_b64).
-template <int NR /* mel rounds of 64 units; 0 = no mel */, bool ST16 = false /* timing experiment: 16-B stores, wrong bin order */>
-__global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
+// POL = cache policy of the streaming traffic (AT_STFT_FLAGS, measurement knob; 0 is shipped):
+//   bit 0: stores `nt`;  bit 1: stores `sc1` (write-through, the line is dropped from the XCD's L2);
+//   bit 2: the sample loads `nt`.
+template <int POL>
+__device__ __forceinline__ void st2(float2* p, float2 v) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  if constexpr (POL & 2) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  } else if constexpr (POL & 1) {
+    const v2f u = {v.x, v.y};
+    __builtin_nontemporal_store(u, reinterpret_cast<v2f*>(p));
+  } else {
+    *p = v;
+  }
+}
+template <int POL>
+__device__ __forceinline__ float2 ld2(const float2* p) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  if constexpr (POL & 4) {
+    const v2f u = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p));
+    return make_float2(u.x, u.y);
+  } else {
+    return *p;
+  }
+}
+
+// NW = waves per workgroup: 4 (two workgroups per CU, 2 waves per SIMD: shipped) or 12 (one workgroup
+// per CU at 3 waves per SIMD, i.e. a 168-register budget: measurement variant, AT_STFT_V2NW=12).
+template <int NR /* mel rounds of 64 units; 0 = no mel */, int POL = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 12 ? 3 : 2) void stft_mel_kernel_v2(const StftArgs A) {
   constexpr bool MEL = NR > 0;
-  constexpr int M = 1024, L = 64, N = 2048, NW = 4, SH = 4;
+  constexpr int M = 1024, L = 64, N = 2048, SH = 4;
   constexpr int WROW = 36;  // floats per window row (32 used): conflict-free ds_read_b128
   constexpr int TROW = 20;  // floats per split-twiddle row (16 used): conflict-free ds_read_b128
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -525,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   const int Ti = (int)A.T;
   const int n_out = (int)A.n_out;
   const int gpr = A.groups_per_row;
-  const int n_x = gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int n_x = (int)gridDim.x < A.n_xcd ? (int)gridDim.x : A.n_xcd;
   const int xcd = blockIdx.x % n_x;
   const int lblk = blockIdx.x / n_x;
   const int nblk_x = ((int)gridDim.x - xcd + n_x - 1) / n_x;
@@ -534,6 +568,10 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   const int RUN = A.run;
   const int64_t Wtot = (int64_t)nblk_x * NW;
   const int64_t w0 = g_lo + ((int64_t)lblk * NW + wave) * RUN;
+  if constexpr (AT_STFT_STAGGER > 0) {   // de-phase the 8 resident waves of a CU (measurement knob)
+    const int slot = NW == 4 ? (wave + NW * (lblk & 1)) & 7 : wave;
+    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(AT_STFT_STAGGER);
+  }
 
   float2 raw[16];   // un-windowed samples; logical q of a phase-p frame is raw[(q + 4 p) & 15]
   float2 nxt[SH];   // the 4 new loads of the NEXT frame, issued ahead of this frame's stores
@@ -562,6 +600,7 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
 #pragma unroll
       for (int i = 0; i < SH; ++i) raw[(12 + i + 4 * P) & 15] = nxt[i];
     }
+    if constexpr (AT_STFT_PRIO == 2) __builtin_amdgcn_s_setprio(2);   // transform phase ahead of the other wave's memory phase
     float2 a[16];
     {
       const float4* wr = reinterpret_cast<const float4*>(s_winr + t * WROW);
@@ -617,8 +656,10 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
     const bool have_nxt = want_next && fo + 1 < gpr && s0n >= 0 && s0n + N <= Ti;
     {
       const float2* __restrict__ p2 = reinterpret_cast<const float2*>(xr + (have_nxt ? s0n : 0)) + t + L * (16 - SH);
+      if constexpr (AT_STFT_PRIO == 1) __builtin_amdgcn_s_setprio(3);
+      if constexpr (AT_STFT_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-      for (int i = 0; i < SH; ++i) nxt[i] = p2[L * i];
+      for (int i = 0; i < SH; ++i) nxt[i] = ld2<POL>(p2 + L * i);
     }
 
     // ---- split step on registers
@@ -662,21 +703,10 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int k0 = 256 * m + t;
-      if constexpr (ST16) {
-        // EXPERIMENT (timing only, bins land in the wrong order): the same bytes as 8 x 16-B stores
-        // per frame instead of 16 x 8-B -- does halving the store instructions pay?
-        struct __attribute__((packed, aligned(8))) f4a8 { float x, y, z, w; };
-        f4a8 u, v;
-        u.x = ascA[m].x; u.y = ascA[m].y; u.z = xaB[m].x; u.w = xaB[m].y;
-        v.x = rcB[m].x; v.y = rcB[m].y; v.z = rcA[m].x; v.w = rcA[m].y;
-        reinterpret_cast<f4a8*>(orow + 256 * m)[t] = u;
-        reinterpret_cast<f4a8*>(orow + 256 * m + 128)[t] = v;
-      } else {
-        orow[k0] = ascA[m];
-        orow[k0 + 64] = xaB[m];
-        orow[k0 + 128] = rcB[m];
-        orow[k0 + 192] = rcA[m];
-      }
+      st2<POL>(orow + k0, ascA[m]);
+      st2<POL>(orow + k0 + 64, xaB[m]);
+      st2<POL>(orow + k0 + 128, rcB[m]);
+      st2<POL>(orow + k0 + 192, rcA[m]);
       if constexpr (MEL) {
         magbuf[k0 + 4 * (k0 >> 4)] = cabs_fast(ascA[m]);
         magbuf[k0 + 64 + 4 * ((k0 + 64) >> 4)] = cabs_fast(xaB[m]);
@@ -685,9 +715,10 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       }
     }
     if (t0) {
-      orow[M] = nyq;
+      st2<POL>(orow + M, nyq);
       if constexpr (MEL) magbuf[M + 4 * (M >> 4)] = fabsf(nyq.x);
     }
+    if constexpr (AT_STFT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if constexpr (MEL) {
       // the last magnitude row holds only the Nyquist bin: zero its other 15 columns (see the
       // generic kernel)
@@ -745,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       if (s0 >= 0 && s0 + N <= Ti) {   // wave-uniform
         const float2* __restrict__ p2 = reinterpret_cast<const float2*>(xr + s0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) raw[q] = p2[t + L * q];
+        for (int q = 0; q < 16; ++q) raw[q] = ld2<POL>(p2 + t + L * q);
       } else {
 #pragma unroll 1
         for (int q = 0; q < 16; ++q) {
@@ -777,38 +808,39 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   }
 }
 
-constexpr size_t v2_lds_floats(int n_units) {
-  return (size_t)4 * 2 * WAVE_LDS_SLOTS + 64 * 36 + 64 * 20 + 16 * 36 + (size_t)n_units * (MELW_ROW + 2);
+constexpr size_t v2_lds_floats(int n_units, int nw = 4) {
+  return (size_t)nw * 2 * WAVE_LDS_SLOTS + 64 * 36 + 64 * 20 + 16 * 36 + (size_t)n_units * (MELW_ROW + 2);
 }
 
 // Run-length balancing shared by both kernels: every wave of an XCD span gets the same number of
 // whole runs (see launch_one).
-static int balanced_run(int64_t total_groups, int64_t blocks, int nw) {
-  const int64_t n_x = blocks < 8 ? blocks : 8;
+static int balanced_run(int64_t total_groups, int64_t blocks, int nw, int run_max = AT_STFT_RUN, int n_xcd = 8) {
+  const int64_t n_x = blocks < n_xcd ? blocks : n_xcd;
   const int64_t waves_x = (blocks / n_x) * nw;
   const int64_t span = (total_groups + n_x - 1) / n_x;
   const int64_t per_wave = (span + waves_x - 1) / (waves_x > 0 ? waves_x : 1);
-  const int64_t runs = (per_wave + AT_STFT_RUN - 1) / AT_STFT_RUN;
+  const int64_t runs = (per_wave + run_max - 1) / run_max;
   int64_t run = (per_wave + runs - 1) / (runs > 0 ? runs : 1);
   if (run < 1) run = 1;
-  if (run > AT_STFT_RUN) run = AT_STFT_RUN;
+  if (run > run_max) run = run_max;
   return (int)run;
 }
 
-template <int NR, bool ST16 = false>
+template <int NR, int POL = 0, int NW = 4>
 int launch_v2(const StftArgs& A, int n_cu, hipStream_t stream) {
-  auto kern = stft_mel_kernel_v2<NR, ST16>;
-  const size_t bytes = v2_lds_floats(A.n_units) * 4;
+  auto kern = stft_mel_kernel_v2<NR, POL, NW>;
+  const size_t bytes = v2_lds_floats(A.n_units, NW) * 4;
   if (bytes > 160 * 1024) return AT_ERR_UNSUPPORTED;
   int e = at::allow_big_lds(reinterpret_cast<const void*>(kern));
   if (e != AT_OK) return e;
   int per_cu = (int)((160 * 1024) / bytes);
-  if (per_cu > 2) per_cu = 2;   // 2 waves per SIMD (launch bounds)
-  int64_t blocks = (A.total_groups + 3) / 4;
+  const int by_regs = NW == 12 ? 1 : 2;   // 3 / 2 waves per SIMD (launch bounds)
+  if (per_cu > by_regs) per_cu = by_regs;
+  int64_t blocks = (A.total_groups + NW - 1) / NW;
   if (blocks > (int64_t)n_cu * per_cu) blocks = (int64_t)n_cu * per_cu;
   StftArgs B = A;
-  B.run = balanced_run(A.total_groups, blocks, 4);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), bytes, stream, B);
+  B.run = balanced_run(A.total_groups, blocks, NW, A.run_max, A.n_xcd);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), bytes, stream, B);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }
@@ -994,8 +1026,19 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   static const int dbg_mode = AT_STFT_DEBUGMODES ? env_int_once("AT_STFT_DEBUG", 0) : 0;
   static const int allow_reuse = env_int_once("AT_STFT_REUSE", 1);
   static const int use_v2 = env_int_once("AT_STFT_V2", 1);
-  static const int exp_flags = env_int_once("AT_STFT_FLAGS", 0);
-  A.flags = exp_flags;
+  // measurement knobs of the v2 schedule, read once (AT_STFT_TUNE=1: re-read on every call so that one
+  // process can sweep them, tools/stftsweep.py)
+  struct Tuning { int flags, run_max, n_xcd, nw; };
+  auto read_tuning = [] {
+    return Tuning{env_int_once("AT_STFT_FLAGS", 0), env_int_once("AT_STFT_RUNMAX", AT_STFT_RUN), env_int_once("AT_STFT_NX", 8),
+                  env_int_once("AT_STFT_V2NW", 4)};
+  };
+  static const int tune_each_call = env_int_once("AT_STFT_TUNE", 0);
+  static Tuning tuning = read_tuning();
+  if (tune_each_call) tuning = read_tuning();
+  A.flags = tuning.flags;
+  A.run_max = tuning.run_max < 1 ? 1 : tuning.run_max;
+  A.n_xcd = tuning.n_xcd < 1 ? 1 : tuning.n_xcd;
   A.debug = dbg_mode;
   A.reuse_shift = (FW == 1 && hop % (2 * (M / 16)) == 0 && pad == 0) ? hop / (2 * (M / 16)) : 0;
   if (!allow_reuse) A.reuse_shift = 0;
@@ -1005,9 +1048,23 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   if (use_v2 && M == 1024 && vec2 && A.reuse_shift == 4 && A.debug == 0 && T >= 2 * 2048) {
     // the reference's default transform at 44.1 / 48 kHz: n_fft 2048, hop 512, no match_stride
     switch (A.n_units / 64) {
-      case 0: return (A.flags & 1) ? launch_v2<0, true>(A, n_cu, s) : launch_v2<0>(A, n_cu, s);
+      case 0:
+        if (tuning.nw == 12) return launch_v2<0, 0, 12>(A, n_cu, s);
+        switch (A.flags & 7) {
+          case 1: return launch_v2<0, 1>(A, n_cu, s);
+          case 2: return launch_v2<0, 2>(A, n_cu, s);
+          case 4: return launch_v2<0, 4>(A, n_cu, s);
+          default: return launch_v2<0>(A, n_cu, s);
+        }
       case 2: return launch_v2<2>(A, n_cu, s);
-      case 4: return (A.flags & 1) ? launch_v2<4, true>(A, n_cu, s) : launch_v2<4>(A, n_cu, s);
+      case 4:
+        if (tuning.nw == 12) return launch_v2<4, 0, 12>(A, n_cu, s);
+        switch (A.flags & 7) {
+          case 1: return launch_v2<4, 1>(A, n_cu, s);
+          case 2: return launch_v2<4, 2>(A, n_cu, s);
+          case 4: return launch_v2<4, 4>(A, n_cu, s);
+          default: return launch_v2<4>(A, n_cu, s);
+        }
       case 6: return launch_v2<6>(A, n_cu, s);
     }
   }
