@@ -461,13 +461,34 @@ int launch_fused_m(int M, int sh, const IstftFusedArgs& F, hipStream_t st) {
 void plan_runs(IstftFusedArgs& F, int64_t rows, int n_fft, int hop) {
   const int R = n_fft / hop;
   F.n_seg = F.n_frames - 1 + R;
-  // runs: >= ~16k frame-slot units so the chip is filled a few times over, but long enough that
-  // the R-1 warm-up frames of a run stay a small fraction
-  static const int want_units = at::env_int_once("AT_ISTFT_UNITS", 16384);   // measurement knob
-  int64_t want = ((want_units > 0 ? want_units : 16384) + rows - 1) / rows;
-  int run = (int)((F.n_seg + want - 1) / want);
-  if (run < 8 * R) run = 8 * R;
+  // A unit is one (row, run of segments) and costs run + R - 1 frames (R - 1 warm-up frames are
+  // transformed again at every run boundary).  Units run in ROUNDS of one per resident frame slot
+  // (2 waves per SIMD, 1024 / M frames per wave), so the launch lasts  rounds x (run + R - 1)  frame
+  // times: take the runs-per-row that minimises it.  (B = 512 x 2 ch x 10 s: 2 runs of 433
+  // segments = exactly one round; the former fixed target of ~16k units, 16 runs of 55, spent 5 %
+  // of the launch on warm-up frames and ran 3.7 % slower, profiles/r02_notes.md.)
+  static const int want_units = at::env_int_once("AT_ISTFT_UNITS", 0);   // measurement knob: fixed unit target
+  int run;
+  if (want_units > 0) {
+    const int64_t want = (want_units + rows - 1) / rows;
+    run = (int)((F.n_seg + want - 1) / want);
+    if (run < 8 * R) run = 8 * R;
+  } else {
+    const int fw = n_fft >= 2048 ? 1 : 2048 / n_fft;
+    const int64_t slots = (int64_t)at::device_cu_count() * 4 * AT_ISTFT_WPS * fw;
+    const int max_rp = F.n_seg / (8 * R) > 1 ? F.n_seg / (8 * R) : 1;
+    double best_cost = 1e300;
+    run = F.n_seg;
+    for (int rp = 1; rp <= max_rp && rp <= 4096; ++rp) {
+      const int r = (F.n_seg + rp - 1) / rp;
+      const int64_t units = rows * ((F.n_seg + r - 1) / r);
+      const int64_t rounds = (units + slots - 1) / slots;
+      const double cost = (double)rounds * (double)(r + R - 1);
+      if (cost < best_cost * 0.999) { best_cost = cost; run = r; }
+    }
+  }
   if (run > F.n_seg) run = F.n_seg;
+  if (run < 1) run = 1;
   F.run = run;
   F.runs_per_row = (F.n_seg + run - 1) / run;
   F.total_units = rows * F.runs_per_row;

@@ -46,9 +46,6 @@
 #ifndef AT_STFT_STAGGER
 #define AT_STFT_STAGGER 0       // start-up stagger per wave slot, in units of 64 cycles (0 = off)
 #endif
-#ifndef AT_STFT_PRIO
-#define AT_STFT_PRIO 0          // v2 kernel: 1 = raised wave priority while the loads + stores of a frame are issued; 2 = during the transform
-#endif
 #ifndef AT_STFT_RUN
 #define AT_STFT_RUN 16          // consecutive frame groups a wave handles before jumping ahead
 #endif
@@ -81,6 +78,7 @@ struct StftArgs {
   int flags;               // measurement knob AT_STFT_FLAGS (read once): cache policy of the v2 kernel's streaming traffic (POL)
   int run_max;             // upper bound of `run` for the v2 kernel (AT_STFT_RUNMAX, read once)
   int n_xcd;               // XCDs the v2 schedule cuts the frame range into (AT_STFT_NX, read once; 8)
+  int stagger;             // v2: start-up delay per wave slot of a CU, in units of 64 cycles (AT_STFT_STAGGERV2)
 };
 
 using at::fetch_padded;
@@ -472,15 +470,12 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
 //  * window and pass-2 twiddles are read as ds_read_b128 rows (the stride-64 float2 reads were
 //    merged by the compiler into half-rate ds_read2st64_b64).
 // POL = cache policy of the streaming traffic (AT_STFT_FLAGS, measurement knob; 0 is shipped):
-//   bit 0: stores `nt`;  bit 1: stores `sc1` (write-through, the line is dropped from the XCD's L2);
-//   bit 2: the sample loads `nt`.
+//   bit 0: stores `nt`;  bit 2: the sample loads `nt`;  bit 3: raised wave priority (s_setprio 3) while
+//   the loads and stores of a frame are issued.  (`sc1` write-through stores were measured 25 % slower.)
 template <int POL>
 __device__ __forceinline__ void st2(float2* p, float2 v) {
   typedef float v2f __attribute__((ext_vector_type(2)));
-  if constexpr (POL & 2) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  } else if constexpr (POL & 1) {
+  if constexpr (POL & 1) {
     const v2f u = {v.x, v.y};
     __builtin_nontemporal_store(u, reinterpret_cast<v2f*>(p));
   } else {
@@ -498,12 +493,11 @@ __device__ __forceinline__ float2 ld2(const float2* p) {
   }
 }
 
-// NW = waves per workgroup: 4 (two workgroups per CU, 2 waves per SIMD: shipped) or 12 (one workgroup
-// per CU at 3 waves per SIMD, i.e. a 168-register budget: measurement variant, AT_STFT_V2NW=12).
-template <int NR /* mel rounds of 64 units; 0 = no mel */, int POL = 0, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 12 ? 3 : 2) void stft_mel_kernel_v2(const StftArgs A) {
+template <int NR /* mel rounds of 64 units; 0 = no mel */, int POL = 0>
+__global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   constexpr bool MEL = NR > 0;
-  constexpr int M = 1024, L = 64, N = 2048, SH = 4;
+  constexpr bool PRIO = (POL & 8) != 0;
+  constexpr int M = 1024, L = 64, N = 2048, NW = 4, SH = 4;
   constexpr int WROW = 36;  // floats per window row (32 used): conflict-free ds_read_b128
   constexpr int TROW = 20;  // floats per split-twiddle row (16 used): conflict-free ds_read_b128
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -568,10 +562,14 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 3 : 2) void stft_mel_kernel_v2(
   const int RUN = A.run;
   const int64_t Wtot = (int64_t)nblk_x * NW;
   const int64_t w0 = g_lo + ((int64_t)lblk * NW + wave) * RUN;
-  if constexpr (AT_STFT_STAGGER > 0) {   // de-phase the 8 resident waves of a CU (measurement knob)
-    const int slot = NW == 4 ? (wave + NW * (lblk & 1)) & 7 : wave;
-    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(AT_STFT_STAGGER);
+  // De-phase the 8 resident waves of a CU.  They all start together and run identical work, so
+  // without a stagger the chip alternates between "everyone transforms" and "everyone stores" and
+  // the memory system idles part of the time; slot s starts s * stagger * 64 cycles late.
+  if (A.stagger > 0) {
+    const int slot = (wave + NW * (lblk & 1)) & 7;
+    for (int i = 0; i < slot * A.stagger; ++i) __builtin_amdgcn_s_sleep(1);
   }
+  if ((A.flags & 16) && (lblk & 1)) __builtin_amdgcn_s_setprio(2);   // measurement knob: the two waves of a SIMD at different priority
 
   float2 raw[16];   // un-windowed samples; logical q of a phase-p frame is raw[(q + 4 p) & 15]
   float2 nxt[SH];   // the 4 new loads of the NEXT frame, issued ahead of this frame's stores
@@ -600,7 +598,6 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 3 : 2) void stft_mel_kernel_v2(
 #pragma unroll
       for (int i = 0; i < SH; ++i) raw[(12 + i + 4 * P) & 15] = nxt[i];
     }
-    if constexpr (AT_STFT_PRIO == 2) __builtin_amdgcn_s_setprio(2);   // transform phase ahead of the other wave's memory phase
     float2 a[16];
     {
       const float4* wr = reinterpret_cast<const float4*>(s_winr + t * WROW);
@@ -656,8 +653,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 3 : 2) void stft_mel_kernel_v2(
     const bool have_nxt = want_next && fo + 1 < gpr && s0n >= 0 && s0n + N <= Ti;
     {
       const float2* __restrict__ p2 = reinterpret_cast<const float2*>(xr + (have_nxt ? s0n : 0)) + t + L * (16 - SH);
-      if constexpr (AT_STFT_PRIO == 1) __builtin_amdgcn_s_setprio(3);
-      if constexpr (AT_STFT_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
       for (int i = 0; i < SH; ++i) nxt[i] = ld2<POL>(p2 + L * i);
     }
@@ -718,7 +714,7 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 3 : 2) void stft_mel_kernel_v2(
       st2<POL>(orow + M, nyq);
       if constexpr (MEL) magbuf[M + 4 * (M >> 4)] = fabsf(nyq.x);
     }
-    if constexpr (AT_STFT_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     if constexpr (MEL) {
       // the last magnitude row holds only the Nyquist bin: zero its other 15 columns (see the
       // generic kernel)
@@ -808,8 +804,8 @@ __global__ __launch_bounds__(NW * 64, NW == 12 ? 3 : 2) void stft_mel_kernel_v2(
   }
 }
 
-constexpr size_t v2_lds_floats(int n_units, int nw = 4) {
-  return (size_t)nw * 2 * WAVE_LDS_SLOTS + 64 * 36 + 64 * 20 + 16 * 36 + (size_t)n_units * (MELW_ROW + 2);
+constexpr size_t v2_lds_floats(int n_units) {
+  return (size_t)4 * 2 * WAVE_LDS_SLOTS + 64 * 36 + 64 * 20 + 16 * 36 + (size_t)n_units * (MELW_ROW + 2);
 }
 
 // Run-length balancing shared by both kernels: every wave of an XCD span gets the same number of
@@ -826,16 +822,16 @@ static int balanced_run(int64_t total_groups, int64_t blocks, int nw, int run_ma
   return (int)run;
 }
 
-template <int NR, int POL = 0, int NW = 4>
+template <int NR, int POL = 0>
 int launch_v2(const StftArgs& A, int n_cu, hipStream_t stream) {
-  auto kern = stft_mel_kernel_v2<NR, POL, NW>;
-  const size_t bytes = v2_lds_floats(A.n_units, NW) * 4;
+  constexpr int NW = 4;
+  auto kern = stft_mel_kernel_v2<NR, POL>;
+  const size_t bytes = v2_lds_floats(A.n_units) * 4;
   if (bytes > 160 * 1024) return AT_ERR_UNSUPPORTED;
   int e = at::allow_big_lds(reinterpret_cast<const void*>(kern));
   if (e != AT_OK) return e;
   int per_cu = (int)((160 * 1024) / bytes);
-  const int by_regs = NW == 12 ? 1 : 2;   // 3 / 2 waves per SIMD (launch bounds)
-  if (per_cu > by_regs) per_cu = by_regs;
+  if (per_cu > 2) per_cu = 2;   // 2 waves per SIMD (launch bounds)
   int64_t blocks = (A.total_groups + NW - 1) / NW;
   if (blocks > (int64_t)n_cu * per_cu) blocks = (int64_t)n_cu * per_cu;
   StftArgs B = A;
@@ -1028,10 +1024,10 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   static const int use_v2 = env_int_once("AT_STFT_V2", 1);
   // measurement knobs of the v2 schedule, read once (AT_STFT_TUNE=1: re-read on every call so that one
   // process can sweep them, tools/stftsweep.py)
-  struct Tuning { int flags, run_max, n_xcd, nw; };
+  struct Tuning { int flags, run_max, n_xcd, stagger; };
   auto read_tuning = [] {
     return Tuning{env_int_once("AT_STFT_FLAGS", 0), env_int_once("AT_STFT_RUNMAX", AT_STFT_RUN), env_int_once("AT_STFT_NX", 8),
-                  env_int_once("AT_STFT_V2NW", 4)};
+                  env_int_once("AT_STFT_STAGGERV2", 0)};
   };
   static const int tune_each_call = env_int_once("AT_STFT_TUNE", 0);
   static Tuning tuning = read_tuning();
@@ -1039,6 +1035,7 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   A.flags = tuning.flags;
   A.run_max = tuning.run_max < 1 ? 1 : tuning.run_max;
   A.n_xcd = tuning.n_xcd < 1 ? 1 : tuning.n_xcd;
+  A.stagger = tuning.stagger < 0 ? 0 : tuning.stagger;
   A.debug = dbg_mode;
   A.reuse_shift = (FW == 1 && hop % (2 * (M / 16)) == 0 && pad == 0) ? hop / (2 * (M / 16)) : 0;
   if (!allow_reuse) A.reuse_shift = 0;
@@ -1048,23 +1045,20 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   if (use_v2 && M == 1024 && vec2 && A.reuse_shift == 4 && A.debug == 0 && T >= 2 * 2048) {
     // the reference's default transform at 44.1 / 48 kHz: n_fft 2048, hop 512, no match_stride
     switch (A.n_units / 64) {
-      case 0:
-        if (tuning.nw == 12) return launch_v2<0, 0, 12>(A, n_cu, s);
-        switch (A.flags & 7) {
-          case 1: return launch_v2<0, 1>(A, n_cu, s);
-          case 2: return launch_v2<0, 2>(A, n_cu, s);
-          case 4: return launch_v2<0, 4>(A, n_cu, s);
-          default: return launch_v2<0>(A, n_cu, s);
-        }
+#define AT_V2_POL(NRV)                                    \
+  switch (A.flags & 13) {                                 \
+    case 1: return launch_v2<NRV, 1>(A, n_cu, s);         \
+    case 4: return launch_v2<NRV, 4>(A, n_cu, s);         \
+    case 5: return launch_v2<NRV, 5>(A, n_cu, s);         \
+    case 8: return launch_v2<NRV, 8>(A, n_cu, s);         \
+    case 9: return launch_v2<NRV, 9>(A, n_cu, s);         \
+    case 13: return launch_v2<NRV, 13>(A, n_cu, s);       \
+    default: return launch_v2<NRV>(A, n_cu, s);           \
+  }
+      case 0: AT_V2_POL(0)
       case 2: return launch_v2<2>(A, n_cu, s);
-      case 4:
-        if (tuning.nw == 12) return launch_v2<4, 0, 12>(A, n_cu, s);
-        switch (A.flags & 7) {
-          case 1: return launch_v2<4, 1>(A, n_cu, s);
-          case 2: return launch_v2<4, 2>(A, n_cu, s);
-          case 4: return launch_v2<4, 4>(A, n_cu, s);
-          default: return launch_v2<4>(A, n_cu, s);
-        }
+      case 4: AT_V2_POL(4)
+#undef AT_V2_POL
       case 6: return launch_v2<6>(A, n_cu, s);
     }
   }
