@@ -549,6 +549,18 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
     twb[b] = A.tw[2 * jb[b]];
   }
   const int src_lane4 = ((64 - lane) & 63) << 2;   // ds_bpermute byte index of the partner lane
+  // this lane's mel units (one per round): magnitude row, the four tree-step bits as bytes, band to store
+  int m_off[MEL ? NR : 1], m_fl[MEL ? NR : 1], m_st[MEL ? NR : 1];
+  if constexpr (MEL) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int2 ui = s_uinfo[r * 64 + lane];
+      const int fl = ui.y;
+      m_off[r] = ui.x;
+      m_fl[r] = (fl & 1) | (((fl >> 1) & 1) << 8) | (((fl >> 2) & 1) << 16) | (((fl >> 3) & 1) << 24);
+      m_st[r] = (fl & 16) ? (fl >> 8) : -1;
+    }
+  }
 
   const int Ti = (int)A.T;
   const int n_out = (int)A.n_out;
@@ -721,37 +733,44 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       if (t >= 1 && t < 16) magbuf[(M / 16) * MAG_ROW + t] = 0.f;
       wave_sync();
       float* mrow = A.mel + ((int64_t)row * n_out + fo) * A.n_mels;
+      // Unit dot products as packed FMAs on the float4 rows as they come out of LDS (two
+      // independent accumulator pairs: dependency depth 6 instead of 16), both units of a round
+      // pair requested before the first is consumed; the segmented sums take their participation
+      // bits as 0.0 / 1.0 factors (v_cvt_f32_ubyte of a per-lane register), one FMA per step.
+      typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int r0 = 0; r0 < NR; r0 += 2) {
-        float acc[2];
-        int u_fl[2];
+        float4 wv[2][4], mv[2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int r = r0 + j;
-          const int2 ui = s_uinfo[r * 64 + lane];
-          u_fl[j] = ui.y;
-          const float4* mq = reinterpret_cast<const float4*>(magbuf + ui.x);
+          const float4* mq = reinterpret_cast<const float4*>(magbuf + m_off[r]);
           const float4* wq = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW);
-          float v = 0.f;
 #pragma unroll
-          for (int i4 = 0; i4 < 4; ++i4) {
-            const float4 w = wq[i4];
-            const float4 m = mq[i4];
-            v = fmaf(w.x, m.x, v);
-            v = fmaf(w.y, m.y, v);
-            v = fmaf(w.z, m.z, v);
-            v = fmaf(w.w, m.w, v);
+          for (int i4 = 0; i4 < 4; ++i4) { wv[j][i4] = wq[i4]; mv[j][i4] = mq[i4]; }
+        }
+        float acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          v2f e = v2f{wv[j][0].x, wv[j][0].y} * v2f{mv[j][0].x, mv[j][0].y};
+          v2f o = v2f{wv[j][0].z, wv[j][0].w} * v2f{mv[j][0].z, mv[j][0].w};
+#pragma unroll
+          for (int i4 = 1; i4 < 4; ++i4) {
+            e = __builtin_elementwise_fma(v2f{wv[j][i4].x, wv[j][i4].y}, v2f{mv[j][i4].x, mv[j][i4].y}, e);
+            o = __builtin_elementwise_fma(v2f{wv[j][i4].z, wv[j][i4].w}, v2f{mv[j][i4].z, mv[j][i4].w}, o);
           }
-          acc[j] = v;
+          const v2f sum = e + o;
+          acc[j] = sum.x + sum.y;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+          const unsigned f = (unsigned)m_fl[r0 + j];
           float sh;
-          sh = dpp_row_shl<1>(acc[j]); acc[j] += (u_fl[j] & 1) ? sh : 0.f;
-          sh = dpp_row_shl<2>(acc[j]); acc[j] += (u_fl[j] & 2) ? sh : 0.f;
-          sh = dpp_row_shl<4>(acc[j]); acc[j] += (u_fl[j] & 4) ? sh : 0.f;
-          sh = dpp_row_shl<8>(acc[j]); acc[j] += (u_fl[j] & 8) ? sh : 0.f;
-          if (u_fl[j] & 16) mrow[u_fl[j] >> 8] = acc[j];
+          sh = dpp_row_shl<1>(acc[j]); acc[j] = fmaf(sh, (float)(f & 0xffu), acc[j]);
+          sh = dpp_row_shl<2>(acc[j]); acc[j] = fmaf(sh, (float)((f >> 8) & 0xffu), acc[j]);
+          sh = dpp_row_shl<4>(acc[j]); acc[j] = fmaf(sh, (float)((f >> 16) & 0xffu), acc[j]);
+          sh = dpp_row_shl<8>(acc[j]); acc[j] = fmaf(sh, (float)(f >> 24), acc[j]);
+          if (m_st[r0 + j] >= 0) mrow[m_st[r0 + j]] = acc[j];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
