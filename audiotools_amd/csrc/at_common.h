@@ -75,6 +75,35 @@ inline int env_int_once(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+// Streaming global accesses with a compile-time cache policy: NT = true marks the access
+// non-temporal (`nt`: the line is not kept in the vector L1 / is the first to leave L2).  Which
+// kernels use it is a per-kernel measurement; the plain form is the default.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef v2f_t v2f_a4_t __attribute__((aligned(4)));     // dword-aligned pair
+template <bool NT> __device__ __forceinline__ float ldg(const float* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+template <bool NT> __device__ __forceinline__ float2 ldg2(const float2* p) {
+  if constexpr (NT) { const v2f_t u = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(p)); return make_float2(u.x, u.y); }
+  else return *p;
+}
+template <bool NT> __device__ __forceinline__ float2 ldg2_a4(const float* p) {
+  if constexpr (NT) { const v2f_a4_t u = __builtin_nontemporal_load(reinterpret_cast<const v2f_a4_t*>(p)); return make_float2(u.x, u.y); }
+  else { const v2f_a4_t u = *reinterpret_cast<const v2f_a4_t*>(p); return make_float2(u.x, u.y); }
+}
+template <bool NT> __device__ __forceinline__ float4 ldg4(const float4* p) {
+  if constexpr (NT) { const v4f_t u = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p)); return make_float4(u.x, u.y, u.z, u.w); }
+  else return *p;
+}
+template <bool NT> __device__ __forceinline__ void stg(float* p, float v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <bool NT> __device__ __forceinline__ void stg2_a4(float* p, float x, float y) {
+  const v2f_a4_t u = {x, y};
+  if constexpr (NT) __builtin_nontemporal_store(u, reinterpret_cast<v2f_a4_t*>(p)); else *reinterpret_cast<v2f_a4_t*>(p) = u;
+}
+
 // Wave-level rendezvous for LDS exchange between the lanes of ONE wave64.
 // DS operations of a wave execute in issue order; the fences stop the
 // compiler from moving LDS traffic across the exchange point.

@@ -189,6 +189,12 @@ __global__ __launch_bounds__(256) void istft_env_kernel(const float* __restrict_
   }
 }
 
+#ifndef AT_NT_ISTFT_LD
+#define AT_NT_ISTFT_LD 0   // 1: spectrum loads non-temporal (measurement build)
+#endif
+#ifndef AT_NT_ISTFT_ST
+#define AT_NT_ISTFT_ST 0   // 1: signal stores non-temporal (measurement build)
+#endif
 #ifndef AT_ISTFT_WPS
 #define AT_ISTFT_WPS 2
 #endif
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     const bool live = fx >= 0 && fx < A.n_x && f < h1;
     const float2* __restrict__ Xf = Xrow + (int64_t)(live ? fx : 0) * (M + 1);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) xa[q] = Xf[t + L * q];
-    xN = Xf[M];
+    for (int q = 0; q < 16; ++q) xa[q] = at::ldg2<AT_NT_ISTFT_LD != 0>(Xf + t + L * q);
+    xN = at::ldg2<AT_NT_ISTFT_LD != 0>(Xf + M);
     if constexpr (MELB) {
       const float* __restrict__ gr = A.gmel + (row * (int64_t)A.n_x + (live ? fx : 0)) * A.n_mels;
 #pragma unroll
@@ -389,8 +395,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
       if (__all(inside)) {
 #pragma unroll
         for (int q = 0; q < SH; ++q) {
-          f2u o; o.x = acc[q].x * env[q].x; o.y = acc[q].y * env[q].y;
-          *reinterpret_cast<f2u*>(orow + p_seg + 2 * (t + L * q)) = o;
+          at::stg2_a4<AT_NT_ISTFT_ST != 0>(orow + p_seg + 2 * (t + L * q), acc[q].x * env[q].x, acc[q].y * env[q].y);
         }
       } else if (emit) {
 #pragma unroll
