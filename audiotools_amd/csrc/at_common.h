@@ -77,7 +77,10 @@ inline int env_int_once(const char* name, int dflt) {
 
 // Streaming global accesses with a compile-time cache policy: NT = true marks the access
 // non-temporal (`nt`: the line is not kept in the vector L1 / is the first to leave L2).  Which
-// kernels use it is a per-kernel measurement; the plain form is the default.
+// kernels use it is a per-kernel measurement (profiles/r02_notes.md): the v2 STFT's spectrum stores
+// and the fused inverse STFT gain 2-4 %; LUFS, the overlap-save FIR and the resampler do not (and a
+// load wrapped in a function cost the LUFS kernel its prefetch: every tile load was followed by
+// s_waitcnt vmcnt(0) -- check the ISA when touching a load that is issued ahead of its use).
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef v2f_t v2f_a4_t __attribute__((aligned(4)));     // dword-aligned pair

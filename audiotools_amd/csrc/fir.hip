@@ -312,12 +312,6 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResMfmaArgs A
 //   * one __syncthreads() per tile swaps the buffers.
 // Tiles are 16 frames (one MFMA row block): two buffers of ~30 KB, two workgroups per CU, and
 // 2 x NPB MFMA waves per CU spread evenly over the four SIMDs.
-#ifndef AT_NT_RES_ST
-#define AT_NT_RES_ST 0      // 1: output stores of the ws kernel non-temporal (measurement build)
-#endif
-#ifndef AT_NT_RES_LD
-#define AT_NT_RES_LD 0      // 2: LDS-DMA tile loads with the nt policy (aux = 2) (measurement build)
-#endif
 constexpr int WS_NC = 6;          // 32-tap chunks a wave keeps in registers (441 -> 160 needs 6)
 
 template <int NC>
@@ -350,7 +344,7 @@ __global__ __launch_bounds__(1024, 6) void resample_mfma_ws_kernel(const ResMfma
         const int i = i0 + lane;
         const float* g = src + 4 * (i < n4 ? i : 0);       // lanes past the end re-read element 0 into the slack
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(dst + 4 * i0), 16, 0, AT_NT_RES_LD);
+                                         (__attribute__((address_space(3))) void*)(dst + 4 * i0), 16, 0, 0);
       }
     } else {
       for (int m = lane; m < 4 * n4; m += 64) {
@@ -407,7 +401,7 @@ __global__ __launch_bounds__(1024, 6) void resample_mfma_ws_kernel(const ResMfma
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t o = (f0 + 4 * k + r) * A.new_sr + ph;
-          if (o < A.out_len) at::stg<AT_NT_RES_ST != 0>(orow + o, acc0[r] + acc1[r]);
+          if (o < A.out_len) orow[o] = acc0[r] + acc1[r];
         }
       }
     }

@@ -23,13 +23,6 @@
 #include "at_common.h"
 #include "fft_wave.h"
 
-#ifndef AT_NT_FIRFFT_LD
-#define AT_NT_FIRFFT_LD 0   // 1: block loads non-temporal (measurement build)
-#endif
-#ifndef AT_NT_FIRFFT_ST
-#define AT_NT_FIRFFT_ST 0   // 1: output stores non-temporal (measurement build)
-#endif
-
 namespace {
 
 constexpr int FF_M = 1024;            // complex FFT length
@@ -183,7 +176,8 @@ __global__ __launch_bounds__(FF_NW * 64, FF_WPS) void fir_fft_kernel(const FirFf
     const float* __restrict__ p = xr + (blk * V - A.half + A.j0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      nx[q] = at::ldg2_a4<AT_NT_FIRFFT_LD != 0>(p + 2 * (t + L * q));
+      const f2u v = *reinterpret_cast<const f2u*>(p + 2 * (t + L * q));
+      nx[q] = make_float2(v.x, v.y);
     }
   };
   bool have_nx = false;
@@ -255,7 +249,8 @@ __global__ __launch_bounds__(FF_NW * 64, FF_WPS) void fir_fft_kernel(const FirFf
         const float2 y = fbuf[phys<L>(n)];
         float* __restrict__ po = orow + o0 + 2 * n;
         if (2 * L * (q + 1) <= lim) {            // the whole wave is inside: wave-uniform, no exec masking
-          at::stg2_a4<AT_NT_FIRFFT_ST != 0>(po, y.x, -y.y);
+          f2u o; o.x = y.x; o.y = -y.y;
+          *reinterpret_cast<f2u*>(po) = o;
         } else if (2 * L * q < lim) {
           if (2 * n < lim) po[0] = y.x;
           if (2 * n + 1 < lim) po[1] = -y.y;

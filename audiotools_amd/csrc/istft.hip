@@ -189,11 +189,13 @@ __global__ __launch_bounds__(256) void istft_env_kernel(const float* __restrict_
   }
 }
 
+// cache policy of the streaming traffic of the fused kernel: non-temporal spectrum loads and signal
+// stores measured 2.097 -> 2.056 ms at B = 512 (same box, profiles/r02_notes.md); 0 = plain
 #ifndef AT_NT_ISTFT_LD
-#define AT_NT_ISTFT_LD 0   // 1: spectrum loads non-temporal (measurement build)
+#define AT_NT_ISTFT_LD 1
 #endif
 #ifndef AT_NT_ISTFT_ST
-#define AT_NT_ISTFT_ST 0   // 1: signal stores non-temporal (measurement build)
+#define AT_NT_ISTFT_ST 1
 #endif
 #ifndef AT_ISTFT_WPS
 #define AT_ISTFT_WPS 2

@@ -31,9 +31,6 @@ constexpr int CHUNK = 32;            // samples per lane
 constexpr int SB = 64 * CHUNK;       // samples per super-block
 constexpr int ROWF = CHUNK + 4;      // padded LDS row (floats): 144 B
 constexpr int MAX_STAGE = 4;
-#ifndef AT_NT_LUFS
-#define AT_NT_LUFS 0     // 1: the sample loads are non-temporal (measurement build)
-#endif
 #ifndef AT_LUFS_WPS
 #define AT_LUFS_WPS 3   // waves per SIMD the register allocator must allow
 #endif
@@ -243,7 +240,7 @@ __global__ __launch_bounds__(256, AT_LUFS_WPS) void kweight_hop_energy(const Luf
       for (int i = 0; i < 8; ++i) {
         const int64_t g = sb + 4 * (int64_t)(i * 64 + lane);
         const int64_t gc = g < A.T ? g : A.T - 4;
-        const float4 val = at::ldg4<AT_NT_LUFS != 0>(reinterpret_cast<const float4*>(xr + gc));
+        const float4 val = *reinterpret_cast<const float4*>(xr + gc);
         R[i] = g < A.T ? val : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
@@ -253,7 +250,7 @@ __global__ __launch_bounds__(256, AT_LUFS_WPS) void kweight_hop_energy(const Luf
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t g = sb + (4 * i + j) * 64 + lane;
-          const float val = at::ldg<AT_NT_LUFS != 0>(xr + (g < A.T ? g : A.T - 1));
+          const float val = xr[g < A.T ? g : A.T - 1];
           e[j] = g < A.T ? val : 0.f;
         }
         R[i] = make_float4(e[0], e[1], e[2], e[3]);

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
 //  * window and pass-2 twiddles are read as ds_read_b128 rows (the stride-64 float2 reads were
 //    merged by the compiler into half-rate ds_read2st64_b64).
 // POL = cache policy of the streaming traffic (AT_STFT_FLAGS, measurement knob; 0 is shipped):
-//   bit 0: stores `nt`;  bit 2: the sample loads `nt`;  bit 3: raised wave priority (s_setprio 3) while
+//   bit 0: spectrum stores `nt`;  bit 1: mel stores `nt`;  bit 2: the sample loads `nt`;  bit 3: raised wave priority (s_setprio 3) while
 //   the loads and stores of a frame are issued.  (`sc1` write-through stores were measured 25 % slower.)
 template <int POL>
 __device__ __forceinline__ void st2(float2* p, float2 v) {
@@ -737,49 +737,53 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       wave_sync();
       float* mrow = A.mel + ((int64_t)row * n_out + fo) * A.n_mels;
       // Unit dot products as packed FMAs on the float4 rows as they come out of LDS (two
-      // independent accumulator pairs: dependency depth 6 instead of 16), both units of a round
-      // pair requested before the first is consumed; the segmented sums take their participation
-      // bits as 0.0 / 1.0 factors (v_cvt_f32_ubyte of a per-lane register), one FMA per step.
+      // independent accumulator pairs: dependency depth 6 instead of 16); the segmented sums take
+      // their participation bits as 0.0 / 1.0 factors, one FMA per step.  Software pipeline over the
+      // rounds with two operand buffers: the reads of round r + 2 are issued as soon as round r's
+      // products are done, and the (serial) DPP chain of round r - 1 shares its issue slots with
+      // the products of round r.
       typedef float v2f __attribute__((ext_vector_type(2)));
+      float4 wv[2][4], mv[2][4];
+      auto load_unit = [&](int r, int b) __attribute__((always_inline)) {
+        const float4* mq = reinterpret_cast<const float4*>(magbuf + m_off[r]);
+        const float4* wq = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW);
 #pragma unroll
-      for (int r0 = 0; r0 < NR; r0 += 2) {
-        float4 wv[2][4], mv[2][4];
+        for (int i4 = 0; i4 < 4; ++i4) { wv[b][i4] = wq[i4]; mv[b][i4] = mq[i4]; }
+      };
+      auto dot_unit = [&](int b) __attribute__((always_inline)) -> float {
+        v2f e = v2f{wv[b][0].x, wv[b][0].y} * v2f{mv[b][0].x, mv[b][0].y};
+        v2f o = v2f{wv[b][0].z, wv[b][0].w} * v2f{mv[b][0].z, mv[b][0].w};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int r = r0 + j;
-          const float4* mq = reinterpret_cast<const float4*>(magbuf + m_off[r]);
-          const float4* wq = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW);
-#pragma unroll
-          for (int i4 = 0; i4 < 4; ++i4) { wv[j][i4] = wq[i4]; mv[j][i4] = mq[i4]; }
+        for (int i4 = 1; i4 < 4; ++i4) {
+          e = __builtin_elementwise_fma(v2f{wv[b][i4].x, wv[b][i4].y}, v2f{mv[b][i4].x, mv[b][i4].y}, e);
+          o = __builtin_elementwise_fma(v2f{wv[b][i4].z, wv[b][i4].w}, v2f{mv[b][i4].z, mv[b][i4].w}, o);
         }
-        float acc[2];
+        const v2f sum = e + o;
+        return sum.x + sum.y;
+      };
+      auto reduce_store = [&](float acc, int r) __attribute__((always_inline)) {
+        const unsigned f = (unsigned)m_fl[r];
+        float sh;
+        sh = dpp_row_shl<1>(acc); acc = fmaf(sh, (float)(f & 0xffu), acc);
+        sh = dpp_row_shl<2>(acc); acc = fmaf(sh, (float)((f >> 8) & 0xffu), acc);
+        sh = dpp_row_shl<4>(acc); acc = fmaf(sh, (float)((f >> 16) & 0xffu), acc);
+        sh = dpp_row_shl<8>(acc); acc = fmaf(sh, (float)(f >> 24), acc);
+        if (m_st[r] >= 0) at::stg<(POL & 2) != 0>(mrow + m_st[r], acc);
+      };
+      load_unit(0, 0);
+      load_unit(1, 1);
+      float acc_prev = dot_unit(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NR > 2) load_unit(2, 0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          v2f e = v2f{wv[j][0].x, wv[j][0].y} * v2f{mv[j][0].x, mv[j][0].y};
-          v2f o = v2f{wv[j][0].z, wv[j][0].w} * v2f{mv[j][0].z, mv[j][0].w};
-#pragma unroll
-          for (int i4 = 1; i4 < 4; ++i4) {
-            e = __builtin_elementwise_fma(v2f{wv[j][i4].x, wv[j][i4].y}, v2f{mv[j][i4].x, mv[j][i4].y}, e);
-            o = __builtin_elementwise_fma(v2f{wv[j][i4].z, wv[j][i4].w}, v2f{mv[j][i4].z, mv[j][i4].w}, o);
-          }
-          const v2f sum = e + o;
-          acc[j] = sum.x + sum.y;
-        }
-        // the two segmented sums step together (independent chains fill each other's DPP wait states)
-        const unsigned f0 = (unsigned)m_fl[r0], f1 = (unsigned)m_fl[r0 + 1];
-        float sh0, sh1;
-        sh0 = dpp_row_shl<1>(acc[0]); sh1 = dpp_row_shl<1>(acc[1]);
-        acc[0] = fmaf(sh0, (float)(f0 & 0xffu), acc[0]); acc[1] = fmaf(sh1, (float)(f1 & 0xffu), acc[1]);
-        sh0 = dpp_row_shl<2>(acc[0]); sh1 = dpp_row_shl<2>(acc[1]);
-        acc[0] = fmaf(sh0, (float)((f0 >> 8) & 0xffu), acc[0]); acc[1] = fmaf(sh1, (float)((f1 >> 8) & 0xffu), acc[1]);
-        sh0 = dpp_row_shl<4>(acc[0]); sh1 = dpp_row_shl<4>(acc[1]);
-        acc[0] = fmaf(sh0, (float)((f0 >> 16) & 0xffu), acc[0]); acc[1] = fmaf(sh1, (float)((f1 >> 16) & 0xffu), acc[1]);
-        sh0 = dpp_row_shl<8>(acc[0]); sh1 = dpp_row_shl<8>(acc[1]);
-        acc[0] = fmaf(sh0, (float)(f0 >> 24), acc[0]); acc[1] = fmaf(sh1, (float)(f1 >> 24), acc[1]);
-        if (m_st[r0] >= 0) mrow[m_st[r0]] = acc[0];
-        if (m_st[r0 + 1] >= 0) mrow[m_st[r0 + 1]] = acc[1];
+      for (int r = 1; r < NR; ++r) {
+        const float acc_cur = dot_unit(r & 1);
+        reduce_store(acc_prev, r - 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (r + 2 < NR) load_unit(r + 2, r & 1);
+        acc_prev = acc_cur;
       }
+      reduce_store(acc_prev, NR - 1);
       wave_sync();
     }
     return have_nxt;
@@ -1077,8 +1081,9 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
     // the reference's default transform at 44.1 / 48 kHz: n_fft 2048, hop 512, no match_stride
     switch (A.n_units / 64) {
 #define AT_V2_POL(NRV)                                    \
-  switch (A.flags & 13) {                                 \
+  switch (A.flags & 15) {                                 \
     case 1: return launch_v2<NRV, 1>(A, n_cu, s);         \
+    case 3: return launch_v2<NRV, 3>(A, n_cu, s);         \
     case 4: return launch_v2<NRV, 4>(A, n_cu, s);         \
     case 5: return launch_v2<NRV, 5>(A, n_cu, s);         \
     case 8: return launch_v2<NRV, 8>(A, n_cu, s);         \
