@@ -175,6 +175,28 @@ __device__ __forceinline__ void pass_compute_store(float2 (&a)[16], float2* __re
   }
 }
 
+// The LAST pass of a transform (NS * R == M) needs no exchange: butterfly j = t + b L writes points
+// j + r NS = t + L (b + r NB), i.e. exactly the register slots q = b + r NB of the same thread in the
+// "point t + L q" layout that load_points() produces.  Results stay in a[].
+template <int R, int NS, int L>
+__device__ __forceinline__ void pass_compute_regs(float2 (&a)[16], const float2* __restrict__ tw /* [NB][R], r=0 unused */) {
+  static_assert(NS * R == 16 * L, "only the last pass is in place");
+  constexpr int NB = 16 / R;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = a[b + r * NB];
+    if constexpr (NS > 1) {
+#pragma unroll
+      for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[b * R + r]);
+    }
+    Dft<R>::run(v);
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[b + r * NB] = v[r];
+  }
+}
+
 template <int L, bool PAD256 = false>
 __device__ __forceinline__ void load_points(float2 (&a)[16], const float2* __restrict__ buf, int t) {
 #pragma unroll

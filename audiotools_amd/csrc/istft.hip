@@ -222,8 +222,11 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   if constexpr (MELB) {
     for (int i = threadIdx.x; i <= M; i += 256) { s_bb[i] = A.bin_bands[i]; s_bw[i] = A.bin_w[i]; }
   }
+  // the 1/N of the inverse transform (1/2 for the adjoint) rides on the window table
+  const float inv_n = ADJ ? 0.5f : 1.0f / (float)(2 * M);
   for (int i = threadIdx.x; i < M; i += 256) {
-    s_win2[i] = reinterpret_cast<const float2*>(A.window)[i];
+    const float2 w = reinterpret_cast<const float2*>(A.window)[i];
+    s_win2[i] = make_float2(w.x * inv_n, w.y * inv_n);
     s_twf[i] = A.tw[i];
   }
   if constexpr (P::R2 > 1) {
@@ -262,7 +265,6 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = make_float2(0.f, 0.f);
 
-  const float inv_n = ADJ ? 0.5f : 1.0f / (float)N;
   // Every lane loads bin k = t + L q of its frame ONCE (ascending, 512 B per wave instruction);
   // the Hermitian partner X[M-k] of the fold is register 15-q of lane (L - t) mod L and comes
   // over the LDS crossbar (ds_bpermute).  Lane 0 pairs with itself: register 16-q, and the
@@ -349,9 +351,14 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
 #pragma unroll
       for (int q = 0; q < SH; ++q) env[q] = e2[t + L * q];
     }
-    pass_compute_store<16, 1, L>(a, fbuf, t, nullptr);
-    wave_sync();
-    if constexpr (P::R2 > 1) {
+    // The last pass of the transform runs in place on registers (pass_compute_regs): its outputs
+    // are the points t + L q of this thread, the layout the register window needs -- no slab
+    // round trip behind it.
+    if constexpr (P::R2 == 1) {
+      pass_compute_regs<16, 1, L>(a, nullptr);
+    } else {
+      pass_compute_store<16, 1, L>(a, fbuf, t, nullptr);
+      wave_sync();
       load_points<L>(a, fbuf, t);
       wave_sync();
       float2 tw2[NB2 * P::R2];
@@ -361,32 +368,31 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
 #pragma unroll
         for (int r = 1; r < P::R2; ++r) tw2[b * P::R2 + r] = rowp[r];
       }
-      pass_compute_store<P::R2, 16, L>(a, fbuf, t, tw2);
-      wave_sync();
-    }
-    if constexpr (P::R3 > 1) {
-      load_points<L>(a, fbuf, t);
-      wave_sync();
-      float2 tw3[NB3 * P::R3];
+      if constexpr (P::R3 == 1) {
+        pass_compute_regs<P::R2, 16, L>(a, tw2);
+      } else {
+        pass_compute_store<P::R2, 16, L>(a, fbuf, t, tw2);
+        wave_sync();
+        load_points<L>(a, fbuf, t);
+        wave_sync();
+        float2 tw3[NB3 * P::R3];
 #pragma unroll
-      for (int b = 0; b < NB3; ++b) {
-        tw3[b * P::R3 + 1] = tw3b[b];
+        for (int b = 0; b < NB3; ++b) {
+          tw3[b * P::R3 + 1] = tw3b[b];
 #pragma unroll
-        for (int r = 2; r < P::R3; ++r) tw3[b * P::R3 + r] = cmul(tw3[b * P::R3 + r - 1], tw3b[b]);
+          for (int r = 2; r < P::R3; ++r) tw3[b * P::R3 + r] = cmul(tw3[b * P::R3 + r - 1], tw3b[b]);
+        }
+        pass_compute_regs<P::R3, 16 * P::R2, L>(a, tw3);
       }
-      pass_compute_store<P::R3, 16 * P::R2, L>(a, fbuf, t, tw3);
-      wave_sync();
     }
     // windowed frame into the register window: acc[q] covers samples 2(t + L q), +1 of frame f
+    // (the window table carries the 1/N)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int n = t + L * q;
-      const float2 y = fbuf[phys<L>(n)];
-      const float2 w = s_win2[n];
-      acc[q].x = fmaf(y.x * inv_n, w.x, acc[q].x);
-      acc[q].y = fmaf(-y.y * inv_n, w.y, acc[q].y);
+      const float2 w = s_win2[t + L * q];
+      acc[q].x = fmaf(a[q].x, w.x, acc[q].x);
+      acc[q].y = fmaf(-a[q].y, w.y, acc[q].y);
     }
-    wave_sync();
     // segment f is complete: scale by 1/envelope, store, shift the window by one hop.
     // Interior segments (all lanes of the wave inside [0, length)) take straight-line stores; the
     // row edges go through the guarded path.
