@@ -12,7 +12,9 @@ restatements by the same author, so each is compared here with something that au
 * the julius windowed-sinc resampler with properties no restatement can fake: a band-limited sine
   keeps amplitude and phase through 44.1 -> 16 kHz and back up, and an integer-ratio resample agrees
   with ``scipy.signal.resample_poly`` run with the SAME kernel (checks the polyphase indexing, not the
-  kernel formula).
+  kernel formula);
+* the julius low-pass design (low_pass / high_pass / equalizer) with ``scipy.signal.firwin``, and the
+  HTK band edges of the equaliser with transformers' mel conversions.
 Runs on CPU; the transformers check is skipped when that package is missing."""
 import math
 
@@ -137,3 +139,29 @@ def test_resample_integer_ratio_vs_scipy_polyphase(old, new):
         out[p] = full[::old][: out.shape[1]]
     ref = out.T.reshape(-1)[: len(y)]
     assert np.abs(ref - y).max() < 1e-5 * max(1.0, np.abs(y).max())
+
+
+@pytest.mark.parametrize("cutoff", [0.25, 0.1, 4000 / 44100, 8000 / 48000, 0.45, 0.02])
+def test_lowpass_taps_vs_scipy_firwin(cutoff):
+    """julius.lowpass.LowPassFilters (the leaf behind low_pass / high_pass / equalizer, dsp.py:153-215):
+    a symmetric-Hann-windowed sinc of half length int(zeros / cutoff / 2) with unit DC gain -- the
+    definition scipy.signal.firwin(window="hann") implements independently."""
+    import scipy.signal as ss
+    for zeros in (8, 51):            # 8: the band-split bank of equalizer(); 51: low_pass / high_pass (dsp.py:153)
+        h = tables.lowpass_half_size(cutoff, zeros)
+        ours = np.asarray(tables.lowpass_taps(torch.tensor(cutoff), float(zeros), h), dtype=np.float64).reshape(-1)
+        want = ss.firwin(2 * h + 1, cutoff, window="hann", fs=1.0)
+        assert ours.shape == want.shape and np.abs(ours - want).max() < 2e-7
+    x = torch.randn(1, 1, 6000, generator=torch.Generator().manual_seed(1))
+    y = restate.low_pass(x, torch.tensor([cutoff * 16000.0]), 16000)[0, 0].numpy().astype(np.float64)
+    xp = np.pad(x[0, 0].numpy().astype(np.float64), (h, h), mode="edge")          # julius pads by replication
+    ref = ss.correlate(xp, want, mode="valid")
+    assert ref.shape == y.shape and np.abs(ref - y).max() < 2e-5
+
+
+def test_htk_band_edges_vs_transformers():
+    au = pytest.importorskip("transformers.audio_utils")
+    for sr, n_bands in [(44100, 6), (48000, 6), (16000, 4), (44100, 12)]:
+        mels = np.linspace(au.hertz_to_mel(0.0, "htk"), au.hertz_to_mel(sr / 2, "htk"), n_bands + 1)
+        want = au.mel_to_hertz(mels, "htk")[1:-1]
+        assert np.abs(tables.htk_band_edges(sr, n_bands) - want).max() < 1e-6 * sr
