@@ -26,13 +26,30 @@ from audiotools_amd import tables
 from oracle import restate
 from oracle.leaves import misc_leaves, pyloudnorm_leaf
 
+def _hf_audio_utils():
+    """transformers.audio_utils, imported with the oracle's leaf shims (spec-less stand-ins for
+    torchaudio, librosa, ... that oracle/ref_import.py may have put into sys.modules in this test
+    session) out of the way: transformers probes optional packages with importlib.util.find_spec,
+    which rejects a module without a __spec__."""
+    import sys
+    hidden = {k: sys.modules.pop(k) for k in list(sys.modules)
+              if k != "__main__" and getattr(sys.modules[k], "__spec__", None) is None
+              and getattr(sys.modules[k], "__file__", None) is None}
+    try:
+        au = pytest.importorskip("transformers.audio_utils")
+    finally:
+        for k, v in hidden.items():
+            sys.modules.setdefault(k, v)
+    return au
+
+
 MEL_CASES = [(44100, 2048, 80, 0.0, None), (16000, 512, 40, 0.0, None), (48000, 2048, 128, 20.0, 16000.0),
              (22050, 1024, 64, 0.0, 8000.0)]
 
 
 @pytest.mark.parametrize("sr,n_fft,n_mels,fmin,fmax", MEL_CASES)
 def test_mel_basis_vs_transformers(sr, n_fft, n_mels, fmin, fmax):
-    au = pytest.importorskip("transformers.audio_utils")
+    au = _hf_audio_utils()
     hf = au.mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=n_mels, min_frequency=fmin,
                             max_frequency=fmax if fmax is not None else sr / 2, sampling_rate=sr, norm="slaney",
                             mel_scale="slaney").T
@@ -160,7 +177,7 @@ def test_lowpass_taps_vs_scipy_firwin(cutoff):
 
 
 def test_htk_band_edges_vs_transformers():
-    au = pytest.importorskip("transformers.audio_utils")
+    au = _hf_audio_utils()
     for sr, n_bands in [(44100, 6), (48000, 6), (16000, 4), (44100, 12)]:
         mels = np.linspace(au.hertz_to_mel(0.0, "htk"), au.hertz_to_mel(sr / 2, "htk"), n_bands + 1)
         want = au.mel_to_hertz(mels, "htk")[1:-1]
