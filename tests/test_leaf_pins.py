@@ -14,7 +14,8 @@ restatements by the same author, so each is compared here with something that au
   with ``scipy.signal.resample_poly`` run with the SAME kernel (checks the polyphase indexing, not the
   kernel formula);
 * the julius low-pass design (low_pass / high_pass / equalizer) with ``scipy.signal.firwin``, and the
-  HTK band edges of the equaliser with transformers' mel conversions.
+  HTK band edges of the equaliser with transformers' mel conversions;
+* the BS.1770 meter as a whole with the expected readings EBU Tech 3341 publishes for its test signals.
 Runs on CPU; the transformers check is skipped when that package is missing."""
 import math
 
@@ -182,3 +183,30 @@ def test_htk_band_edges_vs_transformers():
         mels = np.linspace(au.hertz_to_mel(0.0, "htk"), au.hertz_to_mel(sr / 2, "htk"), n_bands + 1)
         want = au.mel_to_hertz(mels, "htk")[1:-1]
         assert np.abs(tables.htk_band_edges(sr, n_bands) - want).max() < 1e-6 * sr
+
+
+def _tone(db, seconds, sr=48000, f=1000.0):
+    t = torch.arange(int(seconds * sr), dtype=torch.float64) / sr
+    return (10 ** (db / 20) * torch.sin(2 * math.pi * f * t)).float()
+
+
+def test_loudness_ebu_tech_3341_cases():
+    """EBU Tech 3341 minimum-requirement signals (published expected values, tolerance +-0.1 LU):
+    case 1/2 -- stereo 1 kHz sine at -23 / -33 dBFS for 20 s reads -23.0 / -33.0 LUFS;
+    case 3 -- -36 dBFS 10 s, -23 dBFS 60 s, -36 dBFS 10 s reads -23.0 LUFS (relative gate at work);
+    case 5 -- -26 dBFS 20 s, -20 dBFS 20.1 s, -26 dBFS 20 s reads -23.0 LUFS.
+    Run on the oracle (the reference's CPU / IIR branch) and on the product's CPU path."""
+    import audiotools_amd as A
+    sr = 48000
+    cases = [
+        (torch.cat([_tone(-23.0, 20)]), -23.0),
+        (torch.cat([_tone(-33.0, 20)]), -33.0),
+        (torch.cat([_tone(-36.0, 10), _tone(-23.0, 60), _tone(-36.0, 10)]), -23.0),
+        (torch.cat([_tone(-26.0, 20), _tone(-20.0, 20.1), _tone(-26.0, 20)]), -23.0),
+    ]
+    for mono, want in cases:
+        x = mono[None, None].repeat(1, 2, 1)                 # stereo, in phase
+        got = float(restate.loudness(x, sr)[0])
+        assert abs(got - want) < 0.1, (got, want)
+        got2 = float(A.AudioSignal(x.clone(), sr).loudness()[0])
+        assert abs(got2 - want) < 0.1, (got2, want)
