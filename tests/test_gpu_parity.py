@@ -179,6 +179,26 @@ def test_loudness_vs_oracle(sr, dur, C):
     assert float((got - ref).abs().max()) < LU, (got, ref)
 
 
+def test_loudness_ebu_tech_3341_cases_gpu():
+    """The LUFS kernel against PUBLISHED readings (EBU Tech 3341 minimum-requirement signals 1, 2, 3,
+    5; tolerance +-0.1 LU), all four signals in one batch (zero padding to the longest is part of
+    the check: trailing silence is gated out)."""
+    from tests.test_leaf_pins import _tone
+    sr = 48000
+    sigs = [_tone(-23.0, 20), _tone(-33.0, 20),
+            torch.cat([_tone(-36.0, 10), _tone(-23.0, 60), _tone(-36.0, 10)]),
+            torch.cat([_tone(-26.0, 20), _tone(-20.0, 20.1), _tone(-26.0, 20)])]
+    want = [-23.0, -33.0, -23.0, -23.0]
+    for s_, w in zip(sigs, want):
+        x = s_[None, None].repeat(1, 2, 1)
+        got = float(A.AudioSignal(x, sr).to("cuda").loudness()[0])
+        assert abs(got - w) < 0.1, (got, w)
+    T = max(s_.numel() for s_ in sigs)
+    xb = torch.stack([torch.nn.functional.pad(s_, (0, T - s_.numel())) for s_ in sigs])[:, None].repeat(1, 2, 1)
+    got = A.AudioSignal(xb, sr).to("cuda").loudness().cpu()
+    assert float((got - torch.tensor(want)).abs().max()) < 0.1, got
+
+
 def test_loudness_meter_api_and_cache():
     x = synth.audio_batch(4, 2, 2 * 44100, seed=2, gaps=False)
     m = A.Meter(44100).to("cuda")
