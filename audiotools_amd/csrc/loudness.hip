@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256, AT_LUFS_WPS) void kweight_hop_energy(const Luf
   for (int s = 0; s < NS; ++s) { ky1[s] = ky2[s] = 0.f; kx1[s] = kx2[s] = 0.f; }
 
   int h_cur = -1;
+  int h_run = h0;      // hop containing the first sample whose energy is counted (n0 = h0 S)
   double acc = 0.0;
 
   // raw tile of one super-block in registers: 8 x float4 (VEC4) or 32 x float (scalar path)
@@ -314,8 +315,12 @@ __global__ __launch_bounds__(256, AT_LUFS_WPS) void kweight_hop_energy(const Luf
       // ---- hop energies
       const int64_t lo = max(sb, n0), hi = min(sb + (int64_t)SB, n1);
       if (lo < hi) {
-        const int hf = (int)(lo / A.S), hl = (int)((hi - 1) / A.S);
-        for (int h = hf; h <= hl; ++h) {
+        // hops [hf, hl] overlap [lo, hi).  lo never decreases from one super-block to the next, so the
+        // hop that contains it is tracked incrementally (h_run starts at the segment's first hop):
+        // the two 64-bit divisions lo / S and (hi - 1) / S cost ~15 % of the loop's instructions.
+        while ((int64_t)(h_run + 1) * A.S <= lo) ++h_run;
+        const int hf = h_run;
+        for (int h = hf; (int64_t)h * A.S < hi; ++h) {
           const int64_t a = max(lo, (int64_t)h * A.S), b = min(hi, (int64_t)(h + 1) * A.S);
           float e = 0.f;
           if (a == sb && b == sb + SB) {
