@@ -80,7 +80,7 @@ struct StftArgs {
   int debug;               // development: 1 = compute but never store, 2 = store only (no FFT)
   int flags;               // measurement knob AT_STFT_FLAGS (read once): cache policy of the v2 kernel's streaming traffic (POL)
   int run_max;             // upper bound of `run` for the v2 kernel (AT_STFT_RUNMAX, read once)
-  int n_xcd;               // XCDs the v2 schedule cuts the frame range into (AT_STFT_NX, read once; 8)
+  int n_xcd;               // spans the v2 schedule cuts the frame range into (CUs / 32, i.e. 8 on a whole MI355X; AT_STFT_NX overrides)
   int stagger;             // v2: start-up delay per wave slot of a CU, in units of 64 cycles (AT_STFT_STAGGERV2)
 };
 
@@ -1059,7 +1059,7 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   // process can sweep them, tools/stftsweep.py)
   struct Tuning { int flags, run_max, n_xcd, stagger; };
   auto read_tuning = [] {
-    return Tuning{env_int_once("AT_STFT_FLAGS", -1), env_int_once("AT_STFT_RUNMAX", AT_STFT_RUN_V2), env_int_once("AT_STFT_NX", 8),
+    return Tuning{env_int_once("AT_STFT_FLAGS", -1), env_int_once("AT_STFT_RUNMAX", AT_STFT_RUN_V2), env_int_once("AT_STFT_NX", 0),
                   env_int_once("AT_STFT_STAGGERV2", 0)};
   };
   static const int tune_each_call = env_int_once("AT_STFT_TUNE", 0);
@@ -1069,7 +1069,14 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   // boxes measured), plain stores otherwise (nt: +6 % on one box, -2 % on the other)
   A.flags = tuning.flags >= 0 ? tuning.flags : (mel ? 1 : 0);
   A.run_max = tuning.run_max < 1 ? 1 : tuning.run_max;
-  A.n_xcd = tuning.n_xcd < 1 ? 1 : tuning.n_xcd;
+  // XCD spans of the v2 schedule: one per XCD of the device.  Workgroups are dealt round-robin over the
+  // XCDs (an observed placement, not an API guarantee; the spans only affect L2 locality at run
+  // boundaries, never results).  An XCD has 32 CUs, so a partitioned device (CPX: 32 CUs) gets one span.
+  {
+    int auto_x = device_cu_count() / 32;
+    auto_x = auto_x < 1 ? 1 : (auto_x > 8 ? 8 : auto_x);
+    A.n_xcd = tuning.n_xcd >= 1 ? tuning.n_xcd : auto_x;
+  }
   A.stagger = tuning.stagger < 0 ? 0 : tuning.stagger;
   A.debug = dbg_mode;
   A.reuse_shift = (FW == 1 && hop % (2 * (M / 16)) == 0 && pad == 0) ? hop / (2 * (M / 16)) : 0;
