@@ -14,3 +14,4 @@ from .meter import Meter  # noqa: F401
 from .signal import AudioSignal, STFTParams  # noqa: F401
 from . import transforms  # noqa: F401,E402
 from . import core, data, metrics, ml  # noqa: F401,E402
+from .data import datasets  # noqa: F401,E402  (audiotools.datasets, reference __init__.py:9)

@@ -70,6 +70,19 @@ def _get_value(other):
     return other.audio_data if isinstance(other, AudioSignal) else other
 
 
+def hz_to_bin(hz: torch.Tensor, n_fft: int, sample_rate: int) -> torch.Tensor:
+    """Index of the frequency-grid point nearest to each entry of ``hz`` (core/util.py:100-126).
+    The grid is the reference's: ``n_fft // 2 + 2`` points from 0 to Nyquist; frequencies above
+    Nyquist are clamped to it -- on the flattened VIEW of ``hz``, i.e. in the caller's tensor when
+    it is contiguous, as upstream."""
+    nyquist = sample_rate / 2
+    flat = hz.flatten()
+    flat[flat > nyquist] = nyquist
+    grid = torch.linspace(0, nyquist, n_fft // 2 + 2)
+    nearest = (grid[:, None] - flat[None, :]).abs().argmin(dim=0)
+    return nearest.reshape(hz.shape)
+
+
 def random_state(seed: typing.Union[int, np.random.RandomState, None]):
     if seed is None or seed is np.random:
         return np.random.mtrand._rand

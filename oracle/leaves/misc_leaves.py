@@ -77,6 +77,21 @@ def librosa_mel(*, sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False,
 
 
 # ------------------------------------------------------- torchaudio.functional
+def librosa_amplitude_to_db(S, ref=1.0, amin=1e-5, top_db=80.0):
+    """librosa.core.spectrum.amplitude_to_db (the comparator of the reference's
+    tests/core/test_audio_signal.py:459-467): 20 log10(max(amin, |S|)) - 20 log10(max(amin, ref)),
+    floored at (max - top_db).  numpy in, numpy out."""
+    import numpy as np
+    mag = np.abs(np.asarray(S))
+    ref_value = ref(mag) if callable(ref) else np.abs(ref)
+    power = np.square(mag, out=np.empty_like(mag))
+    out = 10.0 * np.log10(np.maximum(amin ** 2, power))
+    out -= 10.0 * np.log10(np.maximum(amin ** 2, ref_value ** 2))
+    if top_db is not None:
+        out = np.maximum(out, out.max() - top_db)
+    return out
+
+
 def lfilter(waveform: torch.Tensor, a_coeffs: torch.Tensor, b_coeffs: torch.Tensor,
             clamp: bool = True, batching: bool = True) -> torch.Tensor:
     """torchaudio.functional.lfilter (Appendix A.7): Direct-Form-I IIR along

@@ -67,7 +67,7 @@ def _install_shims():
         def _load(*a, **k):
             raise RuntimeError("file I/O is out of scope for the oracle")
 
-        lb = _module("librosa", load=_load)
+        lb = _module("librosa", load=_load, amplitude_to_db=misc_leaves.librosa_amplitude_to_db)
         lb.filters = _module("librosa.filters", mel=misc_leaves.librosa_mel)
 
     if "flatten_dict" not in sys.modules:

@@ -1,0 +1,220 @@
+"""The reference's OWN test functions, executed unchanged against this package (CPU).
+
+The drop-in claim at the level of the reference's test suite: the test modules under
+``/root/reference/tests`` are loaded where they lie (never copied), with ``audiotools`` resolving to
+``audiotools_amd`` while they are imported and run, and every test function that does not need a codec
+binary, a plotting backend or real recordings with a known content is called as pytest would call
+it (its own ``parametrize`` marks are honoured).  The recordings the reference keeps in git-lfs are
+not present in this environment (the files are 130-byte pointers), so the three paths the tests name
+are served from in-memory synthetic audio through the package's ``mem://`` registry -- the
+assertions these tests make are properties of the operations, not of the recordings.
+
+Skipped (with the reason) are: tests that shell out to ffmpeg / sox, write and re-read audio files,
+plot, or compare against third-party packages that are not installed.  Runs only where
+``/root/reference`` exists (the build container); the travelling oracle covers the GPU box.
+"""
+import importlib.util
+import itertools
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import audiotools_amd as A
+from oracle import ref_import
+
+REF_TESTS = os.path.join(ref_import.REFERENCE_ROOT, "tests")
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF_TESTS), reason="reference tree not present")
+
+# path literal in the reference tests -> (channels, seconds, rate, kind)
+_RECORDINGS = {
+    "tests/audio/spk/f10_script4_produced.wav": (1, 30.0, 44100, "speech"),
+    "tests/audio/nz/f5_script2_ipad_balcony1_room_tone.wav": (1, 30.0, 44100, "noise"),
+    "tests/audio/ir/h179_Bar_1txts.wav": (1, 1.0, 44100, "ir"),
+}
+
+
+def _synthetic(kind, channels, seconds, rate, seed):
+    g = torch.Generator().manual_seed(seed)
+    n = int(seconds * rate)
+    t = torch.arange(n, dtype=torch.float64) / rate
+    if kind == "speech":      # amplitude-modulated harmonic stack + noise: loud, broadband, non-stationary
+        env = (0.55 + 0.45 * torch.sin(2 * np.pi * 3.1 * t)) * (0.6 + 0.4 * torch.sin(2 * np.pi * 0.37 * t + 1.0))
+        x = sum(torch.sin(2 * np.pi * f0 * k * t + k) / k for f0 in (140.0, 211.0) for k in range(1, 12))
+        x = 0.08 * env * x + 0.01 * torch.randn(n, generator=g, dtype=torch.float64)
+    elif kind == "noise":
+        x = 0.02 * torch.randn(n, generator=g, dtype=torch.float64)
+        x = x + 0.01 * torch.sin(2 * np.pi * 50 * t)
+    else:                     # impulse response: decaying noise with a clear direct path
+        x = torch.randn(n, generator=g, dtype=torch.float64) * torch.exp(-t / 0.15) * 0.3
+        x[int(0.003 * rate)] = 1.0
+    return x.float()[None].repeat(channels, 1)
+
+
+def _out_of_scope(name):
+    class _Missing:
+        def __init__(self, *a, **k):
+            pytest.skip(f"{name} is outside the hot-path scope (SURVEY.md 2.1)")
+    _Missing.__name__ = name
+    return _Missing
+
+
+class _Aliased:
+    """``audiotools`` -> ``audiotools_amd`` in sys.modules for the duration of a block; the oracle's
+    leaf shims (torchaudio etc.) are installed first so that ``import torchaudio`` in a reference test
+    module resolves.  Everything is restored afterwards (other tests import the real reference)."""
+
+    def __enter__(self):
+        ref_import._install_shims()
+        self.saved = {k: v for k, v in sys.modules.items() if k == "audiotools" or k.startswith("audiotools.")}
+        for k in self.saved:
+            del sys.modules[k]
+        sys.modules["audiotools"] = A
+        for k, v in list(sys.modules.items()):
+            if k.startswith("audiotools_amd."):
+                sys.modules["audiotools" + k[len("audiotools_amd"):]] = v
+        sys.modules["audiotools.core.util"] = A.util                  # core/util.py lives at the package root here
+        # the dataset / sampler classes around AudioLoader are out of scope; several
+        # reference test modules import the name at module level without every test using it
+        self.had_ds = hasattr(A.data.datasets, "AudioDataset")
+        if not self.had_ds:
+            A.data.datasets.AudioDataset = _out_of_scope("AudioDataset")
+        # The tests name "tests/audio/*.csv" relative to the repository root.  They run in a scratch copy
+        # of that layout (the few csv manifests only), NEVER inside /root/reference: some of them write
+        # regression files next to their inputs.
+        self.cwd = os.getcwd()
+        self.tmp = tempfile.mkdtemp(prefix="ref_suite_")
+        os.makedirs(os.path.join(self.tmp, "tests", "audio"))
+        for name in os.listdir(os.path.join(REF_TESTS, "audio")):
+            if name.endswith(".csv"):
+                shutil.copy(os.path.join(REF_TESTS, "audio", name), os.path.join(self.tmp, "tests", "audio", name))
+        os.chdir(self.tmp)
+        # file output is out of scope; the regression recordings these calls would be
+        # compared with are git-lfs pointers here, so "first run: write the file" is what the tests take
+        self.orig_write = A.AudioSignal.__dict__.get("write")
+        A.AudioSignal.write = lambda self_, path: self_
+        # FFMPEGMixin.ffmpeg_loudness shells out to ffmpeg's ebur128 filter (out of scope); the tests only
+        # use it to fill metadata["loudness"], which the package's own BS.1770 meter supplies here
+        self.had_ffl = "ffmpeg_loudness" in A.AudioSignal.__dict__
+        if not self.had_ffl:
+            A.AudioSignal.ffmpeg_loudness = lambda self_, quiet=True: self_.loudness()
+        for path, (c, s, r, kind) in _RECORDINGS.items():
+            A.util._memory_audio[path] = (_synthetic(kind, c, s, r, seed=len(path)), r)
+        return self
+
+    def __exit__(self, *exc):
+        os.chdir(self.cwd)
+        shutil.rmtree(self.tmp, ignore_errors=True)
+        if not self.had_ffl:
+            del A.AudioSignal.ffmpeg_loudness
+        if self.orig_write is not None:
+            A.AudioSignal.write = self.orig_write
+        else:
+            del A.AudioSignal.write
+        for path in _RECORDINGS:
+            A.util._memory_audio.pop(path, None)
+        if not self.had_ds:
+            del A.data.datasets.AudioDataset
+        for k in [k for k in sys.modules if k == "audiotools" or k.startswith("audiotools.")]:
+            del sys.modules[k]
+        sys.modules.update(self.saved)
+        return False
+
+
+def _load(relpath):
+    path = os.path.join(REF_TESTS, relpath)
+    spec = importlib.util.spec_from_file_location("ref_" + relpath.replace("/", "_")[:-3], path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode, old = True, sys.dont_write_bytecode      # never write into /root/reference
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.dont_write_bytecode = old
+    return mod
+
+
+def _param_sets(fn):
+    """Argument dicts from the function's own @pytest.mark.parametrize marks (cartesian product)."""
+    axes = []
+    for mark in getattr(fn, "pytestmark", []):
+        if mark.name != "parametrize":
+            continue
+        names, values = mark.args[0], mark.args[1]
+        names = [n.strip() for n in names.split(",")] if isinstance(names, str) else list(names)
+        rows = [dict(zip(names, v if len(names) > 1 else (v,))) for v in values]
+        axes.append(rows)
+    out = []
+    for combo in itertools.product(*axes) if axes else [()]:
+        d = {}
+        for part in combo:
+            d.update(part)
+        out.append(d)
+    return out
+
+
+# reference test module -> test functions run here (the others: see SKIPPED)
+RUN = {
+    "core/test_audio_signal.py": ["test_copy_and_clone", "test_arithmetic", "test_equality",
+                                  "test_indexing", "test_zeros", "test_waves", "test_zero_pad", "test_zero_pad_to",
+                                  "test_truncate", "test_trim", "test_to_from_ops", "test_device", "test_stft",
+                                  "test_log_magnitude", "test_mel_spectrogram", "test_mfcc", "test_to_mono", "test_float",
+                                  "test_resample", "test_batching"],
+    "core/test_util.py": ["test_check_random_state", "test_seed", "test_hz_to_bin", "test_prepare_batch", "test_sample_dist",
+                          "test_collate"],
+    "core/test_grad.py": ["test_batch_grad"],
+    "core/test_loudness.py": ["test_loudness_short", "test_batch_loudness", "test_fir_accuracy"],
+    "data/test_transforms.py": ["test_transform", "test_compose_basic", "test_compose_with_duplicate_transforms",
+                                "test_nested_compose", "test_compose_filtering", "test_sequential_compose", "test_choose_basic",
+                                "test_choose_weighted", "test_choose_with_compose", "test_repeat", "test_masking",
+                                "test_nested_masking", "test_smoothing_edge_case", "test_global_volume_norm"],
+    "metrics/test_spectral.py": None,
+    "metrics/test_distance.py": None,
+    "core/test_dsp.py": ["test_overlap_add", "test_inplace_overlap_add", "test_low_pass", "test_high_pass",
+                         "test_mask_frequencies", "test_mask_timesteps", "test_shift_phase", "test_corrupt_phase"],
+    "core/test_effects.py": ["test_normalize", "test_volume_change", "test_mix", "test_convolve", "test_mel_filterbank",
+                             "test_equalizer", "test_clip_distortion", "test_quantization", "test_mulaw_quantization",
+                             "test_impulse_response_augmentation", "test_apply_ir", "test_ensure_max_of_audio"],
+}
+SKIPPED = {
+    "core/test_audio_signal.py::test_io": "writes and re-reads audio files",
+    "core/test_audio_signal.py::test_salient_excerpt": "writes a wav with soundfile and reads it back",
+    "core/test_util.py::test_find_audio / test_chdir": "file-system helpers over the reference's own tree",
+    "core/test_grad.py::test_audio_grad": "its op list includes apply_codec (ffmpeg codecs, out of scope)",
+    "core/test_loudness.py (all but three)": "soundfile + the ITU-R BS.2217 recordings (git-lfs pointers here); "
+                                             "tests/test_leaf_pins.py holds the EBU Tech 3341 known answers instead",
+    "data/test_datasets.py": "AudioDataset / ConcatDataset / samplers are out of scope (SURVEY.md 2.1)",
+    "core/test_dsp.py::test_preemphasis": "calls specshow() (display mixin, out of scope); preemphasis itself: tests/test_api_parity.py",
+    "core/test_effects.py::test_pipeline": "writes / reads audio files",
+    "core/test_effects.py::test_codec": "ffmpeg codec round trip (apply_codec is out of scope)",
+    "core/test_effects.py::test_pitch_shift": "sox effects chain of the reference (pitch_shift here is a phase vocoder: tests/test_stretch.py)",
+    "core/test_effects.py::test_time_stretch": "sox effects chain of the reference",
+}
+
+def _functions(module, names):
+    if names is not None:
+        return names
+    import re
+    src = open(os.path.join(REF_TESTS, module)).read() if os.path.isdir(REF_TESTS) else ""
+    return re.findall(r"^def (test_\w+)", src, flags=re.M)
+
+
+CASES = [(m, f) for m, fs in RUN.items() for f in _functions(m, fs)]
+
+
+@pytest.mark.parametrize("module,func", CASES, ids=[f"{m}::{f}" for m, f in CASES])
+def test_reference_test_function(module, func):
+    torch.manual_seed(0)
+    np.random.seed(0)
+    with _Aliased():
+        mod = _load(module)
+        fn = getattr(mod, func)
+        for kwargs in _param_sets(fn):
+            # the reference test enumerates dir(transforms); this package's module also holds two
+            # private base classes (_Recipe, _SpectralRecipe) that are not part of the API
+            if str(kwargs.get("transform_name", "")).startswith("_"):
+                continue
+            fn(**kwargs)
