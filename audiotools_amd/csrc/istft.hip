@@ -24,6 +24,7 @@
 #include "at_common.h"
 #include "fft_wave.h"
 #include "generic_fft.h"
+#include <type_traits>
 
 namespace {
 
@@ -150,6 +151,7 @@ struct IstftFusedArgs {
   const float* window;    // (N)
   const float2* tw;       // (N)
   const float* inv_env;   // ((n_frames-1)*hop + N): 1 / sum_f w^2, 0 where the envelope vanishes
+  float* dump;            // 1024 floats behind the envelope table: per-lane, per-q sink of edge-step pair stores (never read)
   float* out;             // (rows, length)
   int64_t rows;
   int64_t length;
@@ -213,6 +215,7 @@ template <int M, int SH /* hop = 2 L SH */, bool ADJ, bool MELB = false>
 __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const IstftFusedArgs A) {
   using P = Plan<M>;
   constexpr int L = P::L, FW = P::FW, N = 2 * M, HOP = 2 * L * SH, R = N / HOP;
+  constexpr bool DUMP = !ADJ;   // the inverse transform has a workspace (envelope table + dump slots behind it)
   __shared__ float2 lds[4 * WAVE_LDS_SLOTS];
   __shared__ float2 s_win2[M];
   __shared__ float2 s_twf[M];                                     // fold twiddles (cos, -sin)(2 pi k / N), k < M
@@ -294,9 +297,16 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     return live;
   };
   bool live_nxt = issue_loads(h0 - (R - 1));
-  // every slot runs the same trip count; frames outside [lead, lead + n_x) are all-zero
-  for (int i = 0; i < A.run + R - 1; ++i) {
-    const int f = h0 - (R - 1) + i;          // virtual frame added in this step = segment finished
+  // One step = one virtual frame added = one segment finished.  Two things in it are shaped by the memory
+  // pipeline rather than by the arithmetic (vmcnt retires IN ORDER, and the compiler can only count memory
+  // operations that are issued on every path; profiles/r03_notes.md):
+  //  * the envelope loads are issued BEFORE the spectrum prefetch of the next frame: the stores of this step
+  //    need them, and behind the prefetch they forced all 17 prefetch loads to complete before the first store;
+  //  * every path issues exactly SH pair stores (edge steps redirect pairs outside the row to a dump slot of
+  //    the workspace instead of branching around them) and the first step is peeled, so both edges of the loop
+  //    carry "prefetch loads, then SH stores": the loop head waits with vmcnt(SH + ...) for the loads only.
+  //    With guarded stores the head was s_waitcnt vmcnt(0): the previous frame's stores drained every frame.
+  auto step = [&](int f) __attribute__((always_inline)) {
     const bool live = live_nxt;
     if constexpr (MELB) {
       // dL/dmel row of this frame -> the frame slot's slab (free between frames), then per bin
@@ -338,9 +348,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
       const float dr = xk.x - xm.x, di = xk.y + xm.y;
       a[q] = make_float2(sr - s * dr - c * di, -(si + c * dr - s * di));
     }
-    live_nxt = issue_loads(f + 1);
-    // reciprocal envelope of the segment this step finishes (table is L2 resident); loaded here,
-    // far ahead of the stores that use it
+    // reciprocal envelope of the segment this step finishes: registers (interior) or the L2-resident table
     float2 env[SH];
     if constexpr (ADJ) {
 #pragma unroll
@@ -351,6 +359,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
 #pragma unroll
       for (int q = 0; q < SH; ++q) env[q] = e2[t + L * q];
     }
+    live_nxt = issue_loads(f + 1);
     // The last pass of the transform runs in place on registers (pass_compute_regs): its outputs
     // are the points t + L q of this thread, the layout the register window needs -- no slab
     // round trip behind it.
@@ -397,20 +406,44 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     // Interior segments (all lanes of the wave inside [0, length)) take straight-line stores; the
     // row edges go through the guarded path.
     {
-      const bool emit = unit_ok && f >= h0 && f < h1;
       const int p_seg = f * HOP - (ADJ ? 0 : N / 2);           // first output sample of the segment
-      const bool inside = emit && p_seg >= 0 && p_seg + HOP <= len;
-      if (__all(inside)) {
-#pragma unroll
-        for (int q = 0; q < SH; ++q) {
-          at::stg2_a4<AT_NT_ISTFT_ST != 0>(orow + p_seg + 2 * (t + L * q), acc[q].x * env[q].x, acc[q].y * env[q].y);
-        }
-      } else if (emit) {
+      const bool emit = unit_ok && f >= h0 && f < h1;
+      if constexpr (DUMP) {
+        // ONE straight-line sequence of SH pair stores on every path (an if / else between a fast and a guarded
+        // form is turned into two flag-guarded regions by the structurizer, and the waitcnt pass then sees a
+        // path with no store at all): pairs that are not entirely inside the row go to this lane's dump slot.
+        bool cut = false;
 #pragma unroll
         for (int q = 0; q < SH; ++q) {
           const int p = p_seg + 2 * (t + L * q);
-          if (p >= 0 && p < len) orow[p] = acc[q].x * env[q].x;
-          if (p + 1 >= 0 && p + 1 < len) orow[p + 1] = acc[q].y * env[q].y;
+          const bool full = emit && p >= 0 && p + 1 < len;
+          cut |= emit && !full && p + 1 >= 0 && p < len;
+          float* dst = full ? orow + p : A.dump + 128 * q + 2 * lane;   // one slot per q: stores to one address would be merged
+          at::stg2_a4<AT_NT_ISTFT_ST != 0>(dst, acc[q].x * env[q].x, acc[q].y * env[q].y);
+        }
+        if (__any(cut)) {   // a pair cut by the end of an odd-length row (or by its start): element stores
+#pragma unroll
+          for (int q = 0; q < SH; ++q) {
+            const int p = p_seg + 2 * (t + L * q);
+            if (!emit || (p >= 0 && p + 1 < len)) continue;
+            if (p >= 0 && p < len) orow[p] = acc[q].x * env[q].x;
+            if (p + 1 >= 0 && p + 1 < len) orow[p + 1] = acc[q].y * env[q].y;
+          }
+        }
+      } else {
+        const bool inside = emit && p_seg >= 0 && p_seg + HOP <= len;
+        if (__all(inside)) {
+#pragma unroll
+          for (int q = 0; q < SH; ++q) {
+            at::stg2_a4<AT_NT_ISTFT_ST != 0>(orow + p_seg + 2 * (t + L * q), acc[q].x * env[q].x, acc[q].y * env[q].y);
+          }
+        } else if (emit) {
+#pragma unroll
+          for (int q = 0; q < SH; ++q) {
+            const int p = p_seg + 2 * (t + L * q);
+            if (p >= 0 && p < len) orow[p] = acc[q].x * env[q].x;
+            if (p + 1 >= 0 && p + 1 < len) orow[p + 1] = acc[q].y * env[q].y;
+          }
         }
       }
     }
@@ -418,7 +451,13 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     for (int q = 0; q < 16 - SH; ++q) acc[q] = acc[q + SH];
 #pragma unroll
     for (int q = 16 - SH; q < 16; ++q) acc[q] = make_float2(0.f, 0.f);
-  }
+  };
+
+  // every slot runs the same trip count; frames outside [lead, lead + n_x) are all-zero
+  const int total = A.run + R - 1;
+  const int f_first = h0 - (R - 1);            // virtual frame of step 0
+  step(f_first);   // peeled (see above)
+  for (int i = 1; i < total; ++i) step(f_first + i);
 }
 
 template <int M, int SH, bool ADJ, bool MELB = false>
@@ -532,7 +571,7 @@ extern "C" {
 int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft, int hop) {
   if (rows < 0 || n_frames <= 0 || n_fft <= 0 || hop <= 0) return AT_ERR_INVALID;
   const bool fused_size = n_fft >= 32 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0;
-  if (fused_size && fused_shift(n_fft, hop)) return ((n_frames - 1) * hop + n_fft) * 4;
+  if (fused_size && fused_shift(n_fft, hop)) return ((n_frames - 1) * hop + n_fft + 1024) * 4;   // envelope table + dump slots
   return rows * n_frames * (int64_t)n_fft * 4;
 }
 
@@ -573,6 +612,7 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
     IstftFusedArgs F;
     F.X = reinterpret_cast<const float2*>(X); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
     F.inv_env = reinterpret_cast<const float*>(workspace); F.out = out; F.rows = rows; F.length = length;
+    F.dump = reinterpret_cast<float*>(workspace) + ((n_frames - 1) * hop + n_fft);
     F.n_x = (int)n_x; F.lead = lead; F.n_frames = (int)n_frames;
     F.gmel = nullptr; F.bin_bands = nullptr; F.bin_w = nullptr; F.n_mels = 0;
     plan_runs(F, rows, n_fft, hop);
@@ -631,7 +671,7 @@ int at_stft_adjoint_f32(const float* G, int64_t rows, int64_t n_frames, const fl
   if (rows == 0) return AT_OK;
   IstftFusedArgs F;
   F.X = reinterpret_cast<const float2*>(G); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
-  F.inv_env = nullptr; F.out = out; F.rows = rows; F.length = out_len;
+  F.inv_env = nullptr; F.dump = nullptr; F.out = out; F.rows = rows; F.length = out_len;
   F.n_x = (int)n_frames; F.lead = 0; F.n_frames = (int)n_frames;
   F.gmel = nullptr; F.bin_bands = nullptr; F.bin_w = nullptr; F.n_mels = 0;
   plan_runs(F, rows, n_fft, hop);
@@ -655,7 +695,7 @@ int at_stft_mel_adjoint_f32(const float* X, const float* gmel, const int* bin_ba
   if (n_mels > 8 * (n_fft / 32) || n_mels >= 0xffff || n_frames >= (1LL << 31) / n_fft) return AT_ERR_UNSUPPORTED;
   IstftFusedArgs F;
   F.X = reinterpret_cast<const float2*>(X); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
-  F.inv_env = nullptr; F.out = out; F.rows = rows; F.length = out_len;
+  F.inv_env = nullptr; F.dump = nullptr; F.out = out; F.rows = rows; F.length = out_len;
   F.n_x = (int)n_frames; F.lead = 0; F.n_frames = (int)n_frames;
   F.gmel = gmel; F.bin_bands = bin_bands; F.bin_w = reinterpret_cast<const float2*>(bin_w); F.n_mels = n_mels;
   plan_runs(F, rows, n_fft, hop);

@@ -351,6 +351,293 @@ __global__ __launch_bounds__(256, AT_LUFS_WPS) void kweight_hop_energy(const Luf
   }
 }
 
+// ---- kweight_hop_energy_dma: the hop-energy path for 16-byte-aligned rows -------------------------
+// Same arithmetic as kweight_hop_energy<NS, true, false> (bit-identical hop energies are NOT required,
+// the per-piece sums are formed in a different order), restructured around the three things the ISA of
+// that kernel spends outside the recursions (profiles/r02_notes.md, r03_notes.md):
+//  * all segment / hop bookkeeping is wave-uniform and lives in SGPRs (the wave index comes from
+//    readfirstlane): no 64-bit vector compares, no exec-mask branches, no division in the loop;
+//  * hop energies are formed DIRECTLY per piece: every lane sums its 32 squares once; a cut (a hop
+//    boundary, or the end of the data) at offset o inside lane c splits that lane's chunk into the
+//    squares below and above o with wave-uniform branches per group of four samples, and the piece
+//    sums are  [lanes strictly between two cuts: full sums] + [the two boundary lanes: partial sums]
+//    -- 32 + ~36 FMAs per cut instead of two masked 32-sample passes with per-sample selects.  No
+//    piece is ever obtained as a difference of two sums (a quiet hop behind a loud one keeps its
+//    relative accuracy: it decides the -70 LUFS gate);
+//  * the next tile is prefetched by LDS-DMA (global_load_lds_dwordx4) straight into the wave's 8 KB
+//    tile instead of 8 float4 staging registers: 32 VGPRs fewer, 4 waves per SIMD instead of 3.
+//    DMA piece i / lane l writes LDS slot 64 i + l (fixed by the hardware); the GLOBAL chunk each lane
+//    fetches is permuted inside its 128-byte line (k = (l & 7) ^ ((c >> 1) & 7)), so HBM access stays
+//    line-coalesced and lane c's k-th float4 sits at slot 8 c + (k ^ ((c >> 1) & 7)): the 16 lanes a
+//    ds_read_b128 serves per cycle hit 16 distinct bank groups (a plain layout is 8-way conflicted).
+#ifndef AT_LUFS_WPS_DMA
+#define AT_LUFS_WPS_DMA 4
+#endif
+
+// squares of the lane's chunk below / at-or-above the wave-uniform offset o (0..31)
+__device__ __forceinline__ void split_energy(const float (&v)[CHUNK], int o, float& elo, float& ehi) {
+  float lo = 0.f, hi = 0.f;
+#pragma unroll
+  for (int g = 0; g < CHUNK / 4; ++g) {
+    if (o >= 4 * g + 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lo = fmaf(v[4 * g + j], v[4 * g + j], lo);
+    } else if (o <= 4 * g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hi = fmaf(v[4 * g + j], v[4 * g + j], hi);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sq = v[4 * g + j] * v[4 * g + j];
+        if (4 * g + j < o) lo += sq; else hi += sq;
+      }
+    }
+  }
+  elo = lo; ehi = hi;
+}
+
+// One biquad stage as biquad_stage<SI>(), with the per-lane scan matrices read from the block's LDS
+// table (3 float4 per lane: q16, q32, q64, then the four in-row step matrices) instead of 12 VGPRs and
+// 16 SGPRs per stage (the SGPR file was over-subscribed: 30 spills reloaded with v_readlane per tile).
+template <int SI>
+__device__ __forceinline__ void biquad_stage_q(float (&v)[CHUNK], const LufsArgs& A, float hx1, float hx2, float& ky1,
+                                               float& ky2, const float4* __restrict__ q /* [3][64] per-lane + [4] uniform */, int lane) {
+  const Stage s = A.st[SI];
+  float x1 = hx1, x2 = hx2;
+  float y1 = 0.f, y2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CHUNK; ++i) {
+    const float xn = v[i];
+    float o = s.b2 * x2;
+    o = fmaf(s.b1, x1, o);
+    o = fmaf(s.b0, xn, o);
+    v[i] = o;
+    x2 = x1;
+    x1 = xn;
+    const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, o));
+    y2 = y1;
+    y1 = y;
+  }
+  const float4 q16 = q[lane], q32 = q[64 + lane], q64 = q[128 + lane];
+  float g1 = y1, g2 = y1 - y2;
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    float u1, u2;
+    if (step == 0) { u1 = row_shr<1>(g1); u2 = row_shr<1>(g2); }
+    if (step == 1) { u1 = row_shr<2>(g1); u2 = row_shr<2>(g2); }
+    if (step == 2) { u1 = row_shr<4>(g1); u2 = row_shr<4>(g2); }
+    if (step == 3) { u1 = row_shr<8>(g1); u2 = row_shr<8>(g2); }
+    const float4 pf = q[192 + step];   // P^(2^step), the same for every lane (LDS broadcast read)
+    const float n1 = fmaf(pf.x, u1, fmaf(pf.y, u2, g1));
+    const float n2 = fmaf(pf.z, u1, fmaf(pf.w, u2, g2));
+    g1 = n1; g2 = n2;
+  }
+  {
+    const float u1 = row_bcast15(g1), u2 = row_bcast15(g2);
+    const float n1 = fmaf(q16.x, u1, fmaf(q16.y, u2, g1));
+    const float n2 = fmaf(q16.z, u1, fmaf(q16.w, u2, g2));
+    g1 = n1; g2 = n2;
+  }
+  {
+    const float u1 = row_bcast31(g1), u2 = row_bcast31(g2);
+    const float n1 = fmaf(q32.x, u1, fmaf(q32.y, u2, g1));
+    const float n2 = fmaf(q32.z, u1, fmaf(q32.w, u2, g2));
+    g1 = n1; g2 = n2;
+  }
+  const float f1 = fmaf(q64.x, ky1, fmaf(q64.y, ky2, g1));
+  const float f2 = fmaf(q64.z, ky1, fmaf(q64.w, ky2, g2));
+  y1 = wave_shr1(f1, ky1);
+  y2 = y1 - wave_shr1(f2, ky2);
+  ky1 = lane63(f1);
+  ky2 = lane63(f2);
+  if (s.g == 1.0f) {
+#pragma unroll
+    for (int i = 0; i < CHUNK; ++i) {
+      const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
+      v[i] = y;
+      y2 = y1;
+      y1 = y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < CHUNK; ++i) {
+      const float y = fmaf(-s.a1, y1, fmaf(-s.a2, y2, v[i]));
+      v[i] = s.g * y;
+      y2 = y1;
+      y1 = y;
+    }
+  }
+}
+
+// Sample indices are 32-bit here (the launcher routes rows of 2^31 - 2^22 samples or more to the
+// register-staged kernel).
+template <int NS>
+__global__ __launch_bounds__(256, AT_LUFS_WPS_DMA) void kweight_hop_energy_dma(const LufsArgs A) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * SB];
+  __shared__ __attribute__((aligned(16))) float4 qtab[NS][3 * 64 + 4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  if (wid >= A.rows * (int64_t)A.segs_per_row) return;   // wave-uniform
+  const int64_t row = wid / A.segs_per_row;
+  const int seg = (int)(wid - row * A.segs_per_row);
+  float* tile = lds + wave * SB;
+
+  const int T = (int)A.T, S = A.S;
+  const int h0 = seg * A.seg_hops;
+  const int h1 = min(h0 + A.seg_hops, A.H_data);
+  const int n0 = h0 * S;
+  const int n1 = (int)min((int64_t)h1 * S, A.T);
+  int start = n0 - A.warm;
+  if (start < 0) start = 0;
+  start &= ~3;
+  const float* __restrict__ xr = A.x + row * A.T;
+  double* __restrict__ Erow = A.E + row * A.H;
+
+  // per-lane scan matrices -> LDS.  Every wave of the block writes the same values (no block barrier:
+  // waves past the end of the grid have already left).
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    auto power = [&](int e) {
+      M2 acc = {1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        if (e & (1 << i)) {
+          const M2 p = {A.Pp[s][i][0], A.Pp[s][i][1], A.Pp[s][i][2], A.Pp[s][i][3]};
+          acc = mmul(acc, p);
+        }
+      }
+      return make_float4((float)acc.a, (float)acc.b, (float)acc.c, (float)acc.d);
+    };
+    qtab[s][lane] = power((lane & 15) + 1);
+    qtab[s][64 + lane] = power((lane & 31) + 1);
+    qtab[s][128 + lane] = power(lane + 1);
+    if (lane < 4) qtab[s][192 + lane] = make_float4(A.Pf[s][lane][0], A.Pf[s][lane][1], A.Pf[s][lane][2], A.Pf[s][lane][3]);
+  }
+  at::wave_sync();
+  float ky1[NS], ky2[NS], kx1[NS], kx2[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { ky1[s] = ky2[s] = 0.f; kx1[s] = kx2[s] = 0.f; }
+
+  // DMA: piece i / lane l lands in LDS slot 64 i + l and fetches the chunk k = (l & 7) ^ ((c >> 1) & 7) of
+  // lane-row c = 8 i + (l >> 3), i.e. float offset 256 i + [32 (l >> 3) + 4 k0] ^ (16 (i & 1)) with
+  // k0 = (l & 7) ^ (l >> 4): two per-lane offsets, the piece index goes into the instruction offset
+  // (which moves the global AND the LDS address).
+  const int offA = 32 * (lane >> 3) + 4 * ((lane & 7) ^ (lane >> 4));
+  const int offB = offA ^ 16;
+  const int rd_base = lane * CHUNK + 4 * ((lane >> 1) & 7);   // the reader's float4 k sits at rd_base ^ (4 k)
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_tile = [&](int sb) __attribute__((always_inline)) {
+    if (sb + SB <= T) {                                     // wave-uniform
+      const float* gA = xr + sb + offA;
+      const float* gB = xr + sb + offB;
+      __builtin_amdgcn_global_load_lds((gptr_t)gA, (lptr_t)tile, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gB, (lptr_t)tile, 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gA, (lptr_t)tile, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)gB, (lptr_t)tile, 16, 3072, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gA + 1024), (lptr_t)(tile + 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gB + 1024), (lptr_t)(tile + 1024), 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gA + 1024), (lptr_t)(tile + 1024), 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gB + 1024), (lptr_t)(tile + 1024), 16, 3072, 0);
+    } else {                                                // last tile of a row: chunk addresses clamped into the row
+#pragma unroll 1
+      for (int i = 0; i < 8; ++i) {
+        int off = sb + 256 * i + ((i & 1) ? offB : offA);
+        off = off > T - 4 ? T - 4 : off;
+        __builtin_amdgcn_global_load_lds((gptr_t)(xr + off), (lptr_t)(tile + 256 * i), 16, 0, 0);
+      }
+    }
+  };
+
+  // hop tracking: h = hop that contains the current position, hb = first sample of hop h + 1
+  int h = start / S;
+  int hb = (h + 1) * S;                  // < T + S: the launcher keeps T below 2^31 - 2^22
+  double acc = 0.0;
+  bool acc_valid = false;
+
+  issue_tile(start);
+  for (int sb = start; sb < n1; sb += SB) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tile has landed (LDS-DMA is covered by vmcnt only)
+    at::wave_sync();
+    float v[CHUNK];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float4 q = *reinterpret_cast<const float4*>(tile + (rd_base ^ (4 * k)));
+      v[4 * k + 0] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // values are in registers before the tile is overwritten
+    at::wave_sync();
+    if (sb + SB < n1) issue_tile(sb + SB);
+    if (sb + SB > T) {                                       // last tile of the row: samples past the end are zeros
+      const int base = sb + lane * CHUNK;
+#pragma unroll
+      for (int i = 0; i < CHUNK; ++i) v[i] = base + i < T ? v[i] : 0.f;
+    }
+
+#define AT_STAGE(SI)                                                     \
+    if constexpr (SI < NS) {                                             \
+      const float hx1 = wave_shr1(v[CHUNK - 1], kx1[SI]);                \
+      const float hx2 = wave_shr1(v[CHUNK - 2], kx2[SI]);                \
+      kx1[SI] = lane63(v[CHUNK - 1]);                                    \
+      kx2[SI] = lane63(v[CHUNK - 2]);                                    \
+      biquad_stage_q<SI>(v, A, hx1, hx2, ky1[SI], ky2[SI], &qtab[SI][0], lane);   \
+    }
+    AT_STAGE(0) AT_STAGE(1) AT_STAGE(2) AT_STAGE(3)
+#undef AT_STAGE
+
+    // ---- hop energies of this super-block, piece by piece (all control flow is wave-uniform)
+    float e_full = 0.f;
+#pragma unroll
+    for (int i = 0; i < CHUNK; ++i) e_full = fmaf(v[i], v[i], e_full);
+    const int sb_end = sb + SB;
+    int c_prev = -1, o_prev = 0;
+    float carry = 0.f;
+    while (true) {
+      const int cut = hb < n1 ? hb : n1;
+      if (cut >= sb_end) {                                   // the piece runs to the end of the block
+        if (h >= h0) {
+          const float contrib = (lane > c_prev ? e_full : 0.f) + carry;
+          acc += (double)wave_sum_dpp(contrib);
+          acc_valid = true;
+        }
+        break;
+      }
+      const int p = cut - sb;
+      const int c = p >> 5, o = p & 31;
+      float elo, ehi;
+      split_energy(v, o, elo, ehi);
+      if (h >= h0) {
+        float contrib;
+        if (c != c_prev) {
+          contrib = carry + ((lane > c_prev && lane < c) ? e_full : 0.f) + (lane == c ? elo : 0.f);
+        } else {
+          // two cuts inside one lane's chunk: only the end of the data can follow a hop boundary this
+          // closely (hop boundaries are >= 100 ms apart).  Sum the samples [o_prev, o) of that lane directly.
+          float mid = 0.f;
+#pragma unroll
+          for (int i = 0; i < CHUNK; ++i) mid += (i >= o_prev && i < o) ? v[i] * v[i] : 0.f;
+          contrib = lane == c ? mid : 0.f;
+        }
+        acc += (double)wave_sum_dpp(contrib);
+        acc_valid = true;
+      }
+      if (cut == n1) break;                                  // end of this segment's data (the outer loop ends too)
+      if (acc_valid) {
+        if (lane == 0) Erow[h] = acc;
+        acc = 0.0;
+        acc_valid = false;
+      }
+      ++h;
+      hb += S;
+      carry = lane == c ? ehi : 0.f;
+      c_prev = c;
+      o_prev = o;
+    }
+  }
+  if (acc_valid && lane == 0) Erow[h] = acc;
+}
+
 // General block energies from a filtered signal (K not a multiple of S): one wave per (row, block).
 __global__ __launch_bounds__(256) void block_energy_kernel(const float* __restrict__ y, double* __restrict__ Z,
                                                             int64_t rows, int64_t T, int K, int S, int nblk) {
@@ -522,6 +809,12 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
     A.y = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up(rows * (int64_t)nblk * 8, 256));
   }
   A.E = E; A.H = H;
+  // kernel choice: the LDS-DMA kernel needs 16-byte aligned rows and the hop path (AT_LUFS_KERNEL=1 forces the
+  // register-staged kernel: A/B measurements, tools/lufsab.py; re-read per call under AT_LUFS_TUNE=1)
+  static const int tune_each_call = at::env_int_once("AT_LUFS_TUNE", 0);
+  static int kernel_sel = at::env_int_once("AT_LUFS_KERNEL", 0);
+  if (tune_each_call) kernel_sel = at::env_int_once("AT_LUFS_KERNEL", 0);
+  const bool use_dma = hop_path && A.vec4 && kernel_sel != 1 && T >= 4 && T < (1LL << 31) - (1LL << 22) && S < (1 << 22);
   // segmentation in units of S samples ("hops") even on the general path
   const int64_t H_data = (T + S - 1) / S;
   A.H_data = (int)H_data;
@@ -531,7 +824,7 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
   int64_t seg;
   {
     const int n_cu = at::device_cu_count();
-    const int64_t slots = (int64_t)n_cu * 4 * AT_LUFS_WPS;
+    const int64_t slots = (int64_t)n_cu * 4 * (use_dma ? AT_LUFS_WPS_DMA : AT_LUFS_WPS);
     int64_t best_s = 1;
     double best_cost = 1e300;
     for (int64_t sp = 1; sp <= H_data && sp <= 4096; ++sp) {
@@ -564,8 +857,17 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
       else hipLaunchKernelGGL((kweight_hop_energy<NSV, false, true>), grid, block, 0, st, A);         \
     }                                                                                              \
     break;
-  switch (nstage) {
-    AT_LAUNCH_NS(1) AT_LAUNCH_NS(2) AT_LAUNCH_NS(3) AT_LAUNCH_NS(4)
+  if (use_dma) {
+    switch (nstage) {
+      case 1: hipLaunchKernelGGL((kweight_hop_energy_dma<1>), grid, block, 0, st, A); break;
+      case 2: hipLaunchKernelGGL((kweight_hop_energy_dma<2>), grid, block, 0, st, A); break;
+      case 3: hipLaunchKernelGGL((kweight_hop_energy_dma<3>), grid, block, 0, st, A); break;
+      case 4: hipLaunchKernelGGL((kweight_hop_energy_dma<4>), grid, block, 0, st, A); break;
+    }
+  } else {
+    switch (nstage) {
+      AT_LAUNCH_NS(1) AT_LAUNCH_NS(2) AT_LAUNCH_NS(3) AT_LAUNCH_NS(4)
+    }
   }
 #undef AT_LAUNCH_NS
   if (!hop_path) {

@@ -496,9 +496,20 @@ __device__ __forceinline__ float2 ld2(const float2* p) {
   }
 }
 
-template <int NR /* mel rounds of 64 units; 0 = no mel */, int POL = 0>
+// VAR bit 0: STATIC STORE COUNT.  The 4 sample loads of the next frame are issued before this frame's stores,
+//   and vmcnt retires in order: the wait for them at the top of the next frame is  vmcnt(#stores behind
+//   them).  The compiler can only count stores that are issued on every path; the Nyquist store under
+//   `if (lane == 0)` and the four band stores under `if (lane heads a band)` sit behind exec-mask branches,
+//   so it assumed 16 stores where 17 (21 with mel) are in flight, and every frame began by waiting for the
+//   acknowledgement of the first 1 (5) stores of the previous frame (ISA: s_waitcnt vmcnt(19..16) at the
+//   loop head, profiles/r03_notes.md).  With VAR & 1 the Nyquist bin is stored by all lanes (same
+//   address, lane 0's value) and the band sums are gathered in the wave's LDS slab and stored by two
+//   unconditional, coalesced instructions: every store is counted, the loop head waits for the loads only.
+template <int NR /* mel rounds of 64 units; 0 = no mel */, int POL = 0, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   constexpr bool MEL = NR > 0;
+  constexpr bool STATIC_STORES = (VAR & 1) != 0;
+  constexpr int MELOUT_OFF = 1312;   // floats: band sums of the frame, behind the 65 x 20 magnitude rows of the slab
   constexpr bool PRIO = (POL & 8) != 0;
   constexpr int M = 1024, L = 64, N = 2048, NW = 4, SH = 4;
   constexpr int WROW = 36;  // floats per window row (32 used): conflict-free ds_read_b128
@@ -564,6 +575,9 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       m_st[r] = (fl & 16) ? (fl >> 8) : -1;
     }
   }
+  // STATIC_STORES: the bands this lane stores (lane, 64 + lane, clamped to the last band: duplicates of it are harmless)
+  const int gb0 = (MEL && STATIC_STORES) ? min(lane, A.n_mels - 1) : 0;
+  const int gb1 = (MEL && STATIC_STORES) ? min(64 + lane, A.n_mels - 1) : 0;
 
   const int Ti = (int)A.T;
   const int n_out = (int)A.n_out;
@@ -725,15 +739,20 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
         magbuf[k0 + 192 + 4 * ((k0 + 192) >> 4)] = cabs_fast(rcA[m]);
       }
     }
-    if (t0) {
-      st2<POL>(orow + M, nyq);
-      if constexpr (MEL) magbuf[M + 4 * (M >> 4)] = fabsf(nyq.x);
+    if constexpr (STATIC_STORES) {
+      const float nyq0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nyq.x), 0));
+      st2<POL>(orow + M, make_float2(nyq0, 0.f));   // every lane, one address: counted on every path
+      // last magnitude row: the Nyquist bin and 15 zero columns (see the generic kernel)
+      if constexpr (MEL) { if (t < 16) magbuf[(M / 16) * MAG_ROW + t] = t0 ? fabsf(nyq0) : 0.f; }
+    } else {
+      if (t0) {
+        st2<POL>(orow + M, nyq);
+        if constexpr (MEL) magbuf[M + 4 * (M >> 4)] = fabsf(nyq.x);
+      }
+      if constexpr (MEL) { if (t >= 1 && t < 16) magbuf[(M / 16) * MAG_ROW + t] = 0.f; }
     }
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     if constexpr (MEL) {
-      // the last magnitude row holds only the Nyquist bin: zero its other 15 columns (see the
-      // generic kernel)
-      if (t >= 1 && t < 16) magbuf[(M / 16) * MAG_ROW + t] = 0.f;
       wave_sync();
       float* mrow = A.mel + ((int64_t)row * n_out + fo) * A.n_mels;
       // Unit dot products as packed FMAs on the float4 rows as they come out of LDS (two
@@ -768,7 +787,11 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
         sh = dpp_row_shl<2>(acc); acc = fmaf(sh, (float)((f >> 8) & 0xffu), acc);
         sh = dpp_row_shl<4>(acc); acc = fmaf(sh, (float)((f >> 16) & 0xffu), acc);
         sh = dpp_row_shl<8>(acc); acc = fmaf(sh, (float)(f >> 24), acc);
-        if (m_st[r] >= 0) at::stg<(POL & 2) != 0>(mrow + m_st[r], acc);
+        if constexpr (STATIC_STORES) {
+          if (m_st[r] >= 0) magbuf[MELOUT_OFF + m_st[r]] = acc;
+        } else {
+          if (m_st[r] >= 0) at::stg<(POL & 2) != 0>(mrow + m_st[r], acc);
+        }
       };
       load_unit(0, 0);
       load_unit(1, 1);
@@ -785,6 +808,12 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       }
       reduce_store(acc_prev, NR - 1);
       wave_sync();
+      if constexpr (STATIC_STORES) {
+        const float b0 = magbuf[MELOUT_OFF + gb0], b1 = magbuf[MELOUT_OFF + gb1];
+        at::stg<(POL & 2) != 0>(mrow + gb0, b0);
+        at::stg<(POL & 2) != 0>(mrow + gb1, b1);
+        wave_sync();
+      }
     }
     return have_nxt;
   };
@@ -853,10 +882,10 @@ static int balanced_run(int64_t total_groups, int64_t blocks, int nw, int run_ma
   return (int)run;
 }
 
-template <int NR, int POL = 0>
+template <int NR, int POL = 0, int VAR = 0>
 int launch_v2(const StftArgs& A, int n_cu, hipStream_t stream) {
   constexpr int NW = 4;
-  auto kern = stft_mel_kernel_v2<NR, POL>;
+  auto kern = stft_mel_kernel_v2<NR, POL, VAR>;
   const size_t bytes = v2_lds_floats(A.n_units) * 4;
   if (bytes > 160 * 1024) return AT_ERR_UNSUPPORTED;
   int e = at::allow_big_lds(reinterpret_cast<const void*>(kern));
@@ -1086,23 +1115,18 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   const int n_cu = device_cu_count();
   if (use_v2 && M == 1024 && vec2 && A.reuse_shift == 4 && A.debug == 0 && T >= 2 * 2048) {
     // the reference's default transform at 44.1 / 48 kHz: n_fft 2048, hop 512, no match_stride
+    // flags bit 0: nt spectrum stores; bit 5: the round-2 store code (conditional Nyquist / band stores) instead
+    // of the static-store-count variant.  The gathered band stores cover n_mels <= 128.
+    const bool stat = !(A.flags & 32) && (A.n_units == 0 || A.n_mels <= 128);
     switch (A.n_units / 64) {
-#define AT_V2_POL(NRV)                                    \
-  switch (A.flags & 15) {                                 \
-    case 1: return launch_v2<NRV, 1>(A, n_cu, s);         \
-    case 3: return launch_v2<NRV, 3>(A, n_cu, s);         \
-    case 4: return launch_v2<NRV, 4>(A, n_cu, s);         \
-    case 5: return launch_v2<NRV, 5>(A, n_cu, s);         \
-    case 8: return launch_v2<NRV, 8>(A, n_cu, s);         \
-    case 9: return launch_v2<NRV, 9>(A, n_cu, s);         \
-    case 13: return launch_v2<NRV, 13>(A, n_cu, s);       \
-    default: return launch_v2<NRV>(A, n_cu, s);           \
-  }
+#define AT_V2_POL(NRV)                                                                   \
+  if (stat) return (A.flags & 1) ? launch_v2<NRV, 1, 1>(A, n_cu, s) : launch_v2<NRV, 0, 1>(A, n_cu, s); \
+  return (A.flags & 1) ? launch_v2<NRV, 1, 0>(A, n_cu, s) : launch_v2<NRV, 0, 0>(A, n_cu, s);
       case 0: AT_V2_POL(0)
-      case 2: return launch_v2<2>(A, n_cu, s);
+      case 2: return stat ? launch_v2<2, 0, 1>(A, n_cu, s) : launch_v2<2, 0, 0>(A, n_cu, s);
       case 4: AT_V2_POL(4)
 #undef AT_V2_POL
-      case 6: return launch_v2<6>(A, n_cu, s);
+      case 6: return stat ? launch_v2<6, 0, 1>(A, n_cu, s) : launch_v2<6, 0, 0>(A, n_cu, s);
     }
   }
   switch (M) {
