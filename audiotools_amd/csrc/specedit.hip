@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256) void spec_mask_lowmag_kernel(const float2* __r
 // physically (rows, N, F): a 32 x 32 tile goes through LDS so that both sides are read / written
 // with unit stride.
 //   mode 0: Y = X * e^{i shift}                          dsp.py:354-370, transforms.py:1250-1278
-//   mode 1: Y = (X == 0) ? a * e^{i b} : X               transforms.py:1456-1536 (the holes a mask left
-//           are refilled with magnitude ~ N(0,1), phase ~ N(0,1); untouched bins keep their value)
+//   mode 1: Y = (X == 0) ? |a| * e^{i b} : X             transforms.py:1456-1536 (the holes a mask left
+//           are refilled with magnitude |N(0,1)| -- `signal.magnitude = mag; signal.phase = phase` ends with
+//           abs(mag) e^{i phase} -- and phase ~ N(0,1); untouched bins keep their value)
 __global__ __launch_bounds__(256) void spec_polar_elem_kernel(const float2* __restrict__ S, float2* __restrict__ Y, int N,
                                                               int F, const float* __restrict__ a, const float* __restrict__ b,
                                                               int mode) {
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void spec_polar_elem_kernel(const float2* __re
     if (f < F && n < N) {
       float sn, cs;
       sincosf(br[(int64_t)f * N + n], &sn, &cs);
-      const float m = mode == 1 ? ar[(int64_t)f * N + n] : 1.0f;
+      const float m = mode == 1 ? fabsf(ar[(int64_t)f * N + n]) : 1.0f;   // the phase setter re-derives |.| (audio_signal.py:1452-1453)
       v = make_float2(m * cs, m * sn);
     }
     tile[ty + 8 * r][tx] = v;      // tile[f][n]

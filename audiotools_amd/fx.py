@@ -48,6 +48,8 @@ def _as_ratio(factor: float):
     if not factor > 0:
         raise ValueError("time_stretch factor must be positive")
     fr = fractions.Fraction(float(factor)).limit_denominator(4096)
+    if fr.numerator == 0:
+        raise ValueError(f"time_stretch factor {factor} is below the smallest representable rate 1/4096")
     return fr.numerator, fr.denominator
 
 

@@ -282,7 +282,18 @@ def _workspace(nbytes: int, device):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+        while len(_ws_cache) > _WS_MAX:          # streams come and go: keep the most recent few
+            _ws_cache.pop(next(iter(_ws_cache)))
     return buf
+
+
+_WS_MAX = 8
+
+
+def release_workspaces():
+    """Drop the cached scratch buffers (the conv workspace of cfg4 is several GB): call between phases of a
+    job that no longer needs them; the next kernel call re-allocates what it needs."""
+    _ws_cache.clear()
 
 
 def integrated_loudness(audio_bct: torch.Tensor, rate: int, filter_class: str = "K-weighting",
@@ -400,8 +411,8 @@ def spec_phase_shift(X: torch.Tensor, shift: torch.Tensor):
 
 
 def spec_polar_elem(X: torch.Tensor, b: torch.Tensor, a: torch.Tensor = None):
-    """Per-element polar edit of a native spectrum: ``X * exp(1j * b)`` (``a`` None) or ``a * exp(1j * b)``
-    where ``X == 0`` and ``X`` elsewhere.  ``a`` / ``b``: float32, broadcastable to X's logical shape."""
+    """Per-element polar edit of a native spectrum: ``X * exp(1j * b)`` (``a`` None) or ``|a| * exp(1j * b)``
+    where ``X == 0`` and ``X`` elsewhere (|a|: the reference's phase setter re-derives the magnitude).  ``a`` / ``b``: float32, broadcastable to X's logical shape."""
     Y, Yr, Xr, B, C, N, F = _spec_out(X)
     shape = (B, C, F, N)
     bb = b.to(X.device, torch.float32).expand(shape).contiguous()
@@ -594,6 +605,11 @@ def fftconv(x: torch.Tensor, ir: torch.Tensor, scale: torch.Tensor = None, engin
     lib = _native.lib()
     if engine is None:
         engine = "fourstep" if longconv_enabled(T) else "rocfft"
+    if engine == "fourstep" and (x.data_ptr() % 8 or ir.data_ptr() % 8):
+        # the four-step kernels read float2: a rows == 1 view with an odd sample offset stays 4-byte aligned
+        # through .contiguous() -- realign instead of failing with AT_ERR_INVALID
+        x = x.clone() if x.data_ptr() % 8 else x
+        ir = ir.clone() if ir.data_ptr() % 8 else ir
     if engine == "fourstep":
         tb = tables.longconv_tables(T, x.device)
         need = int(lib.at_longconv_workspace_bytes(B, C, Cir, T))
@@ -631,6 +647,10 @@ def room_convolve(x: torch.Tensor, ir: torch.Tensor, shift: torch.Tensor = None,
     if scale is not None:
         scale = scale.reshape(B, Cir).to(torch.float32).contiguous()
     sh = None if shift is None else shift.reshape(B, Cir).to(torch.int64).contiguous()
+    if x.data_ptr() % 8:
+        x = x.clone()          # float2 reads (see fftconv)
+    if ir.data_ptr() % 8:
+        ir = ir.clone()
     lib = _native.lib()
     tb = tables.longconv_tables(T, x.device)
     need = int(lib.at_longconv_workspace_bytes(B, C, Cir, T))

@@ -207,8 +207,14 @@ class AudioSignal(SpectralMixin, EffectMixin, LoudnessMixin, ImpulseResponseMixi
                     for s in audio_signals:
                         n = min(s.signal_length, longest)
                         out_data[at: at + s.batch_size, :, :n] = s.audio_data[..., :n]
-                        # the reference pads every input signal in place; keep that observable effect
-                        s.audio_data = out_data[at: at + s.batch_size]
+                        at += s.batch_size
+                    # the reference pads every input signal in place (audio_signal.py:449-451); keep that observable
+                    # effect with the inputs' OWN storage: one copy of the padded block, split among them (sharing
+                    # the batch tensor made `batch *= g` edit the inputs)
+                    own = out_data.clone()
+                    at = 0
+                    for s in audio_signals:
+                        s.audio_data = own[at: at + s.batch_size]
                         at += s.batch_size
                     out = cls(out_data, sample_rate=audio_signals[0].sample_rate)
                     out.path_to_file = [s.path_to_file for s in audio_signals]
@@ -241,7 +247,11 @@ class AudioSignal(SpectralMixin, EffectMixin, LoudnessMixin, ImpulseResponseMixi
             data = bank[:, start:stop]
             if data.shape[-1] == 0:
                 raise RuntimeError(f"Audio file {audio_path} with offset {offset} and duration {duration} is empty!")
-            self.audio_data = data.unsqueeze(0)
+            # a COPY, as decoding a file returns fresh samples: in-place edits of the excerpt (`sig *= g`, the
+            # masked write-back of BaseTransform.transform) must never reach the registered bank, and the copy
+            # is 16-byte aligned whatever the start offset (the read-only candidate scan of
+            # _salient_excerpt_batched keeps slicing the bank in place)
+            self.audio_data = data.clone().unsqueeze(0)
         else:
             try:
                 import soundfile

@@ -195,7 +195,16 @@ def device_table(key, device, builder):
         else:
             hit = torch.from_numpy(np.ascontiguousarray(val)).to(device)
         _device_cache[k] = hit
+        # per-ratio resampler banks are MB-sized and pitch_shift feeds arbitrary ratios: evict the oldest of them
+        if isinstance(key, tuple) and key and key[0] in _EVICTABLE:
+            mine = [q for q in _device_cache if isinstance(q[0], tuple) and q[0] and q[0][0] == key[0]]
+            for q in mine[:-_EVICT_KEEP]:
+                _device_cache.pop(q, None)
     return hit
+
+
+_EVICTABLE = ("resample_mfma", "resample_grouped")
+_EVICT_KEEP = 16
 
 
 def stft_twiddles(n_fft: int, device):
@@ -357,7 +366,7 @@ def band_split_bank(sample_rate: int, n_bands: int, zeros: float = 8):
     return torch.stack([lowpass_taps(c, zeros, half) for c in cut]), half
 
 
-@functools.lru_cache(None)
+@functools.lru_cache(32)      # pitch_shift feeds arbitrary p/q: bounded (MB-sized banks)
 def resample_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
     """Polyphase windowed-sinc bank of the reference's resampler
     (``audio_signal.py:732`` -> julius.resample_frac): returns
@@ -382,7 +391,7 @@ def resample_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.
     return torch.stack(rows), old, new, width
 
 
-@functools.lru_cache(None)
+@functools.lru_cache(32)      # pitch_shift feeds arbitrary p/q: bounded (MB-sized banks)
 def resample_sparse_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
     """Sparse, transposed form of :func:`resample_bank` for ``at_resample_f32``: per output
     phase only the contiguous run of taps with |t| < zeros is non-negligible (the cos^2 window
@@ -408,7 +417,7 @@ def resample_sparse_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: flo
     return ws, k0, old, new, width, Wd
 
 
-@functools.lru_cache(None)
+@functools.lru_cache(32)      # pitch_shift feeds arbitrary p/q: bounded (MB-sized banks)
 def resample_grouped_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
     """Bank layout of ``at_resample_f32``: output phases grouped by 4; group G stores, for every
     tap of the union of its phases' support windows, one float4 (4 phases), zero filled.
@@ -452,7 +461,7 @@ def resample_grouped_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: fl
 MFMA_KOFF = (0, 16, 8, 24)
 
 
-@functools.lru_cache(None)
+@functools.lru_cache(32)      # pitch_shift feeds arbitrary p/q: bounded (MB-sized banks)
 def resample_mfma_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
     """Bank layout of ``at_resample_mfma_f32`` (v_mfma_f32_16x16x4_f32 form of the sparse polyphase
     resampler).  Output phases are cut into blocks of 16 (one MFMA column block); block P keeps the

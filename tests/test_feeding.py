@@ -166,3 +166,27 @@ def test_batch_grouped_resample_on_device():
     got = A.AudioSignal.batch([A.AudioSignal(d.clone().cuda(), sr) for d, (sr, _, _) in zip(data, specs)], resample=True, pad_signals=True)
     assert got.audio_data.is_cuda and got.audio_data.shape == ref.audio_data.shape
     assert float((got.audio_data.cpu() - ref.audio_data).abs().max() / ref.audio_data.abs().max()) < 1e-4
+
+
+def test_memory_excerpt_is_a_copy_and_batch_does_not_alias():
+    """An excerpt of a registered in-memory recording owns its samples (decoding a file returns fresh data), and
+    AudioSignal.batch(pad_signals=True) pads its inputs without sharing storage with the batch."""
+    g = torch.Generator().manual_seed(3)
+    bank = 0.1 * torch.randn(1, 16000, generator=g)
+    keep = bank.clone()
+    path = util.register_memory_audio("alias_check", bank, 16000)
+    sig = A.AudioSignal(path, offset=0.25 + 1 / 16000, duration=0.5)      # odd start sample
+    assert sig.audio_data.data_ptr() % 16 == 0
+    sig.audio_data *= 0.0
+    sig.audio_data[0, 0, :10] = 7.0
+    stored, _ = util.memory_audio(path)
+    assert torch.equal(stored, keep)
+
+    a = A.AudioSignal(torch.ones(1, 1, 100), 16000)
+    b = A.AudioSignal(torch.ones(1, 1, 60), 16000)
+    batch = A.AudioSignal.batch([a, b], pad_signals=True)
+    assert a.signal_length == b.signal_length == 100 and float(b.audio_data[0, 0, 60:].abs().max()) == 0.0
+    batch.audio_data *= 3.0
+    assert float(a.audio_data.max()) == 1.0 and float(b.audio_data.max()) == 1.0
+    b.audio_data += 1.0
+    assert float(batch.audio_data[1].max()) == 3.0 and float(a.audio_data.max()) == 1.0
