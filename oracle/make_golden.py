@@ -1,7 +1,8 @@
 """Generate tests/golden/*.npz from the UNMODIFIED reference (shim-imported from
 /root/reference).  TEST INFRASTRUCTURE ONLY.  Run in the build container:
 
-    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden            # the round-1 fixtures
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden --round3   # edits_r03.npz, ir_mix_loader_r03.npz only
 
 Inputs are stored next to the outputs (float16-exact values are not assumed), so the
 fixtures do not depend on torch's RNG staying stable.  Every array is produced by calling
@@ -86,5 +87,92 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 
+def round3():
+    """Fixtures added in round 3 ("two-hop parity"): STFT-domain edits, apply_ir with DRR + EQ, mix, and
+    two loader-backed transforms, all produced by the unmodified reference.  Writes only the new files."""
+    at = import_reference()
+    AudioSignal = at.AudioSignal
+    os.makedirs(OUT, exist_ok=True)
+    from tests.test_api_parity import BankLoader
+
+    # ---- STFT-domain edits (dsp.py:217-370) on a 0.25 s mono pair @16 kHz, 512/128 hann
+    sr = 16000
+    x = synth.audio_batch(2, 1, 4000, seed=301, gaps=False, sample_rate=sr)
+
+    def fresh():
+        s = AudioSignal(x.clone(), sr)
+        s.stft(512, 128, "hann")
+        return s
+
+    fmin, fmax = torch.tensor([500.0, 1000.0]), torch.tensor([1500.0, 3000.0])
+    tmin, tmax = torch.tensor([0.05, 0.10]), torch.tensor([0.10, 0.20])
+    dbc = torch.tensor([-20.0, -30.0])
+    shift = torch.tensor([0.7, -1.1])
+    out = {"x": x.numpy(), "fmin": fmin.numpy(), "fmax": fmax.numpy(), "tmin": tmin.numpy(), "tmax": tmax.numpy(),
+           "db_cutoff": dbc.numpy(), "shift": shift.numpy()}
+    out["mask_frequencies"] = fresh().mask_frequencies(fmin, fmax).stft_data.numpy()
+    out["mask_frequencies_val"] = fresh().mask_frequencies(fmin, fmax, val=0.25).stft_data.numpy()
+    out["mask_timesteps"] = fresh().mask_timesteps(tmin, tmax).stft_data.numpy()
+    out["mask_low_magnitudes"] = fresh().mask_low_magnitudes(dbc).stft_data.numpy()
+    out["shift_phase"] = fresh().shift_phase(shift).stft_data.numpy()
+    # corrupt_phase draws torch.randn_like(phase) (dsp.py:369): record the draw, the test feeds it back
+    s = fresh()
+    noise = {}
+    real_randn_like = torch.randn_like
+
+    def rec(t, *a, **k):
+        noise["n"] = real_randn_like(t, *a, **k)
+        return noise["n"]
+
+    torch.randn_like = rec
+    try:
+        torch.manual_seed(5)
+        out["corrupt_phase"] = s.corrupt_phase(0.5).stft_data.numpy()
+    finally:
+        torch.randn_like = real_randn_like
+    out["corrupt_noise"] = noise["n"].numpy()
+    out["masked_istft"] = fresh().mask_frequencies(fmin, fmax).istft().audio_data.numpy()   # the SpectralTransform round trip
+    np.savez_compressed(os.path.join(OUT, "edits_r03.npz"), **out)
+
+    # ---- apply_ir with DRR alteration + IR EQ (effects.py:125-179), mix with SNR + EQ (effects.py:27-64)
+    x = synth.audio_batch(2, 1, 12000, seed=302, gaps=False, sample_rate=sr)
+    g = torch.Generator().manual_seed(303)
+    ir = torch.randn(2, 1, 4000, generator=g) * torch.exp(-torch.arange(4000) / 500.0)
+    ir[:, :, 40] += 4.0                                    # a clear direct path, not at sample 0
+    drr = torch.tensor([5.0, 15.0])
+    ir_eq = -torch.rand(2, 6, generator=g)
+    y_ir = AudioSignal(x.clone(), sr).apply_ir(AudioSignal(ir.clone(), sr), drr=drr, ir_eq=ir_eq).audio_data
+    y_ir_plain = AudioSignal(x.clone(), sr).apply_ir(AudioSignal(ir.clone(), sr)).audio_data
+    other = 0.05 * torch.randn(2, 1, 9000, generator=g)   # shorter than the signal: padded in place
+    snr = torch.tensor([5.0, 15.0])
+    other_eq = -torch.rand(2, 3, generator=g)
+    y_mix = AudioSignal(x.clone(), sr).mix(AudioSignal(other.clone(), sr), snr=snr, other_eq=other_eq).audio_data
+    res = {"x": x.numpy(), "ir": ir.numpy(), "drr": drr.numpy(), "ir_eq": ir_eq.numpy(), "apply_ir": y_ir.numpy(),
+           "apply_ir_plain": y_ir_plain.numpy(), "other": other.numpy(), "snr": snr.numpy(), "other_eq": other_eq.numpy(),
+           "mix": y_mix.numpy()}
+
+    # ---- two loader-backed transforms (transforms.py:707-794, 857-938) over an in-memory bank, states 10..12
+    T = at.data.transforms
+    bank_n = (0.1 * torch.randn(4, 2, 24000, generator=g))
+    bank_r = torch.randn(4, 1, 8000, generator=g) * torch.exp(-torch.arange(8000) / 900.0)
+    xs = synth.audio_batch(3, 1, 16000, seed=304, gaps=False, sample_rate=sr)
+    states = [10, 11, 12]
+    bn = T.BackgroundNoise(sources=[], snr=("uniform", 5.0, 15.0), n_bands=3)
+    bn.loader = BankLoader(at, bank_n, sr)
+    sig = AudioSignal(xs.clone(), sr)
+    y_bn = bn(sig.clone(), **bn.batch_instantiate(states, sig)).audio_data
+    rir = T.RoomImpulseResponse(sources=[], duration=0.25, drr=("uniform", 5.0, 20.0), n_bands=4)
+    rir.loader = BankLoader(at, bank_r, sr)
+    y_rir = rir(sig.clone(), **rir.batch_instantiate(states, sig)).audio_data
+    res.update(bank_noise=bank_n.numpy().astype(np.float32), bank_rir=bank_r.numpy(), xs=xs.numpy(),
+               states=np.asarray(states), background_noise=y_bn.numpy(), room_impulse_response=y_rir.numpy())
+    np.savez_compressed(os.path.join(OUT, "ir_mix_loader_r03.npz"), **res)
+    for f in ("edits_r03.npz", "ir_mix_loader_r03.npz"):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if "--round3" in sys.argv:
+        round3()
+    else:
+        main()
