@@ -54,6 +54,64 @@ def _unflatten(d):
     return out
 
 
+def _assemble(values: list):
+    """The batched value ``util.collate`` builds from B per-item values of one parameter -- where every item first
+    became a tensor with ``torch.tensor(v)`` (transforms.py:224-227) and the B tensors were stacked -- assembled ONCE:
+    one numpy array, one tensor, with the dtype / shape ``torch.tensor`` gives a single item (python float -> float32,
+    numpy float64 -> float64, python int / numpy int64 -> int64, bool -> bool)."""
+    v0 = values[0]
+    if isinstance(v0, AudioSignal):
+        return AudioSignal.batch(values, pad_signals=True)
+    if torch.is_tensor(v0):
+        return torch.stack(values)
+    if isinstance(v0, dict):
+        return {k: _assemble([v[k] for v in values]) for k in v0}
+    if isinstance(v0, (list, tuple)):
+        return [_assemble(list(col)) for col in zip(*values)]
+    probe = torch.tensor(v0)
+    try:
+        arr = np.ascontiguousarray(np.asarray(values))
+        out = torch.from_numpy(arr)
+    except (TypeError, ValueError):
+        return torch.stack([torch.tensor(v) for v in values])
+    return out.to(probe.dtype).reshape((len(values),) + tuple(probe.shape))
+
+
+_STATE_POOL = []
+
+
+def _pooled_states(states):
+    """One ``RandomState`` per item.  Integer seeds re-seed POOLED generator objects: ``RandomState(seed)`` costs
+    ~220 us of object construction, ``pooled.seed(seed)`` 2 us for the identical stream.  The pooled objects never
+    leave ``batch_instantiate`` (states handed in by the caller are used as they are)."""
+    out, used = [], 0
+    for s in states:
+        if isinstance(s, (int, np.integer)) and not isinstance(s, bool):
+            if used == len(_STATE_POOL):
+                _STATE_POOL.append(np.random.RandomState(0))
+            st = _STATE_POOL[used]
+            used += 1
+            st.seed(int(s))
+            out.append(st)
+        else:
+            out.append(util.random_state(s))
+    return out
+
+
+def _draw(dist: tuple, state):
+    """``util.sample_from_dist(dist, state)`` -- the same value from the same draws -- without the ~12 us of argument
+    checking ``RandomState.choice`` spends per call: a uniform choice from a sequence is ``a[randint(0, len(a))]``
+    (numpy's own legacy implementation, mtrand.pyx ``choice`` with ``p=None``)."""
+    kind = dist[0]
+    if kind == "const":
+        return dist[1]
+    if kind == "choice" and len(dist) == 2 and not np.isscalar(dist[1]):
+        arr = np.asarray(dist[1])
+        if arr.ndim == 1 and arr.shape[0] > 0:
+            return arr[state.randint(0, arr.shape[0])]
+    return getattr(state, kind)(*dist[1:])
+
+
 class BaseTransform:
     """Base of all transforms.  Subclasses implement ``_instantiate(state[, signal]) -> dict``
     and ``_transform(signal, **params) -> signal``; the parameter names of ``_transform`` (plus
@@ -145,7 +203,27 @@ class BaseTransform:
         return {self.name: params}
 
     def batch_instantiate(self, states: list = None, signal: AudioSignal = None):
-        return util.collate([self.instantiate(s, signal) for s in states])
+        """Parameters of B items (transforms.py:228-265).  Same result as collating B ``instantiate`` calls -- every
+        item's ``RandomState`` sees the same draws in the same order -- but built parameter-major: the scalar draws
+        stay per item (numpy), every parameter becomes ONE tensor (:func:`_assemble`), and transforms that own a
+        loader fetch their B excerpts with one ``loader.batch`` call (no per-item tensor, no per-item launch)."""
+        rs = _pooled_states(states)
+        if len({id(st) for st in rs}) < len(rs):
+            # items sharing one RandomState (or the global one): only the item-major order reproduces the draws
+            return util.collate([self.instantiate(st, signal) for st in rs])
+        return {self.name: self._batch_params(rs, signal)}
+
+    def _draw_items(self, states: list, signal: AudioSignal = None):
+        """B raw parameter dicts (python / numpy values, tensors, AudioSignals), one ``_instantiate`` per state."""
+        needs_signal = "signal" in set(signature(self._instantiate).parameters.keys())
+        extra = {"signal": signal} if needs_signal else {}
+        return [self._instantiate(st, **extra) for st in states]
+
+    def _batch_params(self, states: list, signal: AudioSignal = None):
+        items = self._draw_items(states, signal)
+        params = {k: _assemble([d[k] for d in items]) for k in items[0]}
+        params["mask"] = _assemble([st.rand() <= self.prob for st in states])
+        return params
 
 
 class Identity(BaseTransform):
@@ -196,6 +274,12 @@ class Compose(BaseTransform):
             params.update(t.instantiate(state, signal=signal))
         return params
 
+    def _batch_params(self, states: list, signal: AudioSignal = None):
+        # child-major: every item's state still sees child 0, child 1, ... in order
+        params = {t.name: t._batch_params(states, signal) for t in self.transforms}
+        params["mask"] = _assemble([st.rand() <= self.prob for st in states])
+        return params
+
     def __getitem__(self, idx):
         return self.transforms[idx]
 
@@ -224,6 +308,19 @@ class Choose(Compose):
             one_hot.append(kwargs[t.name]["mask"])
         kwargs["one_hot"] = one_hot
         return kwargs
+
+    def _batch_params(self, states: list, signal: AudioSignal = None):
+        params = {t.name: t._batch_params(states, signal) for t in self.transforms}
+        n = len(self.transforms)
+        picks = np.asarray([st.choice(list(range(n)), p=self.weights) for st in states])
+        one_hot = []
+        for i, t in enumerate(self.transforms):
+            chosen = params[t.name]["mask"] & torch.from_numpy(picks == i)      # a set mask becomes (i == pick)
+            params[t.name]["mask"] = chosen
+            one_hot.append(chosen)
+        params["one_hot"] = torch.stack(one_hot, dim=1)      # per item torch.tensor([masks]) -> (n,), collated (B, n)
+        params["mask"] = _assemble([st.rand() <= self.prob for st in states])
+        return params
 
 
 class Repeat(Compose):
@@ -270,6 +367,10 @@ class _Recipe(BaseTransform):
 
     def _instantiate(self, state):
         return {k: util.sample_from_dist(getattr(self, k), state) for k in self.DISTS}
+
+    def _draw_items(self, states, signal=None):
+        dists = [(k, getattr(self, k)) for k in self.DISTS]
+        return [{k: _draw(d, st) for k, d in dists} for st in states]
 
     def _transform(self, signal, **kwargs):
         kw = {self.RENAME.get(k, k): v for k, v in kwargs.items()}
@@ -389,6 +490,11 @@ class Equalizer(BaseTransform):
     def _instantiate(self, state):
         return {"eq": -util.sample_from_dist(self.eq_amount, state) * state.rand(self.n_bands)}
 
+    def _draw_items(self, states, signal=None):
+        if type(self)._instantiate is not Equalizer._instantiate:
+            return super()._draw_items(states, signal)
+        return [{"eq": -_draw(self.eq_amount, st) * st.rand(self.n_bands)} for st in states]
+
     def _transform(self, signal, eq):
         return signal.equalizer(eq)
 
@@ -483,6 +589,51 @@ class TensorLoader:
         return {"signal": sig, "source_idx": 0, "item_idx": idx, "source": "tensor", "path": ""}
 
 
+def _tensor_loader_batch(self, states, sample_rate: int, duration: float, loudness_cutoff: float = -40,
+                         num_channels: int = 1, offset: float = None, **kwargs):
+    """B items of a :class:`TensorLoader` at once: the per-item draws of ``__call__`` (numpy), then ONE gather from
+    the bank, one mix-down, one resample, one pad."""
+    bank = self.bank
+    sr_b, T_b = bank.sample_rate, bank.signal_length
+    n = int(duration * sr_b)
+    hi = max(T_b - n, 0)
+    idx, starts = [], []
+    for st in states:
+        # choice(N) without weights is randint(0, N) (numpy legacy choice); same stream, a tenth of the call cost
+        idx.append(int(st.randint(0, bank.batch_size)) if self.weights is None else int(st.choice(bank.batch_size, p=self.weights)))
+        if offset is None:
+            starts.append(int(st.randint(0, hi + 1)) if hi > 0 else 0)
+        else:
+            starts.append(int(offset * sr_b))
+    data = bank.audio_data
+    dev = data.device
+    it = torch.as_tensor(idx, device=dev)
+    if len(set(starts)) == 1:
+        seg = data.index_select(0, it)[..., starts[0]: starts[0] + n]
+    else:                                   # random starts never run past the end (hi = T - n): a plain gather
+        pos = torch.as_tensor(starts, device=dev)[:, None] + torch.arange(min(n, T_b), device=dev)[None, :]
+        seg = torch.gather(data.index_select(0, it), 2, pos[:, None, :].expand(-1, data.shape[1], -1))
+    sig = AudioSignal(seg.clone() if seg.data_ptr() == data.data_ptr() else seg, sr_b)
+    if num_channels == 1:
+        sig = sig.to_mono()
+    sig = sig.resample(sample_rate)
+    if duration is not None:
+        sig = sig.zero_pad_to(int(duration * sample_rate))
+    B = len(idx)
+    return {"signal": sig, "source_idx": [0] * B, "item_idx": idx, "source": ["tensor"] * B, "path": [""] * B}
+
+
+TensorLoader.batch = _tensor_loader_batch
+
+
+def _loader_batch(loader, states, *args, **kwargs):
+    """``loader.batch(states, ...)["signal"]`` when the loader has a batched form, else B calls collated like
+    ``util.collate`` does (any callable with the AudioLoader.__call__ signature is a valid loader)."""
+    if hasattr(loader, "batch"):
+        return loader.batch(states, *args, **kwargs)["signal"]
+    return AudioSignal.batch([loader(st, *args, **kwargs)["signal"] for st in states], pad_signals=True)
+
+
 def _resolve_loader(sources, weights, loader, who):
     """``loader`` (any callable with the AudioLoader.__call__ signature, e.g. a TensorLoader over an
     HBM-resident bank) wins; otherwise the reference's construction ``AudioLoader(sources, weights)``
@@ -515,6 +666,15 @@ class BackgroundNoise(BaseTransform):
                          loudness_cutoff=self.loudness_cutoff, num_channels=signal.num_channels)["signal"]
         return {"eq": eq, "bg_signal": bg, "snr": snr}
 
+    def _batch_params(self, states, signal: AudioSignal = None):
+        eq = [-_draw(self.eq_amount, st) * st.rand(self.n_bands) for st in states]
+        snr = [_draw(self.snr, st) for st in states]
+        # every state is its own stream: per item the order is still eq, snr, loader draws, mask
+        bg = _loader_batch(self.loader, states, signal.sample_rate, duration=signal.signal_duration,
+                           loudness_cutoff=self.loudness_cutoff, num_channels=signal.num_channels)
+        return {"eq": _assemble(eq), "bg_signal": bg, "snr": _assemble(snr),
+                "mask": _assemble([st.rand() <= self.prob for st in states])}
+
     def _transform(self, signal, bg_signal, snr, eq):
         return signal.mix(bg_signal.clone(), snr, eq)
 
@@ -534,6 +694,13 @@ class CrossTalk(BaseTransform):
         other = self.loader(state, signal.sample_rate, duration=signal.signal_duration,
                             loudness_cutoff=self.loudness_cutoff, num_channels=signal.num_channels)["signal"]
         return {"crosstalk_signal": other, "snr": snr}
+
+    def _batch_params(self, states, signal: AudioSignal = None):
+        snr = [_draw(self.snr, st) for st in states]
+        other = _loader_batch(self.loader, states, signal.sample_rate, duration=signal.signal_duration,
+                              loudness_cutoff=self.loudness_cutoff, num_channels=signal.num_channels)
+        return {"crosstalk_signal": other, "snr": _assemble(snr),
+                "mask": _assemble([st.rand() <= self.prob for st in states])}
 
     def _transform(self, signal, crosstalk_signal, snr):
         loudness = signal.loudness()
@@ -562,6 +729,15 @@ class RoomImpulseResponse(BaseTransform):
                          loudness_cutoff=None, num_channels=signal.num_channels)["signal"]
         ir.zero_pad_to(signal.sample_rate)
         return {"eq": eq, "ir_signal": ir, "drr": drr}
+
+    def _batch_params(self, states, signal: AudioSignal = None):
+        eq = [-_draw(self.eq_amount, st) * st.rand(self.n_bands) for st in states]
+        drr = [_draw(self.drr, st) for st in states]
+        ir = _loader_batch(self.loader, states, signal.sample_rate, offset=self.offset, duration=self.duration,
+                           loudness_cutoff=None, num_channels=signal.num_channels)
+        ir.zero_pad_to(signal.sample_rate)
+        return {"eq": _assemble(eq), "ir_signal": ir, "drr": _assemble(drr),
+                "mask": _assemble([st.rand() <= self.prob for st in states])}
 
     def _transform(self, signal, ir_signal, drr, eq):
         return signal.apply_ir(ir_signal.clone(), drr, eq, use_original_phase=self.use_original_phase)

@@ -231,16 +231,20 @@ def info(audio_path) -> Info:
 
 
 def find_audio(folder: str, ext: typing.List[str] = AUDIO_EXTENSIONS):
-    """Audio files below ``folder`` (core/util.py:218-250)."""
-    folder = Path(folder)
-    if str(folder).endswith(tuple(ext)):
-        if "*" in str(folder):
-            return glob.glob(str(folder), recursive=("**" in str(folder)))
-        return [folder]
-    files = []
-    for x in ext:
-        files += folder.glob(f"**/*{x}")
-    return files
+    """Audio files below ``folder`` (behaviour of core/util.py:218-250): a path that itself ends in one of the
+    extensions is returned as is (or expanded when it holds a ``*`` pattern); a directory is walked once and every
+    file whose name ends in one of ``ext`` is kept, grouped by extension in the order of ``ext``."""
+    text = str(folder)
+    suffixes = tuple(ext)
+    if text.endswith(suffixes):
+        return glob.glob(text, recursive="**" in text) if "*" in text else [Path(text)]
+    by_ext = {e: [] for e in ext}
+    for root, _dirs, names in os.walk(text):
+        for name in names:
+            for e in ext:
+                if name.endswith(e):
+                    by_ext[e].append(Path(root) / name)
+    return [f for e in ext for f in by_ext[e]]
 
 
 def read_sources(sources: typing.List[str], remove_empty: bool = True, relative_path: str = "",
@@ -280,11 +284,19 @@ def choose_from_list_of_lists(state: np.random.RandomState, list_of_lists: list,
     return list_of_lists[source_idx][item_idx], source_idx, item_idx
 
 
-@contextmanager
-def chdir(newdir):
-    curdir = os.getcwd()
-    try:
-        os.chdir(newdir)
-        yield
-    finally:
-        os.chdir(curdir)
+class chdir:
+    """``with util.chdir(path):`` -- run the block with ``path`` as the working directory, restore the previous one
+    on exit, also when the block raises (core/util.py:325-343)."""
+
+    def __init__(self, newdir):
+        self._target = newdir
+        self._stack = []
+
+    def __enter__(self):
+        self._stack.append(os.getcwd())
+        os.chdir(self._target)
+        return self
+
+    def __exit__(self, *exc):
+        os.chdir(self._stack.pop())
+        return False

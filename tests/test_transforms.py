@@ -102,3 +102,62 @@ def test_ir_tools_match_reference(reference):
         M.AudioSignal(ir.clone(), 48000), drr=torch.tensor([5.0, 10, 15, 20, 0]),
         ir_eq=-torch.rand(5, 6, generator=torch.Generator().manual_seed(2)))
     assert torch.allclose(mk(A).audio_data, mk(reference).audio_data, atol=1e-6)
+
+
+# ------------------------------------------------------------------ batched instantiate (round 3)
+def _same_tree(a, b, path=""):
+    """Nested parameter dicts equal in structure, dtype, shape and value (AudioSignals by their samples)."""
+    assert type(a) is type(b) or (torch.is_tensor(a) and torch.is_tensor(b)), (path, type(a), type(b))
+    if isinstance(a, dict):
+        assert sorted(a) == sorted(b), (path, sorted(a), sorted(b))
+        for k in a:
+            _same_tree(a[k], b[k], f"{path}/{k}")
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same_tree(x, y, f"{path}[{i}]")
+    elif hasattr(a, "audio_data"):
+        assert a.sample_rate == b.sample_rate and a.audio_data.shape == b.audio_data.shape, path
+        assert torch.equal(a.audio_data, b.audio_data), path
+    else:
+        assert a.dtype == b.dtype and a.shape == b.shape, (path, a.dtype, b.dtype, a.shape, b.shape)
+        assert torch.equal(a, b), path
+
+
+def _everything():
+    g = torch.Generator().manual_seed(5)
+    rir_bank = torch.randn(5, 1, 30000, generator=g) * torch.exp(-torch.arange(30000) / 4000.0)
+    nz_bank = 0.1 * torch.randn(5, 2, 80000, generator=g)
+    return tfm.Compose(
+        tfm.VolumeChange(), tfm.LowPass(prob=0.7), tfm.Equalizer(), tfm.ClippingDistortion(prob=0.5),
+        tfm.Choose(tfm.HighPass(), tfm.Quantization(), tfm.MuLawQuantization(), weights=[0.5, 0.3, 0.2]),
+        tfm.RepeatUpTo(tfm.VolumeChange(("uniform", -1.0, 0.0)), max_repeat=4),
+        tfm.BackgroundNoise(loader=tfm.TensorLoader(nz_bank, 44100)),
+        tfm.CrossTalk(loader=tfm.TensorLoader(nz_bank, 44100), loudness_cutoff=None),
+        tfm.RoomImpulseResponse(loader=tfm.TensorLoader(rir_bank, 44100), duration=0.5),
+        tfm.ShiftPhase(prob=0.4), tfm.CorruptPhase(), tfm.FrequencyMask(), tfm.TimeMask(), tfm.Smoothing(),
+        tfm.NoiseFloor(), tfm.Silence(), tfm.RescaleAudio(), name="everything")
+
+
+def test_batch_instantiate_equals_collated_instantiate():
+    """BaseTransform.batch_instantiate builds every parameter once (parameter-major); the result -- structure,
+    dtypes, values, loaded excerpts -- and every RandomState afterwards equal B collated instantiate() calls."""
+    x = synth.audio_batch(5, 1, 22050, seed=2, gaps=False)
+    sig = A.AudioSignal(x, 44100)
+    t = _everything()
+    seeds = [3, 11, 12, 400, 7]
+    s_batch = [np.random.RandomState(s) for s in seeds]
+    s_items = [np.random.RandomState(s) for s in seeds]
+    got = t.batch_instantiate(s_batch, sig)
+    want = A.util.collate([t.instantiate(st, sig) for st in s_items])
+    _same_tree(got, want)
+    assert all(a.rand() == b.rand() for a, b in zip(s_batch, s_items))
+    # plain seeds and a one-item batch
+    _same_tree(t.batch_instantiate([9], sig[0]), A.util.collate([t.instantiate(9, sig[0])]))
+    # one shared state: the item-major fallback keeps the reference's draw order
+    sh_a, sh_b = np.random.RandomState(1), np.random.RandomState(1)
+    _same_tree(t.batch_instantiate([sh_a, sh_a, sh_a], sig), A.util.collate([t.instantiate(sh_b, sig) for _ in range(3)]))
+    # the batch applies like the collated one
+    out_a = t(sig.clone(), **got).audio_data
+    out_b = t(sig.clone(), **want).audio_data
+    assert torch.equal(out_a, out_b)
