@@ -45,9 +45,13 @@ bank = torch.randn(64, 1, 96000, device=dev, generator=g) * torch.exp(-torch.ara
 chain = tfm.Compose(tfm.LowPass(cutoff=("choice", [4000, 8000, 16000])), tfm.Equalizer(n_bands=6),
                     tfm.RoomImpulseResponse(loader=tfm.TensorLoader(bank, SR), duration=2.0))
 sig = A.AudioSignal(x, SR)
-t0 = time.perf_counter()
-kw = chain.batch_instantiate(list(range(B)), A.AudioSignal(x[:1], SR))
-print(f"cfg4 batch_instantiate (host)       {(time.perf_counter() - t0) * 1e3:9.1f} ms")
+for rep in range(4):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kw = chain.batch_instantiate(list(range(B)), A.AudioSignal(x[:1], SR))
+    t_host = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    print(f"cfg4 batch_instantiate #{rep}: host {t_host:7.1f} ms, with the device work {(time.perf_counter() - t0) * 1e3:7.1f} ms", flush=True)
 kw = A.util.prepare_batch(kw, dev)
 kc = kw["Compose"]
 if "lowpass" in only:
