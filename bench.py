@@ -143,16 +143,22 @@ def committed_traffic(config, n_local):
     configuration (profiles/r02_*_pmc_summary.json; FETCH_SIZE and WRITE_SIZE in separate passes,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this
     exact shape is committed -- it is a recorded measurement, not one made by this run."""
-    path = os.path.join(ROOT, "profiles", "r02_bench_pmc_summary.json")
-    if config != "north_star" or n_local != 512 or not os.path.exists(path):
+    if config != "north_star" or n_local != 512:
         return None, None
-    try:
-        d = json.load(open(path))
-        f = [v["FETCH_SIZE"] for k, v in d["pmc_fetch"].items() if "stft_mel_kernel" in k][0]
-        w = [v["WRITE_SIZE"] for k, v in d["pmc_write"].items() if "stft_mel_kernel" in k][0]
-        return (2.0 * f + w) * 1024.0, "profiles/r02_bench_pmc_summary.json (rocprofv3 --pmc, same command)"
-    except Exception:
-        return None, None
+    for name in ("r03_bench_pmc_summary.json", "r02_bench_pmc_summary.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))
+            f = [v["FETCH_SIZE"] for k, v in d["pmc_fetch"].items() if "stft_mel_kernel" in k][0]
+            w = [v["WRITE_SIZE"] for k, v in d["pmc_write"].items() if "stft_mel_kernel" in k][0]
+            box = d.get("box", "another MI355X of the pool (not this run's box)")
+            return (2.0 * f + w) * 1024.0, (f"profiles/{name}: rocprofv3 --pmc of the same command, recorded on {box}; "
+                                            f"a committed measurement replayed here, NOT taken by this run")
+        except Exception:
+            continue
+    return None, None
 
 
 # ----------------------------------------------------------------------------- launching
@@ -208,9 +214,16 @@ def time_steps(step, steps, warmup, adist, device, world, n_events=0):
     adist.barrier()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+    PER_RANK_S[:] = [t1 - t0]
     if world > 1:
+        every = [torch.zeros_like(elapsed) for _ in range(world)]
+        torch.distributed.all_gather(every, elapsed)
+        PER_RANK_S[:] = [float(e[0]) for e in every]
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     return float(elapsed[0]), events
+
+
+PER_RANK_S = []     # wall time of the last timed region on every rank (rank order)
 
 
 def main():
@@ -286,13 +299,11 @@ def main():
             if ev is not None:
                 ev[2].record()
 
-        _, events = time_steps(step_events, max(5, min(args.steps, 20)), args.warmup, adist, device, world, n_events=3)
-        stft_ms = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
-        lufs_ms = sum(e[1].elapsed_time(e[2]) for e in events) / len(events)
-
         launch = "eager"
-        step = lambda ev: api_step()
+        step = step_events
         if args.graph:
+            # (a captured graph cannot carry the per-kernel events: they are taken from a separate eager pass)
+            _, events = time_steps(step_events, max(5, min(args.steps, 20)), args.warmup, adist, device, world, n_events=3)
             try:
                 graph = torch.cuda.CUDAGraph()
                 s = torch.cuda.Stream()
@@ -307,9 +318,40 @@ def main():
             except Exception as e:  # pragma: no cover - capture not supported on this stack
                 launch = f"eager (graph capture failed: {type(e).__name__})"
                 step = lambda ev: api_step()
-        elapsed, _ = time_steps(step, args.steps, args.warmup, adist, device, world)
+        if args.graph:
+            elapsed, _ = time_steps(step, args.steps, args.warmup, adist, device, world)
+            timing_note = "HIP events around eager launches in a separate pass (the timed region replays a graph)"
+        else:
+            # the per-kernel HIP events are recorded INSIDE the timed region: the K launches whose durations are
+            # averaged below are the K launches of ms_per_step (so stft_mel + lufs_total <= ms_per_step)
+            elapsed, events = time_steps(step, args.steps, args.warmup, adist, device, world, n_events=3)
+            timing_note = "HIP events on the launch stream, recorded inside the timed region (the same K steps)"
+        stft_ms = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
+        lufs_ms = sum(e[1].elapsed_time(e[2]) for e in events) / len(events)
         mel, lufs = res["mel"], res["lufs"]
         assert torch.isfinite(mel).all() and torch.isfinite(lufs).all()
+        # the 8-GPU share timed on THIS device: what one rank of an 8-way batch shard would run, so that the
+        # first measured scaling curve has a prediction to be checked against (no collective on the data path)
+        share = None
+        if world == 1 and n_local >= 16 and not args.graph:
+            n_sh = n_local // 8
+            sig_sh = A.AudioSignal(x[:n_sh], sr)
+            res_sh = {}
+
+            def share_step(ev):
+                res_sh["mel"] = sig_sh.mel_spectrogram(N_MELS)
+                sig_sh._loudness = None
+                res_sh["lufs"] = sig_sh.loudness()
+
+            saved = list(PER_RANK_S)
+            el_sh, _ = time_steps(share_step, args.steps, args.warmup, adist, device, world)
+            PER_RANK_S[:] = saved
+            ms_sh = 1e3 * el_sh / args.steps
+            share = {"items": n_sh, "ms_per_step": ms_sh,
+                     "predicted_speedup_8gpu": (1e3 * elapsed / args.steps) / ms_sh,
+                     "predicted_value_8gpu": batch * dur / (ms_sh * 1e-3),
+                     "note": "one rank's share of an 8-way batch shard, timed on this device; the data path has no "
+                             "collective, so 8 ranks are predicted to finish in this time (+ barrier skew)"}
         achieved = stft_bytes / (stft_ms * 1e-3) / 1e9
         traffic, traffic_src = committed_traffic(args.config, n_local)
         # what a plain device copy reaches on THIS box (torch.Tensor.copy_, read + write counted),
@@ -334,7 +376,9 @@ def main():
                            "algorithmic_bytes_per_launch": stft_bytes, "avg_launch_ms": stft_ms,
                            "device_copy_GBps": copy_gbs, "frac_of_device_copy": achieved / copy_gbs}
         out["kernels_ms"] = {"stft_mel": stft_ms, "lufs_total": lufs_ms, "lufs_GBps": lufs_bytes / (lufs_ms * 1e-3) / 1e9,
-                             "timing": "HIP events around eager launches, separate from the timed region"}
+                             "timing": timing_note}
+        if share is not None:
+            out["share_64" if n_local == 512 else f"share_{n_local // 8}"] = share
 
     elif args.config == "cfg4":
         from audiotools_amd import transforms as tfm
@@ -425,6 +469,10 @@ def main():
     if rank == 0:
         out["ms_per_step"] = 1e3 * elapsed / args.steps
         out["value"] = batch * dur / (elapsed / args.steps)
+        out["world_size"] = world
+        out["backend"] = torch.distributed.get_backend() if world > 1 else None
+        out["per_rank_ms_per_step"] = [1e3 * t / args.steps for t in PER_RANK_S]
+        out["host"] = socket.gethostname()
         if world == 1 and not args.no_cpu_baseline:
             if args.config == "north_star":
                 out["cpu_baseline"] = cpu_baseline_north_star(args.cpu_items or 64, args.cpu_iters)
