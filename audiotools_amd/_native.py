@@ -107,6 +107,7 @@ SIGNATURES = {
     "at_stft_native_supported": (_i32, [_i32]),
     "at_stft_fused_supported": (_i32, [_i32]),
     "at_mel_units_host": (_i32, [_p, _i32, _i32, _p, _p]),
+    "at_mel_bands_host": (_i32, [_p, _i32, _i32, _p, _p]),
     "at_stft_mel_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
     "at_istft_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),

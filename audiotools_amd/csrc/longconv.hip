@@ -35,43 +35,23 @@ namespace {
 using at::gfft::cmulf;
 using at::gfft::dft_r;
 using at::gfft::MAX_RADIX;
+using at::gfft::PassList;
+using at::gfft::TILE_POINTS;
+using at::gfft::MAX_PASSES;
+using at::gfft::ColLayout;
+using at::gfft::RowLayout;
+using at::gfft::run_passes;
+using at::gfft::factor;
 
 constexpr int THREADS = 256;
 constexpr int MAX_N1 = 512;
 constexpr int MAX_N2 = 2048;
-constexpr int TILE_POINTS = 4096;   // complex points of one LDS tile (colfft) / one row pair (rowconv)
-constexpr int MAX_PASSES = 12;
-
-struct PassList {
-  int n;
-  int radix[MAX_PASSES];
-  int ns[MAX_PASSES];       // product of the radices before this pass
-};
-
 struct Plan {
   int N1, N2;
   int cw, lcw;              // columns per colfft tile (power of two), log2
   int nhi;                  // ceil(N2 / 64): entries of the coarse row-twiddle table
   PassList p1, p2;
 };
-
-bool factor(int n, PassList* p) {
-  p->n = 0;
-  int ns = 1;
-  auto take = [&](int r) {
-    while (n % r == 0) {
-      if (p->n == MAX_PASSES) return false;
-      p->radix[p->n] = r; p->ns[p->n] = ns; ++p->n;
-      ns *= r; n /= r;
-    }
-    return true;
-  };
-  // Odd radices first: a Stockham pass writes runs of NS consecutive points at a stride of NS R, and
-  // with NS = 1, 4, 16 and R = 4 that is an 8-way LDS bank conflict in the row layout (36 % of the
-  // LDS cycles of rowconv_kernel); strides of 3, 5, 7 points are conflict-free, and once the odd part
-  // is done NS is large enough for the radix-4 / 2 passes.
-  return take(5) && take(3) && take(7) && take(4) && take(2) && n == 1;
-}
 
 bool make_plan(int64_t T, Plan* P) {
   if (T < 2 || (T & 1) || T / 2 > (int64_t)MAX_N1 * MAX_N2) return false;
@@ -113,102 +93,6 @@ TableOffsets table_offsets(const Plan& P) {
   o.sp_hi = o.sp_lo + P.N1;
   o.total = o.sp_hi + P.N2;
   return o;
-}
-
-// ---------------------------------------------------------------- in-place mixed-radix passes
-struct ColLayout {          // tile[point][column]
-  int lcw, cmask;
-  __device__ __forceinline__ void split(int id, int nb, int& batch, int& j) const { batch = id & cmask; j = id >> lcw; (void)nb; }
-  __device__ __forceinline__ int addr(int batch, int p) const { return (p << lcw) + batch; }
-  __device__ __forceinline__ int step(int ns) const { return ns << lcw; }
-};
-struct RowLayout {          // buf[row slot][point]
-  int N;
-  __device__ __forceinline__ void split(int id, int nb, int& batch, int& j) const { batch = id >= nb ? 1 : 0; j = id - (batch ? nb : 0); }
-  __device__ __forceinline__ int addr(int batch, int p) const { return batch * N + p; }
-  __device__ __forceinline__ int step(int ns) const { return ns; }
-};
-
-// One Stockham pass of radix R over `total` butterflies (all batches), in place: every thread reads
-// its NB butterflies, the workgroup meets, every thread writes.  tw = w_N^t, t < N.
-// The loop is branch-free: a thread index past the last butterfly is clamped to it, so the surplus
-// lanes repeat that butterfly and store the same values to the same slots.  With predicated
-// iterations every butterfly was its own basic block and its LDS reads were not issued before the
-// previous butterfly had finished (the kernel ran at 46 % VALU and 26 % LDS utilisation).
-template <int R, int NB, int NT, class L>
-__device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const float2* __restrict__ tw, int N, int NS,
-                                             int total, const L lay) {
-  const int nb = N / R;
-  const int tstep = nb / NS;                 // w_{NS R}^k = w_N^{k tstep}
-  const float inv_ns = 1.0f / (float)NS;
-  float2 v[NB][MAX_RADIX];
-  int o[NB];
-  // opaque copy of the thread index: keeps the per-butterfly index arithmetic of every pass variant
-  // from being hoisted out of the pass loop (that cost > 128 live registers and spills)
-  int tid = (int)threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int last = total - 1;
-  // the last iteration is skipped by the waves that lie entirely past the end (wave-uniform branch)
-  const bool tail = __builtin_amdgcn_readfirstlane(tid & ~63) + NT * (NB - 1) < total;
-  auto load_one = [&](int b) __attribute__((always_inline)) {
-    const int id = min(tid + NT * b, last);
-    int batch, j;
-    lay.split(id, nb, batch, j);
-    const int jd = (int)(((float)j + 0.5f) * inv_ns);     // j / NS (exact: j < 2048)
-    const int k = j - jd * NS;
-#pragma unroll
-    for (int q = 0; q < R; ++q) v[b][q] = buf[lay.addr(batch, j + nb * q)];
-    if (NS > 1) {
-      const int kt = k * tstep;
-#pragma unroll
-      for (int q = 1; q < R; ++q) v[b][q] = cmulf(v[b][q], tw[kt * q]);
-    }
-    o[b] = lay.addr(batch, jd * NS * R + k);
-  };
-#pragma unroll
-  for (int b = 0; b < NB - 1; ++b) load_one(b);
-  if (tail) load_one(NB - 1);
-#pragma unroll
-  for (int b = 0; b < NB - 1; ++b) dft_r<R>(v[b]);
-  if (tail) dft_r<R>(v[NB - 1]);
-  __syncthreads();
-  const int st = lay.step(NS);
-#pragma unroll
-  for (int b = 0; b < NB - 1; ++b) {
-#pragma unroll
-    for (int q = 0; q < R; ++q) buf[o[b] + st * q] = v[b][q];
-  }
-  if (tail) {
-#pragma unroll
-    for (int q = 0; q < R; ++q) buf[o[NB - 1] + st * q] = v[NB - 1][q];
-  }
-  __syncthreads();
-}
-
-// the variant for the iteration count of this launch (uniform): NB = ceil(total / NT)
-template <int R, int NT, class L>
-__device__ __forceinline__ void pass_dispatch(float2* buf, const float2* tw, int N, int NS, int total, const L lay) {
-  constexpr int MAXB = (TILE_POINTS / R + NT - 1) / NT;
-  const int nbi = (total + NT - 1) / NT;
-  if (nbi <= 1) pass_inplace<R, 1, NT>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 2 && nbi == 2) pass_inplace<R, (MAXB >= 2 ? 2 : 1), NT>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 3 && nbi == 3) pass_inplace<R, (MAXB >= 3 ? 3 : 1), NT>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 4 && nbi == 4) pass_inplace<R, (MAXB >= 4 ? 4 : 1), NT>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 6 && nbi <= 6) pass_inplace<R, (MAXB >= 6 ? 6 : 1), NT>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 8) pass_inplace<R, (MAXB >= 8 ? 8 : 1), NT>(buf, tw, N, NS, total, lay);
-}
-
-template <int NT, class L>
-__device__ __forceinline__ void run_passes(float2* buf, const float2* tw, int N, const PassList& pl, int batches, const L lay) {
-  for (int p = 0; p < pl.n; ++p) {
-    const int R = pl.radix[p];
-    const int total = (N / R) * batches;
-    if (R == 4) pass_dispatch<4, NT>(buf, tw, N, pl.ns[p], total, lay);
-    else if (R == 2) pass_dispatch<2, NT>(buf, tw, N, pl.ns[p], total, lay);
-    else if (R == 3) pass_dispatch<3, NT>(buf, tw, N, pl.ns[p], total, lay);
-    else if (R == 5) pass_dispatch<5, NT>(buf, tw, N, pl.ns[p], total, lay);
-    else pass_dispatch<7, NT>(buf, tw, N, pl.ns[p], total, lay);
-  }
 }
 
 // ---------------------------------------------------------------- column FFT

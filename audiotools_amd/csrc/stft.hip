@@ -1036,6 +1036,27 @@ int at_mel_units_host(const float* basis, int n_mels, int n_bins, int* unit_info
   return n;
 }
 
+// Host helper: the BANDED form of a dense (n_mels, n_bins) filterbank for the generic-size kernel.  Call with
+// band == NULL to get the number of weights; then band[3 * n_mels] = {first bin, length, offset} and w[count].
+// Rows are cut to their non-zero span (an all-zero row has length 0).
+int at_mel_bands_host(const float* basis, int n_mels, int n_bins, int* band, float* w) {
+  if (!basis || n_mels <= 0 || n_bins <= 0) return AT_ERR_INVALID;
+  int total = 0;
+  for (int m = 0; m < n_mels; ++m) {
+    const float* b = basis + (int64_t)m * n_bins;
+    int lo = -1, hi = -1;
+    for (int k = 0; k < n_bins; ++k)
+      if (b[k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+    const int len = lo < 0 ? 0 : hi - lo + 1;
+    if (band && w) {
+      band[3 * m] = lo < 0 ? 0 : lo; band[3 * m + 1] = len; band[3 * m + 2] = total;
+      for (int j = 0; j < len; ++j) w[total + j] = b[lo + j];
+    }
+    total += len;
+  }
+  return total;
+}
+
 int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
                     int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,
                     float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,
@@ -1048,8 +1069,10 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   const bool mel = mel_out != nullptr;
   if (!stft_out) return AT_ERR_INVALID;  // stft_data is always produced (audio_signal.py:1210)
   if (!at_stft_fused_supported(n_fft)) {
-    // generic sizes: mixed-radix workgroup FFT (csrc/stft_generic.hip); no fused mel stage
-    if (mel) return AT_ERR_UNSUPPORTED;
+    // generic sizes: mixed-radix workgroup FFT (csrc/stft_generic.hip).  Its fused mel stage takes the filterbank in
+    // BANDED form: mel_unit_info = (n_mels, 3) ints {first bin, length, offset into mel_unit_w}, mel_unit_w = the
+    // concatenated non-zero spans of the rows, n_units = their total length (at_mel_bands_host builds them).
+    if (mel && (!mel_unit_info || !mel_unit_w || n_units <= 0 || n_mels <= 0 || n_fft / 2 > 4096)) return AT_ERR_UNSUPPORTED;
     const int64_t T2g = T + 2 * (int64_t)pad + right_pad;
     if (n_fft / 2 >= T2g) return AT_ERR_INVALID;
     if (pad_mode == at::PAD_REFLECT && (pad >= T || pad + right_pad >= T)) return AT_ERR_INVALID;
@@ -1057,7 +1080,8 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
     if (T >= (1LL << 31) || n_frames_out >= (1LL << 31) / (n_fft / 2 + 1)) return AT_ERR_UNSUPPORTED;
     if (n_frames_out == 0) return AT_OK;
     return at::stft_generic(x, rows, T, window, twiddles, n_fft, hop, pad, right_pad, pad_mode, frame_lo, n_frames_out,
-                            stft_out, reinterpret_cast<hipStream_t>(stream));
+                            stft_out, mel_unit_info, mel_unit_w, n_mels, mel ? mel_out : nullptr,
+                            reinterpret_cast<hipStream_t>(stream));
   }
   if (mel && (!mel_unit_info || !mel_unit_w || (n_units != 128 && n_units != 256 && n_units != 384) || n_mels <= 0))
     return AT_ERR_INVALID;

@@ -223,6 +223,11 @@ class SpectralMixin:
         units = None
         if kernels.stft_fused_supported(n_fft) and audio.is_cuda:
             units = tables.mel_units_or_none(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, audio.device)
+        if (units is None and kernels.is_native(audio) and not kernels.stft_fused_supported(n_fft)
+                and kernels.stft_native_supported(n_fft) and n_fft <= 8192):
+            # generic sizes (4096 @ 96 kHz, 8192 @ 192 kHz, 400 / 1200 / 1920 ...): banded mel fused into the
+            # mixed-radix kernel -- no second pass over stft_data, no dense matmul
+            units = tables.mel_bands(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, audio.device)
         if kernels.is_native(audio) and units is not None:
             dev = audio.device
             info, w = units

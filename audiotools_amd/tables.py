@@ -257,6 +257,28 @@ def mel_units(sr, n_fft, n_mels, fmin, fmax, device):
                         lambda: mel_units_np(mel_filters_np(sr, n_fft, n_mels, fmin, fmax)))
 
 
+def mel_bands_np(basis: np.ndarray):
+    """BANDED form of a dense (n_mels, F) filterbank for the generic-size fused mel stage (``at_mel_bands_host``):
+    ``(band int32 (n_mels, 3) = {first bin, length, offset into w}, w float32 (total,))``."""
+    basis = np.ascontiguousarray(basis, dtype=np.float32)
+    n_mels, F = basis.shape
+    lib = _native.lib()
+    total = int(lib.at_mel_bands_host(basis.ctypes.data, n_mels, F, None, None))
+    if total < 0:
+        _native.check(total, "at_mel_bands_host")
+    band = np.zeros((n_mels, 3), dtype=np.int32)
+    w = np.zeros(max(total, 1), dtype=np.float32)
+    got = int(lib.at_mel_bands_host(basis.ctypes.data, n_mels, F, band.ctypes.data, w.ctypes.data))
+    assert got == total
+    return band, w
+
+
+def mel_bands(sr, n_fft, n_mels, fmin, fmax, device):
+    """Device copy of :func:`mel_bands_np` of the Slaney basis (cached)."""
+    return device_table(("mel_bands", sr, n_fft, n_mels, fmin, fmax), device,
+                        lambda: mel_bands_np(mel_filters_np(sr, n_fft, n_mels, fmin, fmax)))
+
+
 def mel_bin_table_np(basis: np.ndarray):
     """Per-bin view of a triangular filterbank for the mel backward kernel: bin k is covered by at
     most two bands.  Returns ``(bands int32 (F,) = lo | hi << 16, weights float32 (F, 2))`` or None

@@ -44,8 +44,9 @@ extern "C" {
  * at_stft_fused_supported:  1 if n_fft is a power of two in [32, 2048] (fused wave-FFT kernels: mel stage,
  *                           register reuse, adjoint kernels).
  * at_stft_native_supported: 1 if SOME native kernel covers n_fft: the fused ones, or the generic mixed-radix
- *                           transform (even n_fft <= 16384 with n_fft/2 = 2^a 3^b 5^c: 4096, 8192, 400, 1200, 1920 ...;
- *                           no fused mel: mel_out must be NULL for those sizes).
+ *                           transform (even n_fft <= 16384 with n_fft/2 = 2^a 3^b 5^c 7^d: 4096, 8192, 400, 1200,
+ *                           1920 ...).  Those sizes take the mel tables in BANDED form (at_mel_bands_host) and
+ *                           fuse the mel stage for n_fft <= 8192; mel_out must be NULL beyond that.
  * at_stft_mel_f32:
  *   x          (rows, T) f32
  *   window     (n_fft) f32            AudioSignal.get_window (audio_signal.py:1009-1039)
@@ -60,6 +61,13 @@ extern "C" {
  *              n_units in {128, 256, 384} (padded by the helper)
  *   mel_out    (rows, n_frames_out, n_mels) f32, or NULL
  *
+ *              For the generic sizes (at_stft_fused_supported(n_fft) == 0): the BANDED form built by
+ *              at_mel_bands_host -- mel_unit_info = (n_mels, 3) i32 {first bin, length, offset}, mel_unit_w = the
+ *              concatenated non-zero spans of the filterbank rows, n_units = their total length.
+ *
+ * at_mel_bands_host: HOST helper for that banded form (audio_signal.py:1355-1368: abs + matmul with a basis
+ *   whose rows are >= 97 % zeros).  Call with band == NULL for the weight count, then with band[3 * n_mels] and
+ *   w[count].
  * at_mel_units_host: HOST helper that compresses a dense (n_mels, n_bins) float32 filterbank
  *   (librosa.filters.mel layout, audio_signal.py:1323-1331) into unit tables.  Call with
  *   unit_info == NULL to get the unit count, then again with buffers.  Returns the count (>0)
@@ -69,6 +77,7 @@ int at_stft_twiddles_host(int n_fft, float* out_host);
 int at_stft_native_supported(int n_fft);
 int at_stft_fused_supported(int n_fft);
 int at_mel_units_host(const float* basis_host, int n_mels, int n_bins, int* unit_info_host, float* unit_w_host);
+int at_mel_bands_host(const float* basis_host, int n_mels, int n_bins, int* band_host, float* w_host);
 int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
                     int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,
                     float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,

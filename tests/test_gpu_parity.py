@@ -1135,6 +1135,26 @@ def test_stft_generic_match_stride_and_mel():
     assert rel_err(s2.stft_data, Xr) < REL
 
 
+@pytest.mark.parametrize("sr,n_fft,hop,n_mels", [(96000, 4096, 1024, 80), (192000, 8192, 2048, 128), (16000, 400, 160, 40),
+                                                 (24000, 1200, 300, 80), (48000, 1920, 480, 64), (44100, 882, 441, 20),
+                                                 (96000, 4096, 1000, 7)])
+def test_generic_sizes_fused_mel(sr, n_fft, hop, n_mels):
+    """mel_spectrogram at the transform sizes of csrc/stft_generic.hip: the banded filterbank is applied inside the
+    tiled mixed-radix kernel (audio_signal.py:1355-1368 is abs + a dense matmul over the stored spectrum); odd
+    lengths, edge tiles, band counts from 7 (bands hundreds of bins wide) to 128."""
+    T = 9 * n_fft + 211
+    x = synth.audio_batch(3, 2, T, seed=n_fft + n_mels, gaps=False, sample_rate=sr)
+    s = A.AudioSignal(x.clone(), sr).to("cuda")
+    mel = s.mel_spectrogram(n_mels, window_length=n_fft, hop_length=hop, window_type="hann")
+    Xr = restate.stft(x, n_fft, hop)
+    assert mel.shape == (3, 2, n_mels, Xr.shape[-1])
+    assert rel_err(s.stft_data, Xr) < REL
+    assert rel_err(mel, restate.mel_spectrogram(Xr, sr, n_mels)) < REL
+    # the tiled kernel and the one-frame-per-workgroup kernel of round 2 agree on the spectrum
+    if n_fft <= 8192:
+        assert rel_err(s.stft_data, A.AudioSignal(x.clone(), sr).to("cuda").stft(n_fft, hop, "hann")) < 1e-6
+
+
 @pytest.mark.parametrize("n_fft,T", [(2048, 40000), (512, 9000 + 7)])
 def test_spec_polar_elem_kernel(n_fft, T):
     """Per-element polar edits (csrc/specedit.hip spec_polar_elem_kernel) against the torch

@@ -15,7 +15,7 @@ from audiotools_amd import _native  # noqa: E402
 
 def factor(n):
     radix, ns, s = [], [], 1
-    for r in (5, 3, 7, 4, 2):
+    for r in (25, 5, 9, 3, 7, 16, 8, 4, 2):      # csrc/longconv.hip factor(): composite radices before their primes
         while n % r == 0:
             radix.append(r); ns.append(s); s *= r; n //= r
     assert n == 1

@@ -20,11 +20,12 @@ ap.add_argument("--nfft", type=int, default=2048)
 args = ap.parse_args()
 
 dev = torch.device("cuda")
-B, C, T, SR = args.batch, 2, 441000, args.sr
+B, C, SR = args.batch, 2, args.sr
+T = 10 * SR
 x = (0.1 * torch.randn(B, C, T, device=dev)).clamp_(-1, 1)
 n_fft, hop = args.nfft, args.nfft // 4
 win = tables.window("hann", n_fft, dev)
-info, w = tables.mel_units(SR, n_fft, 80, 0.0, None, dev)
+info, w = tables.mel_units(SR, n_fft, 80, 0.0, None, dev) if kernels.stft_fused_supported(n_fft) else (None, None)
 rows = B * C
 N = 1 + T // hop
 F = n_fft // 2 + 1
@@ -49,6 +50,10 @@ for what in args.what.split(","):
     elif what == "stftmel":
         timeit(lambda: kernels.stft_mel(x, win, n_fft, hop, mel=(info, w, 80)),
                rows * T * 4 + rows * N * F * 8 + rows * N * 80 * 4, "stft+mel")
+    elif what == "genmel":          # generic sizes (--nfft 4096 --sr 96000): banded mel fused into the tiled kernel
+        band, bw = tables.mel_bands(SR, n_fft, 80, 0.0, None, dev)
+        timeit(lambda: kernels.stft_mel(x, win, n_fft, hop, mel=(band, bw, 80)),
+               rows * T * 4 + rows * N * F * 8 + rows * N * 80 * 4, "stft+mel(g)")
     elif what == "melonly":
         timeit(lambda: kernels.stft_mel(x, win, n_fft, hop, want_stft=False, mel=(info, w, 80)),
                rows * T * 4 + rows * N * 80 * 4, "mel-only")
