@@ -330,10 +330,12 @@ __device__ __forceinline__ void run_passes(float2* buf, const float2* tw, int N,
 int generic_fft_plan(int n_fft, int* radix /* [16] */);
 
 // STFT of `n_frames_out` frames per row (same argument meaning as at_stft_mel_f32, no mel).
-// mel_out != null: fused banded mel epilogue (mel_band: (n_mels, 3) {first bin, length, offset}; mel_w: the spans).
+// mel_out != null: fused banded mel epilogue (chunk tables of at_mel_bands_host: mel_chunk (n_chunks) first bins,
+// mel_band (n_mels, 2) {first chunk, count}, mel_w (n_chunks, 16) zero-padded weights).
 int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles, int n_fft, int hop,
                  int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out, float* stft_out,
-                 const int* mel_band, const float* mel_w, int n_mels, float* mel_out, hipStream_t st);
+                 const int* mel_chunk, const int* mel_band, const float* mel_w, int n_chunks, int n_mels, float* mel_out,
+                 hipStream_t st);
 
 // Inverse transform of every frame: X (rows, n_frames, n_fft/2+1) -> windowed frames (rows, n_frames, n_fft),
 // the input of istft_ola_kernel.

@@ -1036,25 +1036,36 @@ int at_mel_units_host(const float* basis, int n_mels, int n_bins, int* unit_info
   return n;
 }
 
-// Host helper: the BANDED form of a dense (n_mels, n_bins) filterbank for the generic-size kernel.  Call with
-// band == NULL to get the number of weights; then band[3 * n_mels] = {first bin, length, offset} and w[count].
-// Rows are cut to their non-zero span (an all-zero row has length 0).
-int at_mel_bands_host(const float* basis, int n_mels, int n_bins, int* band, float* w) {
+// Host helper: the BANDED form of a dense (n_mels, n_bins) filterbank for the generic-size kernel: every row is cut to
+// its non-zero span and the span into CHUNKS of 16 bins.  Call with info == NULL to get the chunk count n; then
+// info[n + 2 * n_mels] = {first bin of every chunk} followed by {first chunk, chunk count} per band, and w[16 * n] = the
+// chunk weights, zero padded (an all-zero row has no chunk).
+int at_mel_bands_host(const float* basis, int n_mels, int n_bins, int* info, float* w) {
   if (!basis || n_mels <= 0 || n_bins <= 0) return AT_ERR_INVALID;
-  int total = 0;
-  for (int m = 0; m < n_mels; ++m) {
-    const float* b = basis + (int64_t)m * n_bins;
-    int lo = -1, hi = -1;
-    for (int k = 0; k < n_bins; ++k)
-      if (b[k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
-    const int len = lo < 0 ? 0 : hi - lo + 1;
-    if (band && w) {
-      band[3 * m] = lo < 0 ? 0 : lo; band[3 * m + 1] = len; band[3 * m + 2] = total;
-      for (int j = 0; j < len; ++j) w[total + j] = b[lo + j];
+  int n = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool fill = pass == 1;
+    const int total = n;
+    n = 0;
+    for (int m = 0; m < n_mels; ++m) {
+      const float* b = basis + (int64_t)m * n_bins;
+      int lo = -1, hi = -1;
+      for (int k = 0; k < n_bins; ++k)
+        if (b[k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+      const int cnt = lo < 0 ? 0 : (hi - lo + 16) / 16;
+      if (fill) { info[total + 2 * m] = n; info[total + 2 * m + 1] = cnt; }
+      for (int c = 0; c < cnt; ++c, ++n) {
+        if (!fill) continue;
+        info[n] = lo + 16 * c;
+        for (int j = 0; j < 16; ++j) {
+          const int k = lo + 16 * c + j;
+          w[16 * n + j] = (k <= hi) ? b[k] : 0.f;
+        }
+      }
     }
-    total += len;
+    if (!info || !w) return n;
   }
-  return total;
+  return n;
 }
 
 int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
@@ -1070,8 +1081,8 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   if (!stft_out) return AT_ERR_INVALID;  // stft_data is always produced (audio_signal.py:1210)
   if (!at_stft_fused_supported(n_fft)) {
     // generic sizes: mixed-radix workgroup FFT (csrc/stft_generic.hip).  Its fused mel stage takes the filterbank in
-    // BANDED form: mel_unit_info = (n_mels, 3) ints {first bin, length, offset into mel_unit_w}, mel_unit_w = the
-    // concatenated non-zero spans of the rows, n_units = their total length (at_mel_bands_host builds them).
+    // BANDED form (at_mel_bands_host): mel_unit_info = n_units first bins of 16-bin chunks, then {first chunk, count} per
+    // band; mel_unit_w = (n_units, 16) zero-padded chunk weights.
     if (mel && (!mel_unit_info || !mel_unit_w || n_units <= 0 || n_mels <= 0 || n_fft / 2 > 4096)) return AT_ERR_UNSUPPORTED;
     const int64_t T2g = T + 2 * (int64_t)pad + right_pad;
     if (n_fft / 2 >= T2g) return AT_ERR_INVALID;
@@ -1080,8 +1091,8 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
     if (T >= (1LL << 31) || n_frames_out >= (1LL << 31) / (n_fft / 2 + 1)) return AT_ERR_UNSUPPORTED;
     if (n_frames_out == 0) return AT_OK;
     return at::stft_generic(x, rows, T, window, twiddles, n_fft, hop, pad, right_pad, pad_mode, frame_lo, n_frames_out,
-                            stft_out, mel_unit_info, mel_unit_w, n_mels, mel ? mel_out : nullptr,
-                            reinterpret_cast<hipStream_t>(stream));
+                            stft_out, mel_unit_info, mel ? mel_unit_info + n_units : nullptr, mel_unit_w, n_units, n_mels,
+                            mel ? mel_out : nullptr, reinterpret_cast<hipStream_t>(stream));
   }
   if (mel && (!mel_unit_info || !mel_unit_w || (n_units != 128 && n_units != 256 && n_units != 384) || n_mels <= 0))
     return AT_ERR_INVALID;

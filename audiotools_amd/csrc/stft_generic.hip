@@ -131,58 +131,96 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(const GenArgs A) {
 //  * a workgroup transforms FB frames at once (2 for M <= 2048): the batched in-place passes of
 //    generic_fft.h keep all 256 threads busy on the radix-16 / 25 passes (one frame of 2048 points
 //    has only 128 radix-16 butterflies), one LDS buffer instead of two, composite radices: three
-//    passes for 2048 / 4096 points instead of six;
-//  * persistent workgroups walk RUNS of consecutive frames of one row inside their XCD's span of the
-//    (row, frame) space, so the 4x overlap between neighbouring frames is served by L1 / that XCD's
+//    passes for 2048 / 4096 points instead of six (PLAN 1 / 2: the pass list is compile-time for the
+//    reference's 96 / 192 kHz windows, no run-time dispatch, no plan in SGPRs);
+//  * persistent workgroups walk RUNS of consecutive tiles of one row inside their XCD's span of the
+//    (row, tile) space, so the 4x overlap between neighbouring frames is served by L1 / that XCD's
 //    L2 and HBM sees every sample once (the round-2 kernel dealt frames round-robin over the XCDs:
 //    each of them re-read the overlap, input traffic = output traffic);
-//  * the samples of the next tile are loaded into registers before the passes of the current one;
+//  * THE ONLY VECTOR-MEMORY OPERATIONS OF A TILE are the next tile's sample loads (always issued,
+//    address clamped, before the passes) and this tile's stores, in that order, and the first tile of a
+//    run is peeled: vmcnt retires in order and the compiler counts only what every path issues, so the
+//    head of the loop waits for the loads and leaves the stores in flight.  Window, pass twiddles
+//    and the mel tables live in LDS; the split twiddle w_N^k is w_M^(k >> 1) times w_N^1 for odd k.
+//    (The first version loaded window / twiddles / band weights from L2 behind the stores and guarded
+//    the prefetch: every tile began by draining its predecessor's stores -- 24 us per tile, 16 % of HBM.)
 //  * every bin X[k], k = 0..M, comes from ONE formula on (Z[k mod M], Z[(M - k) mod M], w_N^k) -- DC and
-//    Nyquist included -- in a single ascending sweep: 512-byte store segments, no special cases;
+//    Nyquist included -- in a single ascending sweep: 512-byte store segments, no special cases.  A
+//    row with an odd frame count repeats its last-but-one frame in the last tile (same values stored
+//    twice) instead of carrying a dead frame;
 //  * optional fused mel epilogue (audio_signal.py:1355-1368): |X| goes to LDS (over the transform
-//    buffer) and every (frame, band) pair is a 16-lane dot product over the band's non-zero span
-//    (banded tables: {first bin, length, weight offset} per band) -- no second pass over stft_data,
-//    no dense matmul.
+//    buffer); the banded filterbank is cut into CHUNKS of 16 bins, every thread forms chunk dot
+//    products (weights and magnitudes as ds_read_b128), the partial sums meet in LDS and one thread per
+//    (frame, band) adds its band's chunks in order (deterministic).  No second pass over stft_data, no
+//    dense matmul.
 struct Gen2Args {
   const float* x;
   const float* window;
   const float2* tw;        // (N): (cos, -sin)(2 pi k / N)
   float2* out;             // (rows, n_out, M + 1)
   float* mel;              // (rows, n_out, n_mels) or null
-  const int* band;         // (n_mels, 3): first bin, length, offset into bw
-  const float* bw;         // concatenated non-zero spans of the filterbank rows
+  const int* chunk;        // mel: (n_chunks) first bin of every 16-bin chunk
+  const int* band;         // mel: (n_mels, 2) {first chunk, chunk count}
+  const float* cw;         // mel: (n_chunks, 16) weights, zero padded
   int64_t T, T2, rows, n_out;
   int64_t tiles_per_row, total_tiles;
   int frame_lo, hop, pad, pad_mode;
-  int M, FB, n_mels, run, n_xcd, vec2;
+  int M, FB, n_mels, n_chunks, run, n_xcd, vec2;
   at::gfft::PassList pl;
 };
 
 constexpr int G2_LOADS = at::gfft::TILE_POINTS / 256;     // float2 samples of a tile per thread
+constexpr int G2_KB = at::gfft::TILE_POINTS / 256 + 1;    // bins of a tile per thread (FB (M + 1) <= 4098)
 
-__global__ __launch_bounds__(256, 3) void stft_generic_tiled_kernel(const Gen2Args A) {
+template <int PLAN /* 0: run-time pass list; 1: M = 2048 as 16 16 8 (two frames); 2: M = 4096 as 16 16 16 */>
+__global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Args A) {
   extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
-  const int M = A.M, N = 2 * M, FB = A.FB;
-  float2* buf = gbuf;                 // [FB][M]
-  float2* tw = gbuf + FB * M;         // [M]: w_M^t
-  float* mag = reinterpret_cast<float*>(gbuf);   // [FB][M + 1], over the transform buffer once Z is consumed
-  for (int i = threadIdx.x; i < M; i += 256) tw[i] = A.tw[2 * i];
+  const int M = PLAN == 1 ? 2048 : (PLAN == 2 ? 4096 : A.M);
+  const int FB = PLAN == 1 ? 2 : (PLAN == 2 ? 1 : A.FB);
+  const int N = 2 * M;
+  float2* buf = gbuf;                             // [FB][M]
+  float2* tw = gbuf + FB * M;                     // [M]: w_M^t
+  float2* win = tw + M;                           // [M]: window pairs
+  float* melw = reinterpret_cast<float*>(win + M);             // [n_chunks][16]
+  int* mtab = reinterpret_cast<int*>(melw + 16 * A.n_chunks);  // [n_chunks] first bins, then [n_mels][2]
+  float* part = reinterpret_cast<float*>(mtab + A.n_chunks + 2 * A.n_mels);   // [FB][n_chunks] partial sums
+  float* mag = reinterpret_cast<float*>(gbuf);    // [FB][M + 1] (+ slack), over the transform buffer once Z is consumed
+  const bool MEL = A.mel != nullptr;
+  for (int i = threadIdx.x; i < M; i += 256) {
+    tw[i] = A.tw[2 * i];
+    win[i] = reinterpret_cast<const float2*>(A.window)[i];
+  }
+  if (MEL) {
+    for (int i = threadIdx.x; i < 16 * A.n_chunks; i += 256) melw[i] = A.cw[i];
+    for (int i = threadIdx.x; i < A.n_chunks; i += 256) mtab[i] = A.chunk[i];
+    for (int i = threadIdx.x; i < 2 * A.n_mels; i += 256) mtab[A.n_chunks + i] = A.band[i];
+  }
+  const float2 w1 = A.tw[1];                      // w_N^1
+  __syncthreads();
   const at::gfft::RowLayout lay{M};
-  const int npts = FB * M;
+  const int npts = FB * M, nbins = FB * (M + 1);
+  const int Ti = (int)A.T, n_out = (int)A.n_out, tpr = (int)A.tiles_per_row, hop = A.hop;
 
-  // persistent schedule: one contiguous span of tiles per XCD, runs of A.run tiles per workgroup
   const int n_x = (int)gridDim.x < A.n_xcd ? (int)gridDim.x : A.n_xcd;
   const int xcd = blockIdx.x % n_x, lblk = blockIdx.x / n_x;
   const int nblk_x = ((int)gridDim.x - xcd + n_x - 1) / n_x;
   const int64_t g_lo = A.total_tiles * xcd / n_x, g_hi = A.total_tiles * (xcd + 1) / n_x;
 
-  float2 r[G2_LOADS];
-  const int Ti = (int)A.T, n_out = (int)A.n_out, tpr = (int)A.tiles_per_row, hop = A.hop;
-  // tile g = (row, t): frames f0 = t FB .. f0 + FB - 1; s0 = first sample of frame f0 (outer-padded coordinates)
-  auto interior = [&](int f0, int s0) {
-    return A.vec2 && A.pad == 0 && s0 >= 0 && s0 + (FB - 1) * hop + N <= Ti && f0 + FB <= n_out;
+  // tile g = (row, t): frames f0 .. f0 + FB - 1 with f0 = min(t FB, n_out - FB); s0 = first sample of frame f0
+  auto geom = [&](int64_t g, int& row, int& f0, int& s0) {
+    row = (int)(g / tpr);
+    f0 = min((int)(g - (int64_t)row * tpr) * FB, n_out - FB);
+    s0 = (f0 + A.frame_lo) * hop - M;
   };
-  auto fetch = [&](const float* __restrict__ xs, int tid) __attribute__((always_inline)) {     // xs = x row + s0
+  auto interior = [&](int s0) { return A.vec2 && A.pad == 0 && s0 >= 0 && s0 + (FB - 1) * hop + N <= Ti; };
+  float2 r[G2_LOADS];
+  // the samples of a tile: ALWAYS issued (a tile that is not interior, or no tile at all, reads the row start --
+  // T >= N + hop is a launch condition of this kernel -- and the values are ignored)
+  auto fetch = [&](int64_t g, bool valid, int tid) __attribute__((always_inline)) {
+    int row = 0, f0 = 0, s0 = 0;
+    if (valid) geom(g, row, f0, s0);
+    const bool ok = valid && interior(s0);
+    const float* __restrict__ xs = A.x + (int64_t)row * A.T + (ok ? s0 : 0);
 #pragma unroll
     for (int i = 0; i < G2_LOADS; ++i) {
       if (256 * i < npts) {                               // uniform; lanes past the end repeat the last point
@@ -192,107 +230,116 @@ __global__ __launch_bounds__(256, 3) void stft_generic_tiled_kernel(const Gen2Ar
       }
     }
   };
-  constexpr int KB = at::gfft::TILE_POINTS / 256 + 1;     // bins of a tile per thread (FB (M + 1) <= 4098)
-  const int nbins = FB * (M + 1);
+
+  auto tile = [&](int64_t g, int64_t g_end) __attribute__((always_inline)) {
+    // opaque copy of the thread index per tile: nothing indexed by it is hoisted out of the persistent loops
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    int row, f0, s0;
+    geom(g, row, f0, s0);
+    const float* __restrict__ xr = A.x + (int64_t)row * A.T;
+    // ---- windowed samples -> LDS
+    if (interior(s0)) {
+#pragma unroll
+      for (int i = 0; i < G2_LOADS; ++i) {
+        if (256 * i < npts) {
+          const int e = min(tid + 256 * i, npts - 1);
+          const float2 w = win[e >= M ? e - M : e];
+          buf[e] = make_float2(r[i].x * w.x, r[i].y * w.y);
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int e = tid; e < npts; e += 256) {
+        const int fi = e >= M ? 1 : 0, n = e - fi * M;
+        const int64_t sidx = (int64_t)s0 + fi * hop + 2 * n;
+        const float2 w = win[n];
+        buf[e] = make_float2(at::fetch_padded(xr, sidx, A.T, A.T2, A.pad, A.pad_mode) * w.x,
+                             at::fetch_padded(xr, sidx + 1, A.T, A.T2, A.pad, A.pad_mode) * w.y);
+      }
+    }
+    __syncthreads();
+    fetch(g + 1, g + 1 < g_end, tid);                     // the next tile's samples: in flight during the passes
+    if constexpr (PLAN == 1) {
+      at::gfft::pass_inplace<16, 1, 256>(buf, tw, 2048, 1, 256, lay);
+      at::gfft::pass_inplace<16, 1, 256>(buf, tw, 2048, 16, 256, lay);
+      at::gfft::pass_inplace<8, 2, 256>(buf, tw, 2048, 256, 512, lay);
+    } else if constexpr (PLAN == 2) {
+      at::gfft::pass_inplace<16, 1, 256>(buf, tw, 4096, 1, 256, lay);
+      at::gfft::pass_inplace<16, 1, 256>(buf, tw, 4096, 16, 256, lay);
+      at::gfft::pass_inplace<16, 1, 256>(buf, tw, 4096, 256, 256, lay);
+    } else {
+      at::gfft::run_passes<256>(buf, tw, M, A.pl, FB, lay);
+    }
+    // ---- split step, one ascending sweep over k = 0 .. M per frame; |X| kept for the mel stage
+    float mg[G2_KB];
+    float2* __restrict__ orow = A.out + ((int64_t)row * n_out + f0) * (M + 1);
+#pragma unroll
+    for (int it = 0; it < G2_KB; ++it) {
+      const int e = tid + 256 * it;
+      mg[it] = 0.f;
+      if (it < G2_KB - 1 || e < nbins) {                  // only the last slot can lie past the tile
+        const int ec = min(e, nbins - 1);
+        const int fi = ec >= M + 1 ? 1 : 0, k = ec - fi * (M + 1);
+        const float2 zk = buf[fi * M + (k == M ? 0 : k)], zm = buf[fi * M + ((k == 0 || k == M) ? 0 : M - k)];
+        float2 w = tw[k == M ? 0 : (k >> 1)];
+        if (k == M) w = make_float2(-1.f, 0.f);           // w_N^M
+        else if (k & 1) w = at::gfft::cmulf(w, w1);       // w_N^k = w_M^(k >> 1) w_N^1
+        const float c = w.x, sn = -w.y;
+        const float sr = zk.x + zm.x, si = zk.y - zm.y;
+        const float dr = zk.x - zm.x, di = zk.y + zm.y;
+        const float pp = fmaf(sn, dr, -c * di);
+        const float qq = fmaf(sn, di, c * dr);
+        float2 X = make_float2(0.5f * (sr - pp), 0.5f * (si - qq));
+        if (k == 0 || k == M) X.y = 0.f;                  // exactly real
+        if (it < G2_KB - 1) orow[e] = X;                  // frame f0 + 1 follows frame f0: e indexes both rows
+        else if (e < nbins) orow[e] = X;
+        mg[it] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));
+      }
+    }
+    if (MEL) {
+      __syncthreads();                                    // every Z has been read: the buffer becomes |X|
+#pragma unroll
+      for (int it = 0; it < G2_KB; ++it) {
+        const int e = tid + 256 * it;
+        if (e < nbins) mag[e] = mg[it];
+      }
+      __syncthreads();
+      const int nch = A.n_chunks;
+#pragma unroll 1
+      for (int task = tid; task < FB * nch; task += 256) {
+        const int fi = task >= nch ? 1 : 0, c = task - fi * nch;
+        const float* __restrict__ mrow = mag + fi * (M + 1) + mtab[c];
+        const float4* __restrict__ wq = reinterpret_cast<const float4*>(melw + 16 * c);
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 w = wq[q];
+          acc = fmaf(w.x, mrow[4 * q], acc);
+          acc = fmaf(w.y, mrow[4 * q + 1], acc);
+          acc = fmaf(w.z, mrow[4 * q + 2], acc);
+          acc = fmaf(w.w, mrow[4 * q + 3], acc);
+        }
+        part[task] = acc;
+      }
+      __syncthreads();
+      float* __restrict__ mel0 = A.mel + ((int64_t)row * n_out + f0) * A.n_mels;
+      for (int task = tid; task < FB * A.n_mels; task += 256) {
+        const int fi = task >= A.n_mels ? 1 : 0, m = task - fi * A.n_mels;
+        const int c0 = mtab[nch + 2 * m], cn = mtab[nch + 2 * m + 1];
+        float acc = 0.f;
+        for (int c = 0; c < cn; ++c) acc += part[fi * nch + c0 + c];
+        mel0[task] = acc;                                 // (frame fi, band m) -> fi * n_mels + m = task
+      }
+    }
+    __syncthreads();                                      // the buffer is free for the next tile
+  };
 
   for (int64_t gbase = g_lo + (int64_t)lblk * A.run; gbase < g_hi; gbase += (int64_t)nblk_x * A.run) {
     const int64_t g_end = min(gbase + A.run, g_hi);
-    bool have = false;
-    for (int64_t g = gbase; g < g_end; ++g) {
-      // opaque copy of the thread index per tile: nothing indexed by it is hoisted out of the persistent loops
-      // (the 17 unrolled bin slots and every pass variant would otherwise keep their addresses live: 800 B of spills)
-      int tid = (int)threadIdx.x;
-      asm volatile("" : "+v"(tid));
-      const int row = (int)(g / tpr);
-      const int f0 = (int)(g - (int64_t)row * tpr) * FB;
-      const int s0 = (f0 + A.frame_lo) * hop - M;
-      const float* __restrict__ xr = A.x + (int64_t)row * A.T;
-      const bool fast = interior(f0, s0);
-      if (fast && !have) fetch(xr + s0, tid);
-      // ---- windowed samples -> LDS
-      if (fast) {
-        const float2* __restrict__ w2 = reinterpret_cast<const float2*>(A.window);
-#pragma unroll
-        for (int i = 0; i < G2_LOADS; ++i) {
-          if (256 * i < npts) {
-            const int e = min(tid + 256 * i, npts - 1);
-            const int n = e >= M ? e - M : e;
-            const float2 w = w2[n];
-            buf[e] = make_float2(r[i].x * w.x, r[i].y * w.y);
-          }
-        }
-      } else {
-#pragma unroll 1
-        for (int e = tid; e < npts; e += 256) {
-          const int fi = e >= M ? 1 : 0, n = e - fi * M;
-          float a = 0.f, b = 0.f;
-          if (f0 + fi < n_out) {
-            const int64_t sidx = (int64_t)s0 + fi * hop + 2 * n;
-            a = at::fetch_padded(xr, sidx, A.T, A.T2, A.pad, A.pad_mode);
-            b = at::fetch_padded(xr, sidx + 1, A.T, A.T2, A.pad, A.pad_mode);
-          }
-          buf[e] = make_float2(a * A.window[2 * n], b * A.window[2 * n + 1]);
-        }
-      }
-      __syncthreads();
-      // ---- the next tile's samples: issued now, consumed after this tile's stores
-      have = false;
-      if (g + 1 < g_end) {
-        const int row2 = (int)((g + 1) / tpr);
-        const int f02 = (int)(g + 1 - (int64_t)row2 * tpr) * FB;
-        const int s02 = (f02 + A.frame_lo) * hop - M;
-        if (interior(f02, s02)) { fetch(A.x + (int64_t)row2 * A.T + s02, tid); have = true; }
-      }
-      at::gfft::run_passes<256>(buf, tw, M, A.pl, FB, lay);
-      // ---- split step, one ascending sweep over k = 0 .. M per frame; |X| kept for the mel stage
-      float mg[KB];
-      float2* __restrict__ orow = A.out + ((int64_t)row * n_out + f0) * (M + 1);
-#pragma unroll
-      for (int it = 0; it < KB; ++it) {
-        const int e = tid + 256 * it;
-        mg[it] = 0.f;
-        if (e < nbins) {
-          const int fi = e >= M + 1 ? 1 : 0, k = e - fi * (M + 1);
-          const float2 zk = buf[fi * M + (k == M ? 0 : k)], zm = buf[fi * M + ((k == 0 || k == M) ? 0 : M - k)];
-          const float2 w = A.tw[k];
-          const float c = w.x, sn = -w.y;
-          const float sr = zk.x + zm.x, si = zk.y - zm.y;
-          const float dr = zk.x - zm.x, di = zk.y + zm.y;
-          const float pp = fmaf(sn, dr, -c * di);
-          const float qq = fmaf(sn, di, c * dr);
-          float2 X = make_float2(0.5f * (sr - pp), 0.5f * (si - qq));
-          if (k == 0 || k == M) X.y = 0.f;                   // exactly real
-          if (f0 + fi < n_out) orow[e] = X;                  // frame f0 + 1 follows frame f0: e indexes both rows
-          mg[it] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));
-        }
-      }
-      if (A.mel != nullptr) {
-        __syncthreads();                                      // every Z has been read: the buffer becomes |X|
-#pragma unroll
-        for (int it = 0; it < KB; ++it) {
-          const int e = tid + 256 * it;
-          if (e < nbins) mag[e] = mg[it];
-        }
-        __syncthreads();
-        const int grp = tid >> 4, l16 = tid & 15;
-        float* __restrict__ mel0 = A.mel + ((int64_t)row * n_out + f0) * A.n_mels;
-#pragma unroll 1
-        for (int task = grp; task < FB * A.n_mels; task += 16) {
-          const int fi = task >= A.n_mels ? 1 : 0, m = task - fi * A.n_mels;
-          const int lo = A.band[3 * m], len = A.band[3 * m + 1], off = A.band[3 * m + 2];
-          const float* __restrict__ mrow = mag + fi * (M + 1) + lo;
-          const float* __restrict__ wrow = A.bw + off;
-          float acc = 0.f;
-          for (int j = l16; j < len; j += 16) acc = fmaf(wrow[j], mrow[j], acc);
-          acc += __shfl_xor(acc, 8, 16);
-          acc += __shfl_xor(acc, 4, 16);
-          acc += __shfl_xor(acc, 2, 16);
-          acc += __shfl_xor(acc, 1, 16);
-          if (l16 == 0 && f0 + fi < n_out) mel0[task] = acc;      // (frame fi, band m) -> fi * n_mels + m = task
-        }
-      }
-      __syncthreads();                                        // the buffer is free for the next tile
-    }
+    fetch(gbase, true, (int)threadIdx.x);
+    tile(gbase, g_end);                                   // peeled: both edges of the loop below carry "loads, then stores"
+    for (int64_t g = gbase + 1; g < g_end; ++g) tile(g, g_end);
   }
 }
 
@@ -352,25 +399,37 @@ static int grid_for(int64_t frames) {
 
 int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles, int n_fft, int hop,
                  int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out, float* stft_out,
-                 const int* mel_band, const float* mel_w, int n_mels, float* mel_out, hipStream_t st) {
+                 const int* mel_chunk, const int* mel_band, const float* mel_w, int n_chunks, int n_mels, float* mel_out,
+                 hipStream_t st) {
   static const int force_old = env_int_once("AT_STFT_GENERIC_OLD", 0);    // A/B: the round-2 one-frame-per-workgroup kernel
-  if (n_fft / 2 <= gfft::TILE_POINTS && !(force_old && mel_out == nullptr)) {
+  const int M = n_fft / 2;
+  const int FBv = M <= gfft::TILE_POINTS / 2 ? 2 : 1;
+  // the tiled kernel needs FB whole frames per row and an interior position for its clamped prefetch
+  const bool tiled_ok = M <= gfft::TILE_POINTS && n_frames_out >= FBv && T >= (int64_t)n_fft + (int64_t)(FBv - 1) * hop &&
+                        (int64_t)n_frames_out * hop + n_fft < (1LL << 31);
+  if (tiled_ok && !(force_old && mel_out == nullptr)) {
     Gen2Args G;
-    if (!gfft::factor(n_fft / 2, &G.pl)) return AT_ERR_UNSUPPORTED;
+    if (!gfft::factor(M, &G.pl)) return AT_ERR_UNSUPPORTED;
     G.x = x; G.window = window; G.tw = reinterpret_cast<const float2*>(twiddles); G.out = reinterpret_cast<float2*>(stft_out);
-    G.mel = mel_out; G.band = mel_band; G.bw = mel_w; G.n_mels = mel_out ? n_mels : 0;
+    G.mel = mel_out; G.chunk = mel_chunk; G.band = mel_band; G.cw = mel_w;
+    G.n_mels = mel_out ? n_mels : 0; G.n_chunks = mel_out ? n_chunks : 0;
     G.T = T; G.T2 = T + 2 * (int64_t)pad + right_pad; G.rows = rows; G.n_out = n_frames_out;
-    G.frame_lo = frame_lo; G.hop = hop; G.pad = pad; G.pad_mode = pad_mode; G.M = n_fft / 2;
-    G.FB = G.M <= gfft::TILE_POINTS / 2 ? 2 : 1;
+    G.frame_lo = frame_lo; G.hop = hop; G.pad = pad; G.pad_mode = pad_mode; G.M = M; G.FB = FBv;
     G.tiles_per_row = (n_frames_out + G.FB - 1) / G.FB;
     G.total_tiles = rows * G.tiles_per_row;
-    G.vec2 = ((T % 2) == 0 && (hop % 2) == 0 && (G.M % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 8) == 0) ? 1 : 0;
-    const size_t lds = ((size_t)G.FB * G.M + G.M) * sizeof(float2) + 16;     // + the Nyquist column of the |X| rows
-    int e = allow_big_lds(reinterpret_cast<const void*>(stft_generic_tiled_kernel));
+    G.vec2 = ((T % 2) == 0 && (hop % 2) == 0 && (M % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 8) == 0) ? 1 : 0;
+    size_t lds = ((size_t)G.FB * M + 2 * (size_t)M) * sizeof(float2) + 64;       // transform buffer (+ |X| slack), twiddles, window
+    if (mel_out) lds += (size_t)G.n_chunks * (16 + 1 + G.FB) * 4 + (size_t)2 * n_mels * 4;
+    if (lds > 160 * 1024) return AT_ERR_UNSUPPORTED;
+    const int plan = (M == 2048 && G.FB == 2) ? 1 : (M == 4096 ? 2 : 0);
+    const void* kfn = plan == 1 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<1>)
+                    : plan == 2 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<2>)
+                                : reinterpret_cast<const void*>(stft_generic_tiled_kernel<0>);
+    int e = allow_big_lds(kfn);
     if (e != AT_OK) return e;
     const int n_cu = device_cu_count();
     int per_cu = (int)((160 * 1024) / lds);
-    per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
+    per_cu = per_cu > 2 ? 2 : (per_cu < 1 ? 1 : per_cu);
     int64_t blocks = (int64_t)n_cu * per_cu;
     if (blocks > G.total_tiles) blocks = G.total_tiles;
     int auto_x = n_cu / 32;
@@ -385,7 +444,9 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
       int64_t run = (per_wg + runs - 1) / (runs > 0 ? runs : 1);
       G.run = (int)(run < 1 ? 1 : run);
     }
-    hipLaunchKernelGGL(stft_generic_tiled_kernel, dim3((unsigned)blocks), dim3(256), lds, st, G);
+    if (plan == 1) hipLaunchKernelGGL(stft_generic_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+    else if (plan == 2) hipLaunchKernelGGL(stft_generic_tiled_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+    else hipLaunchKernelGGL(stft_generic_tiled_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, st, G);
     AT_LAUNCH_CHECK();
     return AT_OK;
   }

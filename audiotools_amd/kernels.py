@@ -81,8 +81,8 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
     n_units = n_mels = 0
     if mel is not None:
         info, w, n_mels = mel
-        # fused sizes: unit tables (n_units rows of 2 ints); generic sizes: banded tables (n_units = number of weights)
-        n_units = int(info.shape[0]) if stft_fused_supported(n_fft) else int(w.numel())
+        # fused sizes: unit tables (n_units rows of 2 ints); generic sizes: banded tables (n_units = number of 16-bin chunks)
+        n_units = int(info.shape[0]) if stft_fused_supported(n_fft) else int(w.shape[0])
         mel_buf = torch.empty((B, C, n_out, n_mels), dtype=torch.float32, device=dev)
     code = _native.lib().at_stft_mel_f32(
         _native.ptr(audio), B * C, T, _native.ptr(window), _native.ptr(tw), n_fft, hop, pad, right_pad,

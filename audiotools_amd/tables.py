@@ -259,18 +259,19 @@ def mel_units(sr, n_fft, n_mels, fmin, fmax, device):
 
 def mel_bands_np(basis: np.ndarray):
     """BANDED form of a dense (n_mels, F) filterbank for the generic-size fused mel stage (``at_mel_bands_host``):
-    ``(band int32 (n_mels, 3) = {first bin, length, offset into w}, w float32 (total,))``."""
+    every row cut to its non-zero span, the span into chunks of 16 bins.  Returns ``(info int32 (n_chunks + 2 n_mels,),
+    w float32 (n_chunks, 16))``: the first bin of every chunk, then ``{first chunk, chunk count}`` per band."""
     basis = np.ascontiguousarray(basis, dtype=np.float32)
     n_mels, F = basis.shape
     lib = _native.lib()
-    total = int(lib.at_mel_bands_host(basis.ctypes.data, n_mels, F, None, None))
-    if total < 0:
-        _native.check(total, "at_mel_bands_host")
-    band = np.zeros((n_mels, 3), dtype=np.int32)
-    w = np.zeros(max(total, 1), dtype=np.float32)
-    got = int(lib.at_mel_bands_host(basis.ctypes.data, n_mels, F, band.ctypes.data, w.ctypes.data))
-    assert got == total
-    return band, w
+    n = int(lib.at_mel_bands_host(basis.ctypes.data, n_mels, F, None, None))
+    if n < 0:
+        _native.check(n, "at_mel_bands_host")
+    info = np.zeros(n + 2 * n_mels, dtype=np.int32)
+    w = np.zeros((max(n, 1), 16), dtype=np.float32)
+    got = int(lib.at_mel_bands_host(basis.ctypes.data, n_mels, F, info.ctypes.data, w.ctypes.data))
+    assert got == n
+    return info, w
 
 
 def mel_bands(sr, n_fft, n_mels, fmin, fmax, device):

@@ -62,12 +62,13 @@ extern "C" {
  *   mel_out    (rows, n_frames_out, n_mels) f32, or NULL
  *
  *              For the generic sizes (at_stft_fused_supported(n_fft) == 0): the BANDED form built by
- *              at_mel_bands_host -- mel_unit_info = (n_mels, 3) i32 {first bin, length, offset}, mel_unit_w = the
- *              concatenated non-zero spans of the filterbank rows, n_units = their total length.
+ *              at_mel_bands_host -- every filterbank row cut to its non-zero span and the span into chunks of 16
+ *              bins: mel_unit_info = n_units first bins (one per chunk) followed by {first chunk, count} per band
+ *              (n_units + 2 * n_mels i32), mel_unit_w = (n_units, 16) zero-padded chunk weights.
  *
  * at_mel_bands_host: HOST helper for that banded form (audio_signal.py:1355-1368: abs + matmul with a basis
- *   whose rows are >= 97 % zeros).  Call with band == NULL for the weight count, then with band[3 * n_mels] and
- *   w[count].
+ *   whose rows are >= 97 % zeros).  Call with info == NULL for the chunk count n, then with info[n + 2 * n_mels]
+ *   and w[16 * n].
  * at_mel_units_host: HOST helper that compresses a dense (n_mels, n_bins) float32 filterbank
  *   (librosa.filters.mel layout, audio_signal.py:1323-1331) into unit tables.  Call with
  *   unit_info == NULL to get the unit count, then again with buffers.  Returns the count (>0)
@@ -77,7 +78,7 @@ int at_stft_twiddles_host(int n_fft, float* out_host);
 int at_stft_native_supported(int n_fft);
 int at_stft_fused_supported(int n_fft);
 int at_mel_units_host(const float* basis_host, int n_mels, int n_bins, int* unit_info_host, float* unit_w_host);
-int at_mel_bands_host(const float* basis_host, int n_mels, int n_bins, int* band_host, float* w_host);
+int at_mel_bands_host(const float* basis_host, int n_mels, int n_bins, int* info_host, float* w_host);
 int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
                     int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,
                     float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,

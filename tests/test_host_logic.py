@@ -1,5 +1,6 @@
 """Host-side logic of the drop-in API on CPU tensors (torch path): container semantics,
 table design against the oracle leaves, cache invalidation rules."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -190,3 +191,53 @@ def test_device_stager_passthrough_and_order():
     got = [b.clone() for b in DeviceStager(batches, "cpu")]
     assert len(got) == 5 and all(torch.equal(g, b) for g, b in zip(got, batches))
     assert list(DeviceStager([], "cpu")) == []
+
+
+def test_mixed_radix_butterflies_on_host(tmp_path):
+    """Every radix butterfly of csrc/generic_fft.h (2, 3, 4, 5, 7 and the composite 8, 9, 16, 25) against an O(R^2)
+    float64 DFT: the gfft namespace is lifted out of the header and compiled for the HOST with g++ (the device
+    qualifiers defined away), so the constants and the index algebra are checked without a GPU."""
+    import re
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "audiotools_amd", "csrc", "generic_fft.h")).read()
+    body = src[src.index("namespace gfft {"): src.index("// ---- in-place mixed-radix passes over an LDS tile")] + "}\n"
+    prog = r"""
+#include <cmath>
+#include <cstdio>
+#include <complex>
+#include <random>
+struct float2 { float x, y; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+#define __device__
+#define __forceinline__ inline
+""" + body + r"""
+using namespace gfft;
+template <int R> double check() {
+  std::mt19937 g(R); std::normal_distribution<float> d;
+  float2 v[MAX_RADIX]; std::complex<double> x[MAX_RADIX];
+  for (int i = 0; i < R; ++i) { v[i] = make_float2(d(g), d(g)); x[i] = {v[i].x, v[i].y}; }
+  dft_r<R>(v);
+  double worst = 0;
+  for (int k = 0; k < R; ++k) {
+    std::complex<double> s = 0;
+    for (int n = 0; n < R; ++n) s += x[n] * std::polar(1.0, -2.0 * M_PI * k * n / R);
+    worst = std::fmax(worst, std::abs(s - std::complex<double>(v[k].x, v[k].y)));
+  }
+  return worst;
+}
+int main() {
+  printf("%.3e %.3e %.3e %.3e %.3e %.3e %.3e %.3e %.3e\n", check<2>(), check<3>(), check<4>(), check<5>(), check<7>(),
+         check<8>(), check<9>(), check<16>(), check<25>());
+}
+"""
+    cpp = tmp_path / "dft.cpp"
+    cpp.write_text(prog)
+    exe = tmp_path / "dft"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", str(exe), str(cpp)])
+    errs = [float(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert len(errs) == 9 and max(errs) < 5e-6, errs
