@@ -227,29 +227,54 @@ struct ColLayout {          // tile[point][column]
   int lcw, cmask;
   __device__ __forceinline__ void split(int id, int nb, int& batch, int& j) const { batch = id & cmask; j = id >> lcw; (void)nb; }
   __device__ __forceinline__ int addr(int batch, int p) const { return (p << lcw) + batch; }
-  __device__ __forceinline__ int step(int ns) const { return ns << lcw; }
 };
 struct RowLayout {          // buf[row slot][point]
   int N;
+  // sw != 0 (N a multiple of 16): XOR swizzle of the low 4 bits with the next 4 -- a permutation inside every
+  // 16-block, so contiguous reads stay conflict-free, and the stride-16 stores of a first radix-16 pass (NS = 1:
+  // lane j writes points 16 j + q) land on 16 distinct bank pairs instead of one (65 % of the LDS cycles of the
+  // first tiled STFT kernel were bank conflicts, profiles/r03_notes.md)
+  int sw;
   __device__ __forceinline__ void split(int id, int nb, int& batch, int& j) const { batch = id >= nb ? 1 : 0; j = id - (batch ? nb : 0); }
-  __device__ __forceinline__ int addr(int batch, int p) const { return batch * N + p; }
-  __device__ __forceinline__ int step(int ns) const { return ns; }
+  __device__ __forceinline__ int addr(int batch, int p) const { return batch * N + (sw ? (p ^ ((p >> 4) & 15)) : p); }
 };
 
+// Per-pass twiddle blocks.  A pass of radix R behind NS = (product of the earlier radices) multiplies input q of the
+// butterfly with k = j mod NS by w_{NS R}^{k q}.  Gathering these from ONE table w_N^t (index k q N / (NS R)) is a
+// power-of-two stride across the lanes for every power-of-two NS R: up to 16-way LDS bank conflicts per read (half of
+// rowconv's LDS cycles).  The blocks hold, for every pass with NS > 1, the (R - 1) x NS values in the order the lanes
+// read them -- [q - 1][k], consecutive k in consecutive lanes -- one after the other: sum NS (R - 1) < N entries, the
+// size of the plain table.
+template <int NT>
+__device__ __forceinline__ void build_pass_twiddles(float2* __restrict__ dst, const float2* __restrict__ src, int src_stride,
+                                                    int N, const PassList& pl) {
+  int off = 0;
+  for (int p = 0; p < pl.n; ++p) {
+    const int R = pl.radix[p], NS = pl.ns[p];
+    if (NS <= 1) continue;
+    const int tstep = N / (NS * R), cnt = NS * (R - 1);
+    for (int idx = threadIdx.x; idx < cnt; idx += NT) {
+      const int q1 = idx / NS, k = idx - q1 * NS;
+      dst[off + idx] = src[(int64_t)(k * (q1 + 1) * tstep) * src_stride];
+    }
+    off += cnt;
+  }
+}
+
 // One Stockham pass of radix R over `total` butterflies (all batches), in place: every thread reads
-// its NB butterflies, the workgroup meets, every thread writes.  tw = w_N^t, t < N.
+// its NB butterflies, the workgroup meets, every thread writes.  twp = this pass's twiddle block
+// (build_pass_twiddles): twp[(q - 1) NS + k] = w_{NS R}^{k q}; unused when NS == 1.
 // The loop is branch-free: a thread index past the last butterfly is clamped to it, so the surplus
 // lanes repeat that butterfly and store the same values to the same slots.  With predicated
 // iterations every butterfly was its own basic block and its LDS reads were not issued before the
 // previous butterfly had finished (the kernel ran at 46 % VALU and 26 % LDS utilisation).
 template <int R, int NB, int NT, class L>
-__device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const float2* __restrict__ tw, int N, int NS,
+__device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const float2* __restrict__ twp, int N, int NS,
                                              int total, const L lay) {
   const int nb = N / R;
-  const int tstep = nb / NS;                 // w_{NS R}^k = w_N^{k tstep}
   const float inv_ns = 1.0f / (float)NS;
   float2 v[NB][MAX_RADIX];
-  int o[NB];
+  int o[NB], ob[NB];
   // opaque copy of the thread index: keeps the per-butterfly index arithmetic of every pass variant
   // from being hoisted out of the pass loop (that cost > 128 live registers and spills)
   int tid = (int)threadIdx.x;
@@ -266,11 +291,11 @@ __device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const flo
 #pragma unroll
     for (int q = 0; q < R; ++q) v[b][q] = buf[lay.addr(batch, j + nb * q)];
     if (NS > 1) {
-      const int kt = k * tstep;
 #pragma unroll
-      for (int q = 1; q < R; ++q) v[b][q] = cmulf(v[b][q], tw[kt * q]);
+      for (int q = 1; q < R; ++q) v[b][q] = cmulf(v[b][q], twp[(q - 1) * NS + k]);
     }
-    o[b] = lay.addr(batch, jd * NS * R + k);
+    o[b] = jd * NS * R + k;
+    ob[b] = batch;
   };
 #pragma unroll
   for (int b = 0; b < NB - 1; ++b) load_one(b);
@@ -279,15 +304,14 @@ __device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const flo
   for (int b = 0; b < NB - 1; ++b) dft_r<R>(v[b]);
   if (tail) dft_r<R>(v[NB - 1]);
   __syncthreads();
-  const int st = lay.step(NS);
 #pragma unroll
   for (int b = 0; b < NB - 1; ++b) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) buf[o[b] + st * q] = v[b][q];
+    for (int q = 0; q < R; ++q) buf[lay.addr(ob[b], o[b] + NS * q)] = v[b][q];
   }
   if (tail) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) buf[o[NB - 1] + st * q] = v[NB - 1][q];
+    for (int q = 0; q < R; ++q) buf[lay.addr(ob[NB - 1], o[NB - 1] + NS * q)] = v[NB - 1][q];
   }
   __syncthreads();
 }
@@ -306,21 +330,25 @@ __device__ __forceinline__ void pass_dispatch(float2* buf, const float2* tw, int
 }
 
 template <int NT, class L>
-__device__ __forceinline__ void run_passes(float2* buf, const float2* tw, int N, const PassList& pl, int batches, const L lay) {
+__device__ __forceinline__ void run_passes(float2* buf, const float2* twb /* pass blocks */, int N, const PassList& pl,
+                                           int batches, const L lay) {
+  int off = 0;
   for (int p = 0; p < pl.n; ++p) {
-    const int R = pl.radix[p];
+    const int R = pl.radix[p], NS = pl.ns[p];
     const int total = (N / R) * batches;
+    const float2* tw = twb + off;
     switch (R) {
-      case 16: pass_dispatch<16, NT>(buf, tw, N, pl.ns[p], total, lay); break;
-      case 25: pass_dispatch<25, NT>(buf, tw, N, pl.ns[p], total, lay); break;
-      case 8: pass_dispatch<8, NT>(buf, tw, N, pl.ns[p], total, lay); break;
-      case 9: pass_dispatch<9, NT>(buf, tw, N, pl.ns[p], total, lay); break;
-      case 4: pass_dispatch<4, NT>(buf, tw, N, pl.ns[p], total, lay); break;
-      case 2: pass_dispatch<2, NT>(buf, tw, N, pl.ns[p], total, lay); break;
-      case 3: pass_dispatch<3, NT>(buf, tw, N, pl.ns[p], total, lay); break;
-      case 5: pass_dispatch<5, NT>(buf, tw, N, pl.ns[p], total, lay); break;
-      default: pass_dispatch<7, NT>(buf, tw, N, pl.ns[p], total, lay); break;
+      case 16: pass_dispatch<16, NT>(buf, tw, N, NS, total, lay); break;
+      case 25: pass_dispatch<25, NT>(buf, tw, N, NS, total, lay); break;
+      case 8: pass_dispatch<8, NT>(buf, tw, N, NS, total, lay); break;
+      case 9: pass_dispatch<9, NT>(buf, tw, N, NS, total, lay); break;
+      case 4: pass_dispatch<4, NT>(buf, tw, N, NS, total, lay); break;
+      case 2: pass_dispatch<2, NT>(buf, tw, N, NS, total, lay); break;
+      case 3: pass_dispatch<3, NT>(buf, tw, N, NS, total, lay); break;
+      case 5: pass_dispatch<5, NT>(buf, tw, N, NS, total, lay); break;
+      default: pass_dispatch<7, NT>(buf, tw, N, NS, total, lay); break;
     }
+    if (NS > 1) off += NS * (R - 1);
   }
 }
 

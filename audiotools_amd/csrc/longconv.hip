@@ -140,7 +140,7 @@ __global__ __launch_bounds__(THREADS, 4) void colfft_kernel(const ColArgs A) {
   const int npts = A.N1 << A.lcw;
   float2* __restrict__ dst = A.dst + row * (int64_t)A.N1 * A.N2;
   unsigned pk = 0;
-  for (int i = threadIdx.x; i < A.N1; i += THREADS) tw[i] = A.tw1[i];
+  at::gfft::build_pass_twiddles<THREADS>(tw, A.tw1, 1, A.N1, A.pl);     // per-pass blocks (conflict-free reads)
   if constexpr (MODE & COL_ROLLED) {
     const float* __restrict__ rs = A.rsrc + row * A.src_pitch;
     const int64_t T = 2 * (int64_t)A.N1 * A.N2;
@@ -265,14 +265,14 @@ __global__ __launch_bounds__(RTHREADS, ROW_WGS * RTHREADS / 256) void rowconv_ke
     }
   };
   fetch(gx);
-  for (int i = threadIdx.x; i < N2; i += RTHREADS) tw[i] = A.tw2[i];
+  at::gfft::build_pass_twiddles<RTHREADS>(tw, A.tw2, 1, N2, A.pl);       // per-pass blocks (conflict-free reads)
   for (int i = threadIdx.x; i < nrow * A.rt; i += RTHREADS) {
     const int s = i >= A.rt ? 1 : 0;
     rt[i] = A.rowtw[(int64_t)(s ? k1b : k1a) * A.rt + (i - s * A.rt)];
   }
   __syncthreads();
 
-  const RowLayout lay{N2};
+  const RowLayout lay{N2, 0};
   const float2 wlo = A.sp_lo[k1a];
   const int slot_b = self ? 0 : N2;
   const float sc = (A.scale ? A.scale[hrow] : 1.0f) * A.inv_m;

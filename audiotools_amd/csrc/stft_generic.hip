@@ -180,24 +180,31 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
   const int N = 2 * M;
   float2* buf = gbuf;                             // [FB][M]
   float2* tw = gbuf + FB * M;                     // [M]: w_M^t
-  float2* win = tw + M;                           // [M]: window pairs
-  float* melw = reinterpret_cast<float*>(win + M);             // [n_chunks][16]
+  float2* win = tw + M;                           // [M]: window pairs (PLAN 0; the fixed plans keep theirs in registers)
+  float2* stw = PLAN == 0 ? win + M : tw + M;     // [M / 2 + 1]: split twiddles w_N^j
+  float* melw = reinterpret_cast<float*>(stw + M / 2 + 2);     // [n_chunks][16]
   int* mtab = reinterpret_cast<int*>(melw + 16 * A.n_chunks);  // [n_chunks] first bins, then [n_mels][2]
   float* part = reinterpret_cast<float*>(mtab + A.n_chunks + 2 * A.n_mels);   // [FB][n_chunks] partial sums
   float* mag = reinterpret_cast<float*>(gbuf);    // [FB][M + 1] (+ slack), over the transform buffer once Z is consumed
   const bool MEL = A.mel != nullptr;
-  for (int i = threadIdx.x; i < M; i += 256) {
-    tw[i] = A.tw[2 * i];
-    win[i] = reinterpret_cast<const float2*>(A.window)[i];
+  at::gfft::build_pass_twiddles<256>(tw, A.tw, 2, M, A.pl);        // per-pass blocks of w_M (the table is per N = 2 M)
+  // window pairs of this thread's points: n = (tid + 256 i) mod M is the same for every tile
+  constexpr int NWR = PLAN == 1 ? 8 : (PLAN == 2 ? 16 : 1);
+  float2 wreg[NWR];
+  if constexpr (PLAN == 0) {
+    for (int i = threadIdx.x; i < M; i += 256) win[i] = reinterpret_cast<const float2*>(A.window)[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) wreg[i] = reinterpret_cast<const float2*>(A.window)[threadIdx.x + 256 * i];
   }
+  for (int i = threadIdx.x; i <= M / 2; i += 256) stw[i] = A.tw[i];
   if (MEL) {
     for (int i = threadIdx.x; i < 16 * A.n_chunks; i += 256) melw[i] = A.cw[i];
     for (int i = threadIdx.x; i < A.n_chunks; i += 256) mtab[i] = A.chunk[i];
     for (int i = threadIdx.x; i < 2 * A.n_mels; i += 256) mtab[A.n_chunks + i] = A.band[i];
   }
-  const float2 w1 = A.tw[1];                      // w_N^1
   __syncthreads();
-  const at::gfft::RowLayout lay{M};
+  const at::gfft::RowLayout lay{M, (M & 15) == 0 ? 1 : 0};
   const int npts = FB * M, nbins = FB * (M + 1);
   const int Ti = (int)A.T, n_out = (int)A.n_out, tpr = (int)A.tiles_per_row, hop = A.hop;
 
@@ -244,8 +251,9 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
       for (int i = 0; i < G2_LOADS; ++i) {
         if (256 * i < npts) {
           const int e = min(tid + 256 * i, npts - 1);
-          const float2 w = win[e >= M ? e - M : e];
-          buf[e] = make_float2(r[i].x * w.x, r[i].y * w.y);
+          const int fi = e >= M ? 1 : 0, n = e - fi * M;
+          const float2 w = PLAN == 0 ? win[n] : wreg[i & (NWR - 1)];
+          buf[lay.addr(fi, n)] = make_float2(r[i].x * w.x, r[i].y * w.y);
         }
       }
     } else {
@@ -253,8 +261,8 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
       for (int e = tid; e < npts; e += 256) {
         const int fi = e >= M ? 1 : 0, n = e - fi * M;
         const int64_t sidx = (int64_t)s0 + fi * hop + 2 * n;
-        const float2 w = win[n];
-        buf[e] = make_float2(at::fetch_padded(xr, sidx, A.T, A.T2, A.pad, A.pad_mode) * w.x,
+        const float2 w = PLAN == 0 ? win[n] : reinterpret_cast<const float2*>(A.window)[n];
+        buf[lay.addr(fi, n)] = make_float2(at::fetch_padded(xr, sidx, A.T, A.T2, A.pad, A.pad_mode) * w.x,
                              at::fetch_padded(xr, sidx + 1, A.T, A.T2, A.pad, A.pad_mode) * w.y);
       }
     }
@@ -262,12 +270,12 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
     fetch(g + 1, g + 1 < g_end, tid);                     // the next tile's samples: in flight during the passes
     if constexpr (PLAN == 1) {
       at::gfft::pass_inplace<16, 1, 256>(buf, tw, 2048, 1, 256, lay);
-      at::gfft::pass_inplace<16, 1, 256>(buf, tw, 2048, 16, 256, lay);
-      at::gfft::pass_inplace<8, 2, 256>(buf, tw, 2048, 256, 512, lay);
+      at::gfft::pass_inplace<16, 1, 256>(buf, tw, 2048, 16, 256, lay);            // block 0: 16 x 15 entries
+      at::gfft::pass_inplace<8, 2, 256>(buf, tw + 240, 2048, 256, 512, lay);      // block 1: 256 x 7
     } else if constexpr (PLAN == 2) {
       at::gfft::pass_inplace<16, 1, 256>(buf, tw, 4096, 1, 256, lay);
       at::gfft::pass_inplace<16, 1, 256>(buf, tw, 4096, 16, 256, lay);
-      at::gfft::pass_inplace<16, 1, 256>(buf, tw, 4096, 256, 256, lay);
+      at::gfft::pass_inplace<16, 1, 256>(buf, tw + 240, 4096, 256, 256, lay);     // block 1: 256 x 15
     } else {
       at::gfft::run_passes<256>(buf, tw, M, A.pl, FB, lay);
     }
@@ -278,13 +286,13 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
     for (int it = 0; it < G2_KB; ++it) {
       const int e = tid + 256 * it;
       mg[it] = 0.f;
-      if (it < G2_KB - 1 || e < nbins) {                  // only the last slot can lie past the tile
+      if ((PLAN != 0 && it < G2_KB - 1) || e < nbins) {   // full-size tiles (PLAN 1 / 2): only the last slot can lie past the tile
         const int ec = min(e, nbins - 1);
         const int fi = ec >= M + 1 ? 1 : 0, k = ec - fi * (M + 1);
-        const float2 zk = buf[fi * M + (k == M ? 0 : k)], zm = buf[fi * M + ((k == 0 || k == M) ? 0 : M - k)];
-        float2 w = tw[k == M ? 0 : (k >> 1)];
-        if (k == M) w = make_float2(-1.f, 0.f);           // w_N^M
-        else if (k & 1) w = at::gfft::cmulf(w, w1);       // w_N^k = w_M^(k >> 1) w_N^1
+        const float2 zk = buf[lay.addr(fi, k == M ? 0 : k)], zm = buf[lay.addr(fi, (k == 0 || k == M) ? 0 : M - k)];
+        // w_N^k from the quarter table stw[j] = w_N^j, j <= M / 2, by the symmetry w_N^(M - j) = -conj(w_N^j)
+        float2 w = stw[k <= M / 2 ? k : M - k];
+        if (k > M / 2) w = make_float2(-w.x, w.y);
         const float c = w.x, sn = -w.y;
         const float sr = zk.x + zm.x, si = zk.y - zm.y;
         const float dr = zk.x - zm.x, di = zk.y + zm.y;
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
         const float qq = fmaf(sn, di, c * dr);
         float2 X = make_float2(0.5f * (sr - pp), 0.5f * (si - qq));
         if (k == 0 || k == M) X.y = 0.f;                  // exactly real
-        if (it < G2_KB - 1) orow[e] = X;                  // frame f0 + 1 follows frame f0: e indexes both rows
+        if (PLAN != 0 && it < G2_KB - 1) orow[e] = X;     // frame f0 + 1 follows frame f0: e indexes both rows
         else if (e < nbins) orow[e] = X;
         mg[it] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));
       }
@@ -418,10 +426,11 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
     G.tiles_per_row = (n_frames_out + G.FB - 1) / G.FB;
     G.total_tiles = rows * G.tiles_per_row;
     G.vec2 = ((T % 2) == 0 && (hop % 2) == 0 && (M % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 8) == 0) ? 1 : 0;
-    size_t lds = ((size_t)G.FB * M + 2 * (size_t)M) * sizeof(float2) + 64;       // transform buffer (+ |X| slack), twiddles, window
+    const int plan = (M == 2048 && G.FB == 2) ? 1 : (M == 4096 ? 2 : 0);
+    // transform buffer (+ |X| slack), pass twiddles, [window: run-time plans only], split twiddles
+    size_t lds = ((size_t)G.FB * M + (plan == 0 ? 2 : 1) * (size_t)M + M / 2 + 2) * sizeof(float2) + 64;
     if (mel_out) lds += (size_t)G.n_chunks * (16 + 1 + G.FB) * 4 + (size_t)2 * n_mels * 4;
     if (lds > 160 * 1024) return AT_ERR_UNSUPPORTED;
-    const int plan = (M == 2048 && G.FB == 2) ? 1 : (M == 4096 ? 2 : 0);
     const void* kfn = plan == 1 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<1>)
                     : plan == 2 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<2>)
                                 : reinterpret_cast<const void*>(stft_generic_tiled_kernel<0>);
