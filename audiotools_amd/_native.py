@@ -112,6 +112,8 @@ SIGNATURES = {
                                _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
     "at_istft_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
     "at_istft_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i64, _i64, _p, _p, _i64, _p]),
+    "at_istft_edit_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i64, _i64, _p, _p, _i64,
+                                 _i32, _i64, _p, _p, _p, _p, _p, _f32, _f32, _f32, _i32, _f32, _p]),
     "at_stft_adjoint_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
     "at_stft_mel_adjoint_f32": (_i32, [_p, _p, _p, _p, _i32, _i64, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
     "at_fir_per_item_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p, _p]),

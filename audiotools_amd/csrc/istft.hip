@@ -167,6 +167,19 @@ struct IstftFusedArgs {
   const int* bin_bands;   // (M+1): the two bands whose triangles cover bin k: lo | hi << 16
   const float2* bin_w;    // (M+1): their weights basis[lo][k], basis[hi][k] (0 where absent)
   int n_mels;
+  // STFT-domain edit applied to the spectrum as it is loaded (EDIT kernels): SpectralTransform's
+  // stft -> edit -> istft (transforms.py:274-286) without the edit's own pass over stft_data (dsp.py:217-352)
+  int edit_kind;           // 1: bins [lo, hi) of every frame := fill;  2: frames [lo, hi) := fill;
+                           // 3: X *= e^{i shift};  4: |X| in dB below the cutoff -> val e^{i angle X}
+  int edit_C;              // channels per item: the parameters are per ITEM, row / C
+  const int* edit_lo;      // (B) kinds 1, 2
+  const int* edit_hi;
+  const float* edit_shift; // (B) kind 3
+  const double* edit_cut;  // (B) kind 4: cutoff in dB
+  const unsigned* edit_maxpow;   // kind 4: max |X|^2 over the whole batch as float bits (at_spec_maxpow_f32)
+  float2 edit_fill;
+  float edit_top_db, edit_val;
+  int edit_use_top;
 };
 
 struct __attribute__((packed, aligned(4))) f2u { float x, y; };  // dword-aligned pair
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(256) void istft_env_kernel(const float* __restrict_
 // gradient is dL/dmel; the spectrum gradient  G[k] = (sum_m basis[m,k] gmel[m]) X[k] / |X[k]|  is formed
 // on the fly from a per-bin table (a triangular bank has at most two non-zero bands per bin) and
 // never touches HBM.
-template <int M, int SH /* hop = 2 L SH */, bool ADJ, bool MELB = false>
+template <int M, int SH /* hop = 2 L SH */, bool ADJ, bool MELB = false, bool EDIT = false>
 __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const IstftFusedArgs A) {
   using P = Plan<M>;
   constexpr int L = P::L, FW = P::FW, N = 2 * M, HOP = 2 * L * SH, R = N / HOP;
@@ -256,6 +269,19 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   const float2* __restrict__ Xrow = A.X + row * (int64_t)A.n_x * (M + 1);
   float* __restrict__ orow = A.out + row * A.length;
   const int len = (int)A.length;
+  // edit parameters of this frame slot's item (constant over the run)
+  int e_lo = 0, e_hi = 0;
+  float e_cs = 1.f, e_sn = 0.f, e_floor = 0.f;
+  double e_cut = 0.0;
+  if constexpr (EDIT) {
+    const int64_t item = row / A.edit_C;
+    if (A.edit_kind == 1 || A.edit_kind == 2) { e_lo = A.edit_lo[item]; e_hi = A.edit_hi[item]; }
+    if (A.edit_kind == 3) sincosf(A.edit_shift[item], &e_sn, &e_cs);
+    if (A.edit_kind == 4) {
+      e_cut = A.edit_cut[item];
+      e_floor = 10.0f * log10f(fmaxf(__uint_as_float(*A.edit_maxpow), 1e-10f)) - A.edit_top_db;
+    }
+  }
 
   float2 tw3b[P::R3 > 1 ? NB3 : 1];
   if constexpr (P::R3 > 1) {
@@ -328,6 +354,28 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
       for (int q = 0; q < 16; ++q) xa[q] = to_grad(xa[q], t + L * q);
       xN = to_grad(xN, M);
       wave_sync();   // the slab is about to be overwritten by pass 1
+    }
+    if constexpr (EDIT) {
+      // the arithmetic of spec_mask_kernel / spec_phase_shift_kernel / spec_mask_lowmag_kernel (specedit.hip) on the
+      // registers the loads filled; masked / unmasked elements are the same ones (integer ranges = the reference's
+      // float comparisons against a monotone grid, evaluated by the caller)
+      const int fx = f - A.lead;
+      auto edit = [&](float2 x, int k) __attribute__((always_inline)) -> float2 {
+        if (A.edit_kind == 1) return (k >= e_lo && k < e_hi) ? A.edit_fill : x;
+        if (A.edit_kind == 2) return (fx >= e_lo && fx < e_hi) ? A.edit_fill : x;
+        if (A.edit_kind == 3) return make_float2(x.x * e_cs - x.y * e_sn, x.x * e_sn + x.y * e_cs);
+        const float mag = hypotf(x.x, x.y);
+        float ls = 10.0f * log10f(fmaxf(mag * mag, 1e-10f));
+        if (A.edit_use_top) ls = fmaxf(ls, e_floor);
+        if ((double)ls < e_cut) {
+          const float inv = mag > 0.f ? 1.0f / mag : 0.f;
+          return mag > 0.f ? make_float2(A.edit_val * x.x * inv, A.edit_val * x.y * inv) : make_float2(A.edit_val, 0.f);
+        }
+        return x;
+      };
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xa[q] = edit(xa[q], t + L * q);
+      xN = edit(xN, M);
     }
     float2 a[16];
 #pragma unroll
@@ -460,13 +508,13 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   for (int i = 1; i < total; ++i) step(f_first + i);
 }
 
-template <int M, int SH, bool ADJ, bool MELB = false>
+template <int M, int SH, bool ADJ, bool MELB = false, bool EDIT = false>
 int launch_fused(const IstftFusedArgs& A, hipStream_t stream) {
   constexpr int FW = Plan<M>::FW;
   const int64_t waves = (A.total_units + FW - 1) / FW;
   const int64_t blocks = (waves + 3) / 4;
   if (blocks > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((istft_fused_kernel<M, SH, ADJ, MELB>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
+  hipLaunchKernelGGL((istft_fused_kernel<M, SH, ADJ, MELB, EDIT>), dim3((unsigned)blocks), dim3(256), 0, stream, A);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }
@@ -478,6 +526,19 @@ int launch_fused_sh(int sh, const IstftFusedArgs& A, hipStream_t stream) {
     case 2: return launch_fused<M, 2, ADJ>(A, stream);
     case 4: return launch_fused<M, 4, ADJ>(A, stream);
     case 8: return launch_fused<M, 8, ADJ>(A, stream);
+  }
+  return AT_ERR_UNSUPPORTED;
+}
+
+// fused STFT-domain edit: hop = n_fft / 4 (the default hop of every SpectralTransform), n_fft >= 64
+int launch_fused_edit(int M, const IstftFusedArgs& F, hipStream_t st) {
+  switch (M) {
+    case 32: return launch_fused<32, 4, false, false, true>(F, st);
+    case 64: return launch_fused<64, 4, false, false, true>(F, st);
+    case 128: return launch_fused<128, 4, false, false, true>(F, st);
+    case 256: return launch_fused<256, 4, false, false, true>(F, st);
+    case 512: return launch_fused<512, 4, false, false, true>(F, st);
+    case 1024: return launch_fused<1024, 4, false, false, true>(F, st);
   }
   return AT_ERR_UNSUPPORTED;
 }
@@ -580,9 +641,9 @@ int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft, int 
 // `lead` and the last n_frames - lead - n_x are all-zero (match_stride re-inserts the two edge
 // frames the forward transform dropped, audio_signal.py:1278-1281, without copying X).
 // out (rows, length): sample p comes from centre-padded position p + n_fft/2.
-int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft,
-                 int hop, int lead, int64_t n_frames, int64_t length, float* out, void* workspace,
-                 int64_t workspace_bytes, void* stream) {
+static int istft_run(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft,
+                     int hop, int lead, int64_t n_frames, int64_t length, float* out, void* workspace,
+                     int64_t workspace_bytes, void* stream, const IstftFusedArgs* edit) {
   if (rows == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
   if (!X || !window || !twiddles || !out || rows < 0 || n_x <= 0 || hop <= 0 || length < 0 || lead < 0 ||
       n_frames < lead + n_x)
@@ -593,6 +654,7 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
   if (!workspace || workspace_bytes < at_istft_workspace_bytes(rows, n_frames, n_fft, hop)) return AT_ERR_INVALID;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!fused_size) {
+    if (edit) return AT_ERR_UNSUPPORTED;
     // generic sizes (4096 ..., non powers of two): mixed-radix frames + the gather kernel
     if (lead != 0 || n_frames != n_x) return AT_ERR_UNSUPPORTED;
     int rc = at::istft_frames_generic(X, rows, n_frames, window, twiddles, n_fft, reinterpret_cast<float*>(workspace), st);
@@ -615,6 +677,14 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
     F.dump = reinterpret_cast<float*>(workspace) + ((n_frames - 1) * hop + n_fft);
     F.n_x = (int)n_x; F.lead = lead; F.n_frames = (int)n_frames;
     F.gmel = nullptr; F.bin_bands = nullptr; F.bin_w = nullptr; F.n_mels = 0;
+    F.edit_kind = 0;
+    if (edit) {
+      if (sh != 4 || M < 32) return AT_ERR_UNSUPPORTED;
+      F.edit_kind = edit->edit_kind; F.edit_C = edit->edit_C; F.edit_lo = edit->edit_lo; F.edit_hi = edit->edit_hi;
+      F.edit_shift = edit->edit_shift; F.edit_cut = edit->edit_cut; F.edit_maxpow = edit->edit_maxpow;
+      F.edit_fill = edit->edit_fill; F.edit_top_db = edit->edit_top_db; F.edit_val = edit->edit_val;
+      F.edit_use_top = edit->edit_use_top;
+    }
     plan_runs(F, rows, n_fft, hop);
     const int64_t env_n = (n_frames - 1) * hop + n_fft;
     int64_t eb = (env_n + 255) / 256;
@@ -622,8 +692,9 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
     hipLaunchKernelGGL(istft_env_kernel, dim3((unsigned)eb), dim3(256), 0, st, window, reinterpret_cast<float*>(workspace),
                        (int)n_frames, n_fft, hop, env_n);
     AT_LAUNCH_CHECK();
-    return launch_fused_m<false>(M, sh, F, st);
+    return edit ? launch_fused_edit(M, F, st) : launch_fused_m<false>(M, sh, F, st);
   }
+  if (edit) return AT_ERR_UNSUPPORTED;
   // generic hop: frame buffer + gather.  Virtual zero frames are not supported here.
   if (lead != 0 || n_frames != n_x) return AT_ERR_UNSUPPORTED;
   IstftArgs A;
@@ -649,6 +720,38 @@ int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window,
                      (int)n_frames, n_fft, hop, length);
   AT_LAUNCH_CHECK();
   return AT_OK;
+}
+
+int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft,
+                 int hop, int lead, int64_t n_frames, int64_t length, float* out, void* workspace,
+                 int64_t workspace_bytes, void* stream) {
+  return istft_run(X, rows, n_x, window, twiddles, n_fft, hop, lead, n_frames, length, out, workspace, workspace_bytes,
+                   stream, nullptr);
+}
+
+// at_istft_f32 with an STFT-domain edit applied to X as it is read (X itself is not modified): the inverse transform
+// of  edit(X)  for the edits of dsp.py:217-352 with per-ITEM parameters (rows = B * C, item = row / C):
+//   kind 1  mask_frequencies: bins  lo[b] <= k < hi[b]  of every frame := (fill_re, fill_im)
+//   kind 2  mask_timesteps:   frames lo[b] <= n < hi[b] := (fill_re, fill_im)
+//   kind 3  shift_phase:      X * e^{i shift[b]}
+//   kind 4  mask_low_magnitudes: 10 log10(max(|X|^2, 1e-10)) (floored at max - top_db when use_top_db; maxpow = the
+//           batch maximum of |X|^2 from at_spec_maxpow_f32) < cut_db[b]  ->  val e^{i angle X}
+// The integer ranges are the reference's float comparisons against the (monotone) frequency / time grid, evaluated
+// by the caller.  hop must be n_fft / 4 and 64 <= n_fft <= 2048 (AT_ERR_UNSUPPORTED otherwise: apply the edit with
+// at_spec_* and call at_istft_f32).
+int at_istft_edit_f32(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft,
+                      int hop, int lead, int64_t n_frames, int64_t length, float* out, void* workspace,
+                      int64_t workspace_bytes, int kind, int64_t C, const int* lo, const int* hi, const float* shift,
+                      const double* cut_db, const float* maxpow, float fill_re, float fill_im, float top_db,
+                      int use_top_db, float val, void* stream) {
+  if (kind < 1 || kind > 4 || C <= 0 || rows % C != 0) return AT_ERR_INVALID;
+  if ((kind <= 2 && (!lo || !hi)) || (kind == 3 && !shift) || (kind == 4 && (!cut_db || !maxpow))) return AT_ERR_INVALID;
+  IstftFusedArgs E;
+  E.edit_kind = kind; E.edit_C = (int)C; E.edit_lo = lo; E.edit_hi = hi; E.edit_shift = shift; E.edit_cut = cut_db;
+  E.edit_maxpow = reinterpret_cast<const unsigned*>(maxpow); E.edit_fill = make_float2(fill_re, fill_im);
+  E.edit_top_db = top_db; E.edit_val = val; E.edit_use_top = use_top_db;
+  return istft_run(X, rows, n_x, window, twiddles, n_fft, hop, lead, n_frames, length, out, workspace, workspace_bytes,
+                   stream, &E);
 }
 
 // Adjoint of the forward STFT (the backward pass of stft() for a real signal):

@@ -63,6 +63,16 @@ def _broadcasts_to(t, shape) -> bool:
         return False
 
 
+class SpecEdit:
+    """A STFT-domain edit that has been requested but not yet applied: ``apply(X)`` runs the eager kernel (a new
+    spectrum), ``fused`` holds the arguments with which ``at_istft_edit_f32`` applies the same edit while the inverse
+    transform reads ``X``."""
+    __slots__ = ("apply", "fused")
+
+    def __init__(self, apply, fused):
+        self.apply, self.fused = apply, fused
+
+
 def _per_item_native(X, *params) -> bool:
     """The in-place stft_data kernels apply: native spectrum and every parameter is a scalar or
     has one value per item (shape (), (1,), (B,), (B,1,1,1))."""
@@ -166,6 +176,21 @@ class DSPMixin:
         return self._sinc_filter(cutoffs, zeros, highpass=True)
 
     # ----------------------------------------------------------- STFT masks
+    def _spec_edit(self, eager, fused_args):
+        """Apply a per-item edit of a native spectrum -- now, or, inside a SpectralTransform (``_defer_edits``) whose
+        inverse transform can take it (hop = n_fft / 4, fused sizes), as a pending edit that ``istft()`` folds into
+        its spectrum load (transforms.py:274-286: stft -> edit -> istft; the edit's read + write pass of stft_data
+        disappears).  Reading ``stft_data`` before that materialises it."""
+        X = self.stft_data                      # (materialises an earlier pending edit: edits compose in order)
+        if self._defer_edits:
+            n_fft = 2 * (X.shape[-2] - 1)
+            p = self.stft_params
+            if p.window_length == n_fft and kernels.istft_edit_supported(n_fft, p.hop_length):
+                self._pending_edit = SpecEdit(eager, fused_args(X))
+                return self
+        self.stft_data = eager(X)
+        return self
+
     def mask_frequencies(self, fmin_hz, fmax_hz, val: float = 0.0):
         """Set magnitude AND phase to ``val`` for fmin <= f < fmax (dsp.py:217-261)."""
         if self.stft_data is None:
@@ -174,8 +199,8 @@ class DSPMixin:
             lo, hi = util.ensure_tensor(fmin_hz, ndim=1), util.ensure_tensor(fmax_hz, ndim=1)
             assert torch.all(lo < hi)
             grid = torch.linspace(0, self.sample_rate / 2, self.stft_data.shape[-2], device=self.device)
-            self.stft_data = kernels.spec_mask(self.stft_data, 0, lo, hi, grid, val)
-            return self
+            return self._spec_edit(lambda X: kernels.spec_mask(X, 0, lo, hi, grid, val),
+                                   lambda X: kernels.mask_edit(1, lo, hi, grid, val, X.shape[0], X.device))
         mag, phase = self.magnitude, self.phase
         fmin_hz = util.ensure_tensor(fmin_hz, ndim=mag.ndim)
         fmax_hz = util.ensure_tensor(fmax_hz, ndim=mag.ndim)
@@ -197,8 +222,8 @@ class DSPMixin:
             lo, hi = util.ensure_tensor(tmin_s, ndim=1), util.ensure_tensor(tmax_s, ndim=1)
             assert torch.all(lo < hi)
             grid = torch.linspace(0, self.signal_duration, self.stft_data.shape[-1], device=self.device)
-            self.stft_data = kernels.spec_mask(self.stft_data, 1, lo, hi, grid, val)
-            return self
+            return self._spec_edit(lambda X: kernels.spec_mask(X, 1, lo, hi, grid, val),
+                                   lambda X: kernels.mask_edit(2, lo, hi, grid, val, X.shape[0], X.device))
         mag, phase = self.magnitude, self.phase
         tmin_s = util.ensure_tensor(tmin_s, ndim=mag.ndim)
         tmax_s = util.ensure_tensor(tmax_s, ndim=mag.ndim)
@@ -217,8 +242,14 @@ class DSPMixin:
         if self.stft_data is None:
             self.stft()
         if _per_item_native(self.stft_data, db_cutoff):
-            self.stft_data = kernels.spec_mask_lowmag(self.stft_data, util.ensure_tensor(db_cutoff, ndim=1), val)
-            return self
+            cut = util.ensure_tensor(db_cutoff, ndim=1)
+
+            def fused(X):
+                B = X.shape[0]
+                return {"kind": 4, "cut": cut.reshape(-1).to(X.device, torch.float64).expand(B).contiguous(),
+                        "maxpow": kernels.spec_maxpow(X), "top_db": 80.0, "use_top": 1, "val": float(val)}
+
+            return self._spec_edit(lambda X: kernels.spec_mask_lowmag(X, cut, val), fused)
         mag = self.magnitude
         log_mag = self.log_magnitude()
         db_cutoff = util.ensure_tensor(db_cutoff, ndim=mag.ndim).to(self.device)
@@ -229,8 +260,9 @@ class DSPMixin:
         if self.stft_data is None:
             self.stft()
         if _per_item_native(self.stft_data, shift) and util.ensure_tensor(shift).dtype in (torch.float32, torch.int64):
-            self.stft_data = kernels.spec_phase_shift(self.stft_data, util.ensure_tensor(shift, ndim=1))
-            return self
+            sh = util.ensure_tensor(shift, ndim=1)
+            return self._spec_edit(lambda X: kernels.spec_phase_shift(X, sh),
+                                   lambda X: {"kind": 3, "shift": sh.reshape(-1).to(X.device, torch.float32).expand(X.shape[0]).contiguous()})
         if kernels.spec_native(self.stft_data) and _broadcasts_to(shift, self.stft_data.shape):
             # a full (B, C, F, N) / (C, F, N) shift tensor (CorruptPhase): one tiled pass instead of
             # angle, add, abs, exp, mul

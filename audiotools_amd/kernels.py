@@ -139,11 +139,18 @@ def istft_fused_supported(n_fft: int, hop: int) -> bool:
     return stft_fused_supported(n_fft) and any(hop * r == n_fft for r in (2, 4, 8, 16))
 
 
+def istft_edit_supported(n_fft: int, hop: int) -> bool:
+    """The fused inverse kernel can apply a pending STFT-domain edit while it reads the spectrum."""
+    return istft_fused_supported(n_fft, hop) and hop * 4 == n_fft and 64 <= n_fft <= 2048
+
+
 def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, length: int,
-          lead: int = 0, trail: int = 0) -> torch.Tensor:
+          lead: int = 0, trail: int = 0, edit: dict = None) -> torch.Tensor:
     """Inverse STFT of a (B, C, F, N) complex64 HIP tensor -> (B, C, length) float32
     (torch.istft(center=True) semantics).  ``lead`` / ``trail`` all-zero frames are added in front
-    of / behind the N frames without copying (match_stride, audio_signal.py:1278-1281)."""
+    of / behind the N frames without copying (match_stride, audio_signal.py:1278-1281).
+    ``edit``: a pending STFT-domain edit (``filters.SpecEdit.fused``) applied to the spectrum as it is read
+    (``at_istft_edit_f32``); requires :func:`istft_edit_supported`."""
     _require_native_ok(stft_bcfn)
     B, C, F, N = stft_bcfn.shape
     assert F == n_fft // 2 + 1
@@ -162,6 +169,16 @@ def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, l
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     tw = tables.stft_twiddles(n_fft, dev)
     out = torch.empty((B, C, length), dtype=torch.float32, device=dev)
+    if edit is not None:
+        code = lib.at_istft_edit_f32(_native.ptr(torch.view_as_real(X)), B * C, N, _native.ptr(window), _native.ptr(tw), n_fft, hop,
+                                     lead, n_frames, length, _native.ptr(out), _native.ptr(ws), need, int(edit["kind"]), C,
+                                     _native.ptr(edit.get("lo")), _native.ptr(edit.get("hi")), _native.ptr(edit.get("shift")),
+                                     _native.ptr(edit.get("cut")), _native.ptr(edit.get("maxpow")),
+                                     float(edit.get("fill_re", 0.0)), float(edit.get("fill_im", 0.0)),
+                                     float(edit.get("top_db", 0.0)), int(edit.get("use_top", 0)), float(edit.get("val", 0.0)),
+                                     _native.current_stream(dev))
+        _native.check(code, "at_istft_edit_f32")
+        return out
     code = lib.at_istft_f32(_native.ptr(torch.view_as_real(X)), B * C, N, _native.ptr(window), _native.ptr(tw), n_fft, hop,
                             lead, n_frames, length, _native.ptr(out), _native.ptr(ws), need, _native.current_stream(dev))
     _native.check(code, "at_istft_f32")
@@ -400,6 +417,36 @@ def spec_mask(X: torch.Tensor, axis: int, lo: torch.Tensor, hi: torch.Tensor, gr
                                           _native.current_stream(X.device))
     _native.check(code, "at_spec_mask_f32")
     return Y
+
+
+def spec_mask_fill(val: float):
+    """(re, im) of ``val * exp(1j * val)`` as float32 ops: magnitude = phase = val (dsp.py:252-258)."""
+    v = float(val)
+    fill = torch.tensor(v, dtype=torch.float32) * torch.exp(1j * torch.tensor(v, dtype=torch.float32))
+    return float(fill.real), float(fill.imag)
+
+
+def mask_edit(kind: int, lo: torch.Tensor, hi: torch.Tensor, grid: torch.Tensor, val: float, B: int, device) -> dict:
+    """Arguments of ``at_istft_edit_f32`` for a frequency (kind 1) / time (kind 2) mask: the per-item index ranges
+    ``lo <= grid[i] < hi`` selects.  The grid is monotone, so the selected set is the contiguous range between the
+    first index with ``grid >= lo`` and the first with ``grid >= hi`` -- evaluated in float64 like spec_mask_kernel."""
+    g = grid.to(device, torch.float64).contiguous()
+    lo64 = lo.reshape(-1).to(device, torch.float64).expand(B).contiguous()
+    hi64 = hi.reshape(-1).to(device, torch.float64).expand(B).contiguous()
+    re, im = spec_mask_fill(val)
+    return {"kind": kind, "lo": torch.searchsorted(g, lo64).to(torch.int32), "hi": torch.searchsorted(g, hi64).to(torch.int32),
+            "fill_re": re, "fill_im": im}
+
+
+def spec_maxpow(X: torch.Tensor) -> torch.Tensor:
+    """max |X|^2 over the whole (batch) spectrum as a 1-element float32 device tensor (log_magnitude's global
+    top_db floor, audio_signal.py:1486)."""
+    B, C, F, N = X.shape
+    Xr = torch.view_as_real(X.transpose(2, 3))
+    mp = torch.empty(1, dtype=torch.float32, device=X.device)
+    _native.check(_native.lib().at_spec_maxpow_f32(_native.ptr(Xr), B * C * N * F, _native.ptr(mp), _native.current_stream(X.device)),
+                  "at_spec_maxpow_f32")
+    return mp
 
 
 def spec_phase_shift(X: torch.Tensor, shift: torch.Tensor):

@@ -386,16 +386,27 @@ class AudioSignal(SpectralMixin, EffectMixin, LoudnessMixin, ImpulseResponseMixi
 
     samples = audio_data
 
+    # A STFT-domain edit recorded by mask_frequencies / mask_timesteps / mask_low_magnitudes / shift_phase while a
+    # SpectralTransform runs (``_defer_edits``): ``istft()`` applies it inside the inverse kernel, reading
+    # ``stft_data`` materialises it -- either way the caller sees the reference's values (a NEW stft_data tensor
+    # whose untouched bins are bit-identical), the edit's own read + write pass only happens when somebody looks.
+    _pending_edit = None
+    _defer_edits = False
+
     @property
     def stft_data(self):
+        if self._pending_edit is not None:
+            edit, self._pending_edit = self._pending_edit, None
+            self._stft_data = edit.apply(self._stft_data)
         return self._stft_data
 
     @stft_data.setter
     def stft_data(self, data):
         if data is not None:
             assert torch.is_tensor(data) and torch.is_complex(data)
-            if self.stft_data is not None and self.stft_data.shape != data.shape:
+            if self._stft_data is not None and self._stft_data.shape != data.shape:
                 warnings.warn("stft_data changed shape")
+        self._pending_edit = None
         self._stft_data = data
 
     @property

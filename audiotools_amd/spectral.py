@@ -178,9 +178,28 @@ class SpectralMixin:
     def istft(self, window_length: int = None, hop_length: int = None, window_type: str = None,
               match_stride: bool = None, length: int = None):
         """Inverse STFT of ``stft_data`` into ``audio_data`` (audio_signal.py:1214-1296)."""
-        if self.stft_data is None:
+        if self._stft_data is None:
             raise RuntimeError("Cannot do inverse STFT without self.stft_data!")
         n_fft, hop, wtype, match_stride, _ = self._resolve(window_length, hop_length, window_type, match_stride)
+        # a pending STFT-domain edit rides on the inverse kernel's spectrum load when that kernel takes this transform;
+        # otherwise reading stft_data below materialises it
+        pending = self._pending_edit
+        Xraw = self._stft_data
+        fuse = (pending is not None and kernels.is_native(torch.view_as_real(Xraw)) and not Xraw.requires_grad
+                and Xraw.shape[-2] == n_fft // 2 + 1 and kernels.istft_edit_supported(n_fft, hop))
+        if fuse:
+            window = self.get_window(wtype, n_fft, str(Xraw.device))
+            nb, nch, nf, nt = Xraw.shape
+            right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
+            if length is None:
+                length = self.original_signal_length + 2 * pad + right_pad
+            edge = 2 if match_stride else 0
+            x = kernels.istft(Xraw, window, n_fft, hop, int(length), lead=edge, trail=edge, edit=pending.fused)
+            x = x.reshape(nb, nch, -1)
+            if match_stride:
+                x = x[..., pad: -(pad + right_pad)]
+            self.audio_data = x
+            return self
         window = self.get_window(wtype, n_fft, str(self.stft_data.device))
         nb, nch, nf, nt = self.stft_data.shape
         X = self.stft_data.reshape(nb * nch, nf, nt)

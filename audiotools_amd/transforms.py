@@ -166,9 +166,9 @@ class BaseTransform:
                 # AudioSignal.__setitem__ only writes _loudness / stft_data back when BOTH sides have
                 # them (audio_signal.py:1672-1679).
                 params = {k: v for k, v in params.items() if k != "mask"}
-                loud0, stft0 = signal._loudness, signal.stft_data
+                loud0, stft0 = signal._loudness, signal._stft_data      # raw attribute: a pending edit stays pending
                 out = self._transform(signal, **params)
-                loud1, stft1 = out._loudness, out.stft_data
+                loud1, stft1 = out._loudness, out._stft_data
                 if out is not signal:
                     # rebind instead of copying into the old storage (a 2 GB pass at cfg4): like the
                     # methods that return ``self`` with a fresh ``audio_data`` tensor (low_pass,
@@ -176,6 +176,8 @@ class BaseTransform:
                     signal.audio_data = out.audio_data
                 signal._loudness = None if loud0 is None else (loud0 if loud1 is None else loud1)
                 signal._stft_data = None if stft0 is None else (stft0 if stft1 is None else stft1)
+                if out is not signal:
+                    signal._pending_edit = out._pending_edit if signal._stft_data is stft1 else None
             elif mask.ndim == 0:
                 # un-batched use (instantiate() of one item): the reference's scalar-mask indexing
                 params = self.apply_mask(params, mask)
@@ -226,6 +228,18 @@ class BaseTransform:
         return params
 
 
+def _deferring(signal, body):
+    """Run ``body`` with the signal's STFT-domain edits DEFERRED: between the stft() and the istft() of a spectral
+    transform a per-item mask / phase shift is recorded on the signal and applied by the inverse kernel as it loads
+    the spectrum (filters._spec_edit, csrc/istft.hip EDIT) instead of in a pass of its own."""
+    prev = signal._defer_edits
+    signal._defer_edits = True
+    try:
+        return body()
+    finally:
+        signal._defer_edits = prev
+
+
 class Identity(BaseTransform):
     """Does nothing (audiotools/data/transforms.py:268-271)."""
 
@@ -235,7 +249,7 @@ class SpectralTransform(BaseTransform):
 
     def transform(self, signal, **kwargs):
         signal.stft()
-        super().transform(signal, **kwargs)
+        _deferring(signal, lambda: BaseTransform.transform(self, signal, **kwargs))
         signal.istft()
         return signal
 
@@ -432,7 +446,7 @@ class _SpectralRecipe(_Recipe):
 
     def transform(self, signal, **kwargs):
         signal.stft()
-        BaseTransform.transform(self, signal, **kwargs)
+        _deferring(signal, lambda: BaseTransform.transform(self, signal, **kwargs))
         signal.istft()
         return signal
 

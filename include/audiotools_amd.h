@@ -103,6 +103,19 @@ int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft, int 
 int at_istft_f32(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft,
                  int hop, int lead, int64_t n_frames, int64_t length, float* out, void* workspace,
                  int64_t workspace_bytes, void* stream);
+/* at_istft_f32 of edit(X): the STFT-domain edits of audiotools/core/dsp.py:217-352 (mask_frequencies,
+ * mask_timesteps, shift_phase, mask_low_magnitudes; per-ITEM parameters, item = row / C) applied to the spectrum as the
+ * inverse transform reads it -- SpectralTransform.transform (data/transforms.py:274-286) is stft -> edit -> istft, and
+ * the edit's own read + write of stft_data disappears.  X is not modified.
+ *   kind 1: bins  lo[b] <= k < hi[b] := (fill_re, fill_im);   kind 2: frames lo[b] <= n < hi[b] := fill;
+ *   kind 3: X * e^{i shift[b]};   kind 4: 10 log10(max(|X|^2, 1e-10)) [floored at max - top_db] < cut_db[b]
+ *           -> val e^{i angle X}  (maxpow: 1 float, the batch maximum of |X|^2 from at_spec_maxpow_f32).
+ * hop must be n_fft / 4, 64 <= n_fft <= 2048; AT_ERR_UNSUPPORTED otherwise (edit with at_spec_*, then at_istft_f32). */
+int at_istft_edit_f32(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft,
+                      int hop, int lead, int64_t n_frames, int64_t length, float* out, void* workspace,
+                      int64_t workspace_bytes, int kind, int64_t C, const int* lo, const int* hi, const float* shift,
+                      const double* cut_db, const float* maxpow, float fill_re, float fill_im, float top_db,
+                      int use_top_db, float val, void* stream);
 
 /* ---- adjoint of the forward STFT (backward pass of stft()) --------------------------------
  * What torch.autograd computes for  audiotools/core/audio_signal.py:1195  torch.stft(center=True)

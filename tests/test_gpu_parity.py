@@ -1283,3 +1283,72 @@ def test_sinc_filters_structured_inputs(highpass):
         lp = torch.nn.functional.conv1d(xp, f.filters.double())[:, 0]
         y64[i] = (x[i].double() - lp) if highpass else lp
     _bounded_by_torch(got.cpu(), y32, y64, "high_pass" if highpass else "low_pass")
+
+
+# ------------------------------------------------------------------------------------------------
+# STFT-domain edits folded into the inverse transform (csrc/istft.hip EDIT)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sr,T", [(44100, 60000 + 7), (16000, 20000)])
+@pytest.mark.parametrize("match_stride", [False, True])
+def test_deferred_spectral_edits_equal_eager(sr, T, match_stride):
+    """Inside a SpectralTransform a per-item mask / phase shift is recorded and applied by the inverse kernel as it
+    loads the spectrum (at_istft_edit_f32).  Same audio as the eager edit kernel + plain inverse, stft_data (read
+    afterwards) is the eagerly edited spectrum with untouched bins bit-identical, and a new tensor."""
+    from audiotools_amd import transforms as tfm
+    x = synth.audio_batch(3, 2, T, seed=T, gaps=False, sample_rate=sr)
+    kw = dict(match_stride=match_stride, window_type="sqrt_hann") if match_stride else {}
+    edits = {
+        "mask_frequencies": lambda s: s.mask_frequencies(torch.tensor([300.0, 1000.0, 50.0]), torch.tensor([900.0, 4000.0, 7000.0])),
+        "mask_frequencies_val": lambda s: s.mask_frequencies(500.0, 2500.0, val=0.3),
+        "mask_timesteps": lambda s: s.mask_timesteps(torch.tensor([0.1, 0.2, 0.0]), torch.tensor([0.3, 0.25, 0.9])),
+        "mask_low_magnitudes": lambda s: s.mask_low_magnitudes(torch.tensor([-30.0, -20.0, -45.0])),
+        "shift_phase": lambda s: s.shift_phase(torch.tensor([0.5, -2.0, 3.0])),
+    }
+    for name, edit in edits.items():
+        a = A.AudioSignal(x.clone(), sr).to("cuda")
+        b = A.AudioSignal(x.clone(), sr).to("cuda")
+        Xa = a.stft(**kw).clone()
+        b.stft(**kw)
+        held = a._stft_data
+        tfm._deferring(a, lambda: edit(a))
+        assert a._pending_edit is not None, name                 # recorded, not applied
+        assert a._stft_data is held and torch.equal(a._stft_data, Xa)
+        edit(b)                                                  # eager
+        assert b._pending_edit is None
+        ya = a.istft(**{k: v for k, v in kw.items()}).audio_data
+        yb = b.istft(**{k: v for k, v in kw.items()}).audio_data
+        assert a._pending_edit is not None                       # still lazy after the fused inverse
+        assert rel_err(ya, yb) < 2e-6, name
+        Xe = a.stft_data                                         # reading materialises
+        assert a._pending_edit is None and Xe is not held
+        assert torch.equal(Xe, b.stft_data), name
+        assert torch.equal(held, Xa)                             # the tensor a caller may still hold did not change
+    # two edits in a row compose in order (the first is materialised when the second arrives)
+    a = A.AudioSignal(x.clone(), sr).to("cuda")
+    b = A.AudioSignal(x.clone(), sr).to("cuda")
+    a.stft(); b.stft()
+    tfm._deferring(a, lambda: a.shift_phase(0.7).mask_frequencies(200.0, 3000.0))
+    b.shift_phase(0.7).mask_frequencies(200.0, 3000.0)
+    assert rel_err(a.istft().audio_data, b.istft().audio_data) < 2e-6
+
+
+def test_spectral_transforms_use_the_fused_inverse():
+    """FrequencyMask / TimeMask / ShiftPhase / MaskLowMagnitudes through BaseTransform on the HIP path: the edit is
+    pending when istft() runs (one pass saved), the result equals the CPU path with the same parameters."""
+    from audiotools_amd import transforms as tfm
+    sr = 44100
+    x = synth.audio_batch(4, 1, 44100, seed=77, gaps=False)
+    for t in (tfm.FrequencyMask(), tfm.TimeMask(), tfm.ShiftPhase(), tfm.MaskLowMagnitudes(), tfm.InvertPhase()):
+        sig = A.AudioSignal(x.clone(), sr)
+        kw = t.batch_instantiate([5, 6, 7, 8], sig)
+        ref = t(sig.clone(), **kw).audio_data
+        dev = sig.clone().to("cuda")
+        calls = []
+        orig = kernels.istft
+        kernels.istft = lambda *a, **k: (calls.append(k.get("edit") is not None), orig(*a, **k))[1]
+        try:
+            got = t(dev, **A.util.prepare_batch(kw, "cuda")).audio_data
+        finally:
+            kernels.istft = orig
+        assert calls == [True], (type(t).__name__, calls)
+        assert rel_err(got, ref) < REL, type(t).__name__

@@ -32,3 +32,23 @@ for name, kw in (("mask_frequencies", dict(fmin_hz=1000.0, fmax_hz=3000.0)), ("m
                  ("shift_phase", dict(shift=1.0)), ("mask_low_magnitudes", dict(db_cutoff=-10.0))):
     run(name, True, **kw)
     run(name, False, **kw)
+
+# ---- the SpectralTransform round trip: edit + istft, eager (edit kernel, then inverse) vs deferred (inverse applies it)
+from audiotools_amd import transforms as tfm
+win_len = s.stft_params.window_length
+for name, kw in (("mask_frequencies", dict(fmin_hz=1000.0, fmax_hz=3000.0)), ("shift_phase", dict(shift=1.0)),
+                 ("mask_low_magnitudes", dict(db_cutoff=-10.0))):
+    def eager():
+        s.stft_data = X0
+        getattr(s, name)(**kw)
+        s.istft()
+    def deferred():
+        s.stft_data = X0
+        tfm._deferring(s, lambda: getattr(s, name)(**kw))
+        s.istft()
+    def plain():
+        s.stft_data = X0
+        s.istft()
+    timed(eager, f"{name} + istft, eager")
+    timed(deferred, f"{name} + istft, folded into the inverse")
+timed(plain, "istft alone")
