@@ -116,6 +116,30 @@ def band_split_torch(audio: torch.Tensor, sample_rate: int, n_bands: int) -> tor
     return torch.stack(bands)
 
 
+def band_split_native(audio: torch.Tensor, sample_rate: int, n_bands: int) -> torch.Tensor:
+    """(n_bands, B, C, T) mel band split of a HIP tensor (effects.py:399-403 -> julius.SplitBands): one overlap-save
+    FIR launch per band straight into its slab of the result.  julius builds every low-pass of the split with the
+    SAME length (the lowest cutoff's), filters with all of them and takes differences of the outputs; the difference of
+    two convolutions with a common replicate padding is the convolution with the difference of the taps, so band k is
+    one FIR with taps  h_k - h_(k-1)  (band 0: h_0; the last band  delta - h_last,  i.e. x - low_last) -- the
+    (n_bands - 1) low-pass outputs and the n_bands subtraction passes over them are never materialised."""
+    bank, half = tables.band_split_bank(int(sample_rate), int(n_bands))
+    if bank is None:
+        return audio[None]
+    dev = audio.device
+    bank = tables.device_table(("band_split_bank", int(sample_rate), int(n_bands)), dev, lambda: (bank.numpy(),))[0]
+    taps = torch.empty((n_bands, bank.shape[1]), dtype=torch.float32, device=dev)
+    taps[0] = bank[0]
+    taps[1:-1] = bank[1:] - bank[:-1]
+    taps[-1] = -bank[-1]
+    taps[-1, half] += 1.0
+    x = audio.contiguous()
+    out = torch.empty((n_bands,) + tuple(x.shape), dtype=torch.float32, device=dev)
+    for k in range(n_bands):
+        kernels.fir_per_item(x, taps[k: k + 1], replicate=True, out=out[k])
+    return out
+
+
 def equalizer_taps(sample_rate: int, weights: torch.Tensor, device=None):
     """Composite per-item FIR (B, L) equivalent to sum_k weights[:, k] * band_k, designed on
     ``device`` (default: where ``weights`` lives) without a host round trip."""
@@ -326,7 +350,10 @@ class EffectMixin:
     # ------------------------------------------------------------ equaliser
     def mel_filterbank(self, n_bands: int):
         """(B, C, T, n_bands) mel-spaced band split that sums to the input (effects.py:386-403)."""
-        return band_split_torch(self.audio_data, self.sample_rate, n_bands).permute(1, 2, 3, 0)
+        audio = self.audio_data
+        if kernels.is_native(audio):
+            return band_split_native(audio, self.sample_rate, n_bands).permute(1, 2, 3, 0)
+        return band_split_torch(audio, self.sample_rate, n_bands).permute(1, 2, 3, 0)
 
     def equalizer(self, db: typing.Union[torch.Tensor, np.ndarray]):
         """Per-band gains ``10 ** db`` (sic, effects.py:429) applied to the mel band split."""

@@ -357,9 +357,10 @@ FIR_FFT_MIN_TAPS = 96   # below this the direct register-window kernel is cheape
 
 
 def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False, replicate: bool = True,
-                 method: str = "auto"):
+                 method: str = "auto", out: torch.Tensor = None):
     """Per-item FIR with replicate padding.  ``taps`` (B or 1, L) odd-length, centred.
-    ``method``: "direct" (at_fir_per_item_f32), "fft" (overlap-save, at_fir_fft_f32) or "auto"."""
+    ``method``: "direct" (at_fir_per_item_f32), "fft" (overlap-save, at_fir_fft_f32) or "auto".
+    ``out``: optional contiguous float32 result buffer of ``audio``'s shape (e.g. one slab of a band stack)."""
     _require_native_ok(audio)
     assert replicate
     B, C, T = audio.shape
@@ -370,7 +371,9 @@ def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False
     Lp = _pad8(L)
     tp = torch.zeros((rows, Lp), dtype=torch.float32, device=audio.device)
     tp[:, :L] = taps.to(audio.device, torch.float32)
-    out = torch.empty_like(audio)
+    if out is None:
+        out = torch.empty_like(audio)
+    assert out.shape == audio.shape and out.is_contiguous() and out.dtype == torch.float32 and out.device == audio.device
     if method == "auto":
         method = os.environ.get("AT_FIR_METHOD") or ("fft" if L >= FIR_FFT_MIN_TAPS else "direct")
     if method == "fft":

@@ -325,6 +325,13 @@ def test_equalizer_and_filterbank_properties():
     assert rel_err(s.clone().equalizer(db).audio_data, restate.equalizer(x, 44100, db)) < REL
     fb = s.clone().mel_filterbank(8)
     assert float((fb.sum(-1).cpu() - x).abs().max()) < 1e-5
+    # the native band split (one FIR per band with difference taps, effects.py:399-403) against the oracle's
+    # julius.SplitBands restatement, band by band, 1 / 2 / 6 / 8 bands at two rates
+    for sr, nb in ((44100, 8), (48000, 6), (16000, 2), (16000, 1)):
+        got = A.AudioSignal(x.clone(), sr).to("cuda").mel_filterbank(nb)
+        ref = restate.mel_filterbank(x, sr, nb)
+        assert got.shape == ref.shape == (3, 2, 24000, nb)
+        assert rel_err(got.permute(0, 1, 3, 2), ref.permute(0, 1, 3, 2), lead=3) < REL, (sr, nb)   # every band its own row
 
 
 @pytest.mark.parametrize("T", [16, 126, 4096, 8192, 12288, 9600, 44100, 24000, 2 * 81 * 1225, 240000])
