@@ -518,10 +518,7 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   float* s_winr = lds_f + NW * 2 * WAVE_LDS_SLOTS;                       // [64 threads][16 q] float2, halved
   float* s_twp = s_winr + 64 * WROW;              // [64 t] rows of 20 floats: split twiddles, pair A r=0..3, pair B r=0..3
   float* s_tw2 = s_twp + 64 * TROW;                // 16 rows x 36: pass-2 twiddles r = 1..15 of row (j mod 16)
-  constexpr bool TW3_LDS = (VAR & 2) != 0;         // w^2, w^3 of the last pass from a per-lane LDS row instead of 2 complex
-  constexpr int T3ROW = 20;                        // products per butterfly and frame (32 of ~780 VALU instructions)
-  float* s_tw3 = s_tw2 + 16 * 36;                  // [64 lanes] rows of 20 floats: (w2, w3) of butterflies 0..3
-  float* s_melw = s_tw3 + (TW3_LDS ? 64 * T3ROW : 0);
+  float* s_melw = s_tw2 + 16 * 36;
   int2* s_uinfo = reinterpret_cast<int2*>(s_melw + A.n_units * MELW_ROW);
 
   for (int i = threadIdx.x; i < N; i += NW * 64) {
@@ -564,16 +561,6 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   for (int b = 0; b < 4; ++b) {
     pj[b] = phys<L, true>(jb[b]);
     twb[b] = A.tw[2 * jb[b]];
-  }
-  if constexpr (TW3_LDS) {
-    if (wave == 0) {                               // one wave fills the block's table: w^2 = w_1024^(2 j), w^3 = w_1024^(3 j)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        reinterpret_cast<float2*>(s_tw3 + lane * T3ROW)[2 * b] = A.tw[(4 * jb[b]) & (N - 1)];
-        reinterpret_cast<float2*>(s_tw3 + lane * T3ROW)[2 * b + 1] = A.tw[(6 * jb[b]) & (N - 1)];
-      }
-    }
-    __syncthreads();
   }
   const int src_lane4 = ((64 - lane) & 63) << 2;   // ds_bpermute byte index of the partner lane
   // this lane's mel units (one per round): magnitude row, the four tree-step bits as bytes, band to store
@@ -677,17 +664,9 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Z[b][r] = fbuf[pj[b] + 257 * r];
     wave_sync();   // slab free: it is reused for |X| below
-    float4 t3[4];
-    if constexpr (TW3_LDS) {
-      const float4* tp3 = reinterpret_cast<const float4*>(s_tw3 + t * T3ROW);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) t3[b] = tp3[b];
-    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const float2 w1 = twb[b];
-      const float2 w2 = TW3_LDS ? make_float2(t3[b].x, t3[b].y) : cmul(w1, w1);
-      const float2 w3 = TW3_LDS ? make_float2(t3[b].z, t3[b].w) : cmul(w2, w1);
+      const float2 w1 = twb[b], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
       Z[b][1] = cmul(Z[b][1], w1);
       Z[b][2] = cmul(Z[b][2], w2);
       Z[b][3] = cmul(Z[b][3], w3);
@@ -883,8 +862,8 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   }
 }
 
-constexpr size_t v2_lds_floats(int n_units, bool tw3 = false) {
-  return (size_t)4 * 2 * WAVE_LDS_SLOTS + 64 * 36 + 64 * 20 + 16 * 36 + (tw3 ? 64 * 20 : 0) + (size_t)n_units * (MELW_ROW + 2);
+constexpr size_t v2_lds_floats(int n_units) {
+  return (size_t)4 * 2 * WAVE_LDS_SLOTS + 64 * 36 + 64 * 20 + 16 * 36 + (size_t)n_units * (MELW_ROW + 2);
 }
 
 // Run-length balancing shared by both kernels: every wave of an XCD span gets the same number of
@@ -907,7 +886,7 @@ template <int NR, int POL = 0, int VAR = 0>
 int launch_v2(const StftArgs& A, int n_cu, hipStream_t stream) {
   constexpr int NW = 4;
   auto kern = stft_mel_kernel_v2<NR, POL, VAR>;
-  const size_t bytes = v2_lds_floats(A.n_units, (VAR & 2) != 0) * 4;
+  const size_t bytes = v2_lds_floats(A.n_units) * 4;
   if (bytes > 160 * 1024) return AT_ERR_UNSUPPORTED;
   int e = at::allow_big_lds(reinterpret_cast<const void*>(kern));
   if (e != AT_OK) return e;
@@ -1171,14 +1150,13 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   const int n_cu = device_cu_count();
   if (use_v2 && M == 1024 && vec2 && A.reuse_shift == 4 && A.debug == 0 && T >= 2 * 2048) {
     // the reference's default transform at 44.1 / 48 kHz: n_fft 2048, hop 512, no match_stride
-    // flags bit 0: nt spectrum stores; bit 6: last-pass twiddle powers from LDS (measurement); bit 5: the round-2 store code (conditional Nyquist / band stores) instead
+    // flags bit 0: nt spectrum stores; bit 5: the round-2 store code (conditional Nyquist / band stores) instead
     // of the static-store-count variant.  The gathered band stores cover n_mels <= 128.
     // (session s40, same box, interleaved: with mel 2.172 vs 2.190 ms nt / 2.134 vs 2.163 ms plain stores; without
     // mel the round-2 code is 0.9 % faster, 1.814 vs 1.830 ms -- there the only uncounted store was the Nyquist one)
     const bool stat = !(A.flags & 32) && A.n_units != 0 && A.n_mels <= 128;
     switch (A.n_units / 64) {
 #define AT_V2_POL(NRV)                                                                   \
-  if (stat && (A.flags & 64)) return (A.flags & 1) ? launch_v2<NRV, 1, 3>(A, n_cu, s) : launch_v2<NRV, 0, 3>(A, n_cu, s); \
   if (stat) return (A.flags & 1) ? launch_v2<NRV, 1, 1>(A, n_cu, s) : launch_v2<NRV, 0, 1>(A, n_cu, s); \
   return (A.flags & 1) ? launch_v2<NRV, 1, 0>(A, n_cu, s) : launch_v2<NRV, 0, 0>(A, n_cu, s);
       case 0: AT_V2_POL(0)
