@@ -122,6 +122,7 @@ SIGNATURES = {
     "at_spec_phase_shift_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "at_spec_polar_elem_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _p, _p, _i32, _p]),
     "at_spec_maxpow_f32": (_i32, [_p, _i64, _p, _p]),
+    "at_spec_gate_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _p, _i32, _p, _p, _i32, _p, _i32, _p]),
     "at_spec_mask_lowmag_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _p, _p, _f32, _i32, _f32, _p]),
     "at_phase_vocoder_frames": (_i64, [_i64, _i64, _i64]),
     "at_phase_vocoder_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p]),

@@ -154,9 +154,111 @@ __global__ __launch_bounds__(256) void spec_polar_elem_kernel(const float2* __re
   }
 }
 
+// ---- spectral gate (ml/layers/spectral_gate.py:58-127) -----------------------------------------------
+// gate[f, n] = 20 log10(max(|X|, 1e-4)) < thr_db[f];  S = conv2d(gate, outer(tf, tt), zero padding);
+// Y = X (1 - amount S).  The reference runs ~8 whole-tensor passes (abs, clamp, log10, compare, float, conv2d,
+// scale, complex multiply); here one workgroup owns 16 frames of one row: the gate bits of the 16 + 2 halo_t
+// frames go to LDS as bytes, every thread then owns a column (bin) -- the smoothing is separable, so the tent
+// over frequency is applied per frame from 7 byte reads into registers and the tent over time runs on those
+// registers -- and the product is written.  X is read once from HBM (1.6x with the halo frames, the second
+// touch of the 16 centre frames comes from L2), Y written once.
+constexpr int GATE_TN = 16;         // frames per workgroup
+constexpr int GATE_MAXH = 8;        // largest half width of either tent
+
+struct GateKArgs {
+  const float2* X;       // (rows, N, F)
+  float2* Y;
+  const float* thr_db;   // (thr_rows, F)
+  const float* amount;   // (B)
+  const float* tf;       // (kf) tent over frequency, already divided by the sum of the 2-D kernel
+  const float* tt;       // (kt) tent over time
+  int64_t rows;
+  int N, F, C, kf, kt, thr_per_item;   // thr_per_item: thr_db has one row per signal row, else one per channel
+};
+
+__global__ __launch_bounds__(256) void spec_gate_kernel(const GateKArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gbits[];   // [TN + 2 ht][F + 2 hf]
+  __shared__ float s_tf[2 * GATE_MAXH + 1], s_tt[2 * GATE_MAXH + 1];
+  const int hf = A.kf / 2, ht = A.kt / 2;
+  const int FP = A.F + 2 * hf;
+  const int tiles = (A.N + GATE_TN - 1) / GATE_TN;
+  const int64_t row = blockIdx.x / tiles;
+  const int n0 = (int)(blockIdx.x - row * tiles) * GATE_TN;
+  const int nrows = GATE_TN + 2 * ht;
+  if (threadIdx.x < A.kf) s_tf[threadIdx.x] = A.tf[threadIdx.x];
+  if (threadIdx.x < A.kt) s_tt[threadIdx.x] = A.tt[threadIdx.x];
+  const float2* __restrict__ Xr = A.X + row * (int64_t)A.N * A.F;
+  const float* __restrict__ thr = A.thr_db + (A.thr_per_item ? row : row % A.C) * (int64_t)A.F;
+  // gate bits of frames n0 - ht .. n0 + TN + ht - 1 (zeros outside the spectrogram and in the frequency halo)
+  for (int i = threadIdx.x; i < nrows * FP; i += 256) {
+    const int r = i / FP, fp = i - r * FP;
+    const int n = n0 - ht + r, f = fp - hf;
+    unsigned char g = 0;
+    if (n >= 0 && n < A.N && f >= 0 && f < A.F) {
+      const float2 v = Xr[(int64_t)n * A.F + f];
+      const float db = 20.0f * log10f(fmaxf(hypotf(v.x, v.y), 1e-4f));
+      g = db < thr[f] ? 1 : 0;
+    }
+    gbits[i] = g;
+  }
+  __syncthreads();
+  const float amt = A.amount[row / A.C];
+  float2* __restrict__ Yr = A.Y + row * (int64_t)A.N * A.F;
+  for (int f = threadIdx.x; f < A.F; f += 256) {
+    float g1[GATE_TN + 2 * GATE_MAXH];
+#pragma unroll
+    for (int r = 0; r < GATE_TN + 2 * GATE_MAXH; ++r) {
+      float acc = 0.f;
+      if (r < nrows) {
+        const unsigned char* __restrict__ gp = gbits + r * FP + f;      // taps f - hf .. f + hf sit at f .. f + 2 hf
+        for (int d = 0; d < A.kf; ++d) acc = fmaf(s_tf[d], (float)gp[d], acc);
+      }
+      g1[r] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < GATE_TN; ++j) {
+      const int n = n0 + j;
+      if (n < A.N) {
+        float sm = 0.f;
+#pragma unroll
+        for (int d = 0; d < 2 * GATE_MAXH + 1; ++d)
+          if (d < A.kt) sm = fmaf(s_tt[d], g1[j + d], sm);
+        const float keep = 1.0f - amt * sm;
+        const float2 v = Xr[(int64_t)n * A.F + f];
+        Yr[(int64_t)n * A.F + f] = make_float2(v.x * keep, v.y * keep);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// Spectral gate: Y = X (1 - amount[b] * conv2d(gate, outer(tf, tt))) with gate = 20 log10(max(|X|, 1e-4)) < thr_db
+// (ml/layers/spectral_gate.py:96-121).  X, Y (B, C, N, F) complex64 bin-contiguous; thr_db (B * C, F) when
+// thr_per_item else (C, F) (a one-item noise clip broadcast over the batch); tf (kf), tt (kt): the two tents, their
+// outer product being the NORMALISED smoothing filter (kf, kt odd, <= 17); amount (B).
+int at_spec_gate_f32(const float* X, float* Y, int64_t B, int64_t C, int64_t N, int64_t F, const float* thr_db,
+                     int thr_per_item, const float* amount, const float* tf, int kf, const float* tt, int kt, void* stream) {
+  if (B == 0) return AT_OK;
+  if (!X || !Y || !thr_db || !amount || !tf || !tt || B < 0 || C <= 0 || N <= 0 || F <= 0) return AT_ERR_INVALID;
+  if (kf < 1 || kt < 1 || !(kf & 1) || !(kt & 1) || kf > 2 * GATE_MAXH + 1 || kt > 2 * GATE_MAXH + 1) return AT_ERR_UNSUPPORTED;
+  if (N >= (1LL << 31) || F >= (1LL << 30)) return AT_ERR_UNSUPPORTED;
+  GateKArgs A;
+  A.X = reinterpret_cast<const float2*>(X); A.Y = reinterpret_cast<float2*>(Y); A.thr_db = thr_db; A.amount = amount;
+  A.tf = tf; A.tt = tt; A.rows = B * C; A.N = (int)N; A.F = (int)F; A.C = (int)C; A.kf = kf; A.kt = kt;
+  A.thr_per_item = thr_per_item;
+  const size_t lds = (size_t)(GATE_TN + 2 * (kt / 2)) * (F + 2 * (kf / 2));
+  if (lds > 150 * 1024) return AT_ERR_UNSUPPORTED;
+  int e = at::allow_big_lds(reinterpret_cast<const void*>(spec_gate_kernel));
+  if (e != AT_OK) return e;
+  const int64_t tiles = (N + GATE_TN - 1) / GATE_TN;
+  if (B * C * tiles > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(spec_gate_kernel, dim3((unsigned)(B * C * tiles)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), A);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
 
 // X (B, C, N, F) complex64 interleaved, bin-contiguous.  axis 0: bins f with lo[b] <= grid[f] < hi[b]
 // (grid = linspace(0, sr/2, F) as float32); axis 1: frames n with lo[b] <= grid[n] < hi[b]

@@ -452,6 +452,23 @@ def spec_maxpow(X: torch.Tensor) -> torch.Tensor:
     return mp
 
 
+def spec_gate(X: torch.Tensor, thr_db: torch.Tensor, amount: torch.Tensor, tf: torch.Tensor, tt: torch.Tensor):
+    """``X * (1 - amount * conv2d(20 log10(max(|X|, 1e-4)) < thr_db, outer(tf, tt)))`` for a native (B, C, F, N)
+    spectrum (``at_spec_gate_f32``).  ``thr_db`` (B or 1, C, F); ``amount`` broadcastable to (B,); ``tf`` / ``tt`` the
+    two 1-D factors of the normalised smoothing filter."""
+    Y, Yr, Xr, B, C, N, F = _spec_out(X)
+    thr = thr_db.to(X.device, torch.float32).reshape(-1, C, F).contiguous()
+    assert thr.shape[0] in (1, B)
+    amt = amount.to(X.device, torch.float32).reshape(-1).expand(B).contiguous()
+    tf = tf.to(X.device, torch.float32).contiguous()
+    tt = tt.to(X.device, torch.float32).contiguous()
+    code = _native.lib().at_spec_gate_f32(_native.ptr(Xr), _native.ptr(Yr), B, C, N, F, _native.ptr(thr), 1 if thr.shape[0] == B and B > 1 else 0,
+                                          _native.ptr(amt), _native.ptr(tf), int(tf.numel()), _native.ptr(tt), int(tt.numel()),
+                                          _native.current_stream(X.device))
+    _native.check(code, "at_spec_gate_f32")
+    return Y
+
+
 def spec_phase_shift(X: torch.Tensor, shift: torch.Tensor):
     Y, Yr, Xr, B, C, N, F = _spec_out(X)
     sh = shift.reshape(-1).to(X.device, torch.float32).expand(B).contiguous()

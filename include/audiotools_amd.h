@@ -210,6 +210,13 @@ int at_spec_phase_shift_f32(const float* src, float* X, int64_t B, int64_t C, in
 int at_spec_polar_elem_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const float* a,
                            const float* b, int mode, void* stream);
 int at_spec_maxpow_f32(const float* X, int64_t n, float* out, void* stream);
+/* Spectral gate core (audiotools/ml/layers/spectral_gate.py:96-121):
+ *   gate = 20 log10(max(|X|, 1e-4)) < thr_db;  Y = X * (1 - amount[b] * conv2d(gate, outer(tf, tt), zero padding))
+ * in ONE pass (gate bits of 16 + halo frames in LDS, separable tent smoothing in registers) instead of ~8 torch passes.
+ * X, Y (B, C, N, F) complex64 bin-contiguous; thr_db (B*C, F) if thr_per_item else (C, F); amount (B); tf (kf), tt (kt)
+ * odd lengths <= 17 whose outer product is the normalised smoothing filter. */
+int at_spec_gate_f32(const float* X, float* Y, int64_t B, int64_t C, int64_t N, int64_t F, const float* thr_db,
+                     int thr_per_item, const float* amount, const float* tf, int kf, const float* tt, int kt, void* stream);
 int at_spec_mask_lowmag_f32(const float* src, float* X, int64_t B, int64_t C, int64_t N, int64_t F, const double* cutoff_db,
                             const float* maxpow, float top_db, int use_top_db, float val, void* stream);
 

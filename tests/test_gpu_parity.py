@@ -1359,3 +1359,42 @@ def test_spectral_transforms_use_the_fused_inverse():
             kernels.istft = orig
         assert calls == [True], (type(t).__name__, calls)
         assert rel_err(got, ref) < REL, type(t).__name__
+
+
+@pytest.mark.parametrize("nz_batch,amount", [(1, 1.0), (3, torch.tensor([0.5, 1.0, 0.8])), (1, 0.0)])
+def test_spectral_gate_kernel_vs_torch_formulation(nz_batch, amount):
+    """csrc/specedit.hip spec_gate_kernel (gate bits in LDS, separable tent smoothing, complex product: one pass)
+    against the reference's whole-tensor formulation (ml/layers/spectral_gate.py:96-121) evaluated with torch ops ON
+    THE SAME DEVICE SPECTRUM, so the only differences are bins whose dB value sits on the threshold."""
+    from audiotools_amd.ml.layers import SpectralGate
+    sr = 44100
+    x = synth.audio_batch(3, 2, 30000 + 11, seed=5, gaps=False)
+    nz = 0.02 * torch.randn(nz_batch, 2, 15000, generator=torch.Generator().manual_seed(8))
+    gate = SpectralGate(3, 5).to("cuda")
+    sig = A.AudioSignal(x.clone(), sr).to("cuda")
+    noise = A.AudioSignal(nz.clone(), sr).to("cuda")
+    got = gate(sig, noise, amount, n_std=2.0)
+    # the torch formulation on the device (the module's own fallback branch)
+    saved = kernels.spec_native
+    kernels.spec_native = lambda X: False
+    try:
+        ref = gate(sig, noise, amount, n_std=2.0)
+    finally:
+        kernels.spec_native = saved
+    d = (got.audio_data - ref.audio_data).abs()
+    scale = ref.audio_data.abs().amax(-1, keepdim=True)
+    assert float((d > 1e-3 * scale).float().mean()) < 1e-3          # isolated threshold flips only
+    assert float(d.max() / scale.max()) < 0.05
+    if isinstance(amount, float) and amount == 0.0:
+        assert rel_err(got.audio_data, ref.audio_data) < 1e-5
+    # the gate kernel itself against the formula on a small spectrum, exactly (thresholds far from the data)
+    X = torch.view_as_complex(torch.randn(2, 1, 37, 65, 2, generator=torch.Generator().manual_seed(1))).cuda()   # (B, C, N, F) physical
+    Xl = X.transpose(2, 3)
+    thr = torch.full((1, 1, 65), -3.0)
+    tf, tt = gate.tent_f.cpu(), gate.tent_t.cpu()
+    Y = kernels.spec_gate(Xl, thr, torch.tensor([1.0, 0.5]), tf, tt)
+    db = 20 * Xl.abs().clamp(1e-4).log10()
+    g = (db < -3.0).float()
+    sm = torch.nn.functional.conv2d(g.reshape(2, 1, 65, 37), torch.outer(tf, tt)[None, None].cuda(), padding=(3, 5)).reshape(2, 1, 65, 37)
+    want = Xl * (1 - sm * torch.tensor([1.0, 0.5]).cuda()[:, None, None, None])
+    assert rel_err(torch.view_as_real(Y), torch.view_as_real(want)) < 1e-5
