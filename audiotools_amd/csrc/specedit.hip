@@ -177,8 +177,11 @@ struct GateKArgs {
 };
 
 __global__ __launch_bounds__(256) void spec_gate_kernel(const GateKArgs A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char gbits[];   // [TN + 2 ht][F + 2 hf]
-  __shared__ float s_tf[2 * GATE_MAXH + 1], s_tt[2 * GATE_MAXH + 1];
+  // dynamic LDS only (a static array next to a raised dynamic limit fails the launch): the two tents, then the bits
+  extern __shared__ __attribute__((aligned(16))) unsigned char gate_lds[];
+  float* s_tf = reinterpret_cast<float*>(gate_lds);
+  float* s_tt = s_tf + 2 * GATE_MAXH + 1;
+  unsigned char* gbits = gate_lds + 2 * (2 * GATE_MAXH + 1) * sizeof(float) + 8;   // [TN + 2 ht][F + 2 hf]
   const int hf = A.kf / 2, ht = A.kt / 2;
   const int FP = A.F + 2 * hf;
   const int tiles = (A.N + GATE_TN - 1) / GATE_TN;
@@ -249,10 +252,12 @@ int at_spec_gate_f32(const float* X, float* Y, int64_t B, int64_t C, int64_t N, 
   A.X = reinterpret_cast<const float2*>(X); A.Y = reinterpret_cast<float2*>(Y); A.thr_db = thr_db; A.amount = amount;
   A.tf = tf; A.tt = tt; A.rows = B * C; A.N = (int)N; A.F = (int)F; A.C = (int)C; A.kf = kf; A.kt = kt;
   A.thr_per_item = thr_per_item;
-  const size_t lds = (size_t)(GATE_TN + 2 * (kt / 2)) * (F + 2 * (kf / 2));
+  const size_t lds = (size_t)(GATE_TN + 2 * (kt / 2)) * (F + 2 * (kf / 2)) + 2 * (2 * GATE_MAXH + 1) * sizeof(float) + 8;
   if (lds > 150 * 1024) return AT_ERR_UNSUPPORTED;
-  int e = at::allow_big_lds(reinterpret_cast<const void*>(spec_gate_kernel));
-  if (e != AT_OK) return e;
+  if (lds > 48 * 1024) {
+    int e = at::allow_big_lds(reinterpret_cast<const void*>(spec_gate_kernel));
+    if (e != AT_OK) return e;
+  }
   const int64_t tiles = (N + GATE_TN - 1) / GATE_TN;
   if (B * C * tiles > 0x7fffffffLL) return AT_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(spec_gate_kernel, dim3((unsigned)(B * C * tiles)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), A);
