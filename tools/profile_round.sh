@@ -16,9 +16,9 @@ timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_lds -o bench -- $CMD > $O/pmc_lds.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_mem -o bench -- $CMD > $O/pmc_mem.log 2>&1
 python3 - $O <<'PY'
-import csv, glob, sys, collections, json, os
+import csv, glob, sys, collections, json, os, socket
 O = sys.argv[1]
-out = {}
+out = {"box": socket.gethostname(), "command": "bench.py --steps 10 --warmup 3 --no-cpu-baseline (one rocprofv3 pass per counter group)"}
 st = glob.glob(O + "/stats/**/*kernel_stats.csv", recursive=True)
 if st:
     rows = list(csv.DictReader(open(st[0])))
