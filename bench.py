@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the north-star step from a captured HIP graph instead of eager launches")
+    ap.add_argument("--no-share", action="store_true",
+                    help="skip the share_64 block (the 8-GPU share timed on this device): profile runs use it so that the "
+                         "per-kernel averages of rocprofv3 only see launches of the benchmark's own size")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only (process group, sharding, table broadcast; gloo on a CPU-only host): no kernels")
     args = ap.parse_args()
@@ -333,7 +336,7 @@ def main():
         # the 8-GPU share timed on THIS device: what one rank of an 8-way batch shard would run, so that the
         # first measured scaling curve has a prediction to be checked against (no collective on the data path)
         share = None
-        if world == 1 and n_local >= 16 and not args.graph:
+        if world == 1 and n_local >= 16 and not args.graph and not args.no_share:
             n_sh = n_local // 8
             sig_sh = A.AudioSignal(x[:n_sh], sr)
             res_sh = {}

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profile_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline $*"
+CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share $*"
 # 1. kernel trace + stats for the bench command
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $CMD > $O/bench_stats.log 2>&1
 # 2. HBM traffic counters, each in its own pass (guide: FETCH_SIZE 3 TCC slots, WRITE_SIZE 2)
@@ -18,7 +18,7 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VME
 python3 - $O <<'PY'
 import csv, glob, sys, collections, json, os, socket
 O = sys.argv[1]
-out = {"box": socket.gethostname(), "command": "bench.py --steps 10 --warmup 3 --no-cpu-baseline (one rocprofv3 pass per counter group)"}
+out = {"box": socket.gethostname(), "command": "bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share (one rocprofv3 pass per counter group)"}
 st = glob.glob(O + "/stats/**/*kernel_stats.csv", recursive=True)
 if st:
     rows = list(csv.DictReader(open(st[0])))
