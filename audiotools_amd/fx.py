@@ -181,9 +181,12 @@ class EffectMixin:
         self._convolve(other, start_at_max, want_peaks=False)
         return self
 
-    def _convolve(self, other, start_at_max: bool, want_peaks: bool):
+    def _convolve(self, other, start_at_max: bool, want_peaks: bool, scratch_ir: bool = False):
         """``convolve``; with ``want_peaks`` returns (max|x|, max|y|) per (B, C, 1) when the native
-        four-step path found them inside the transforms (apply_ir needs both), else None."""
+        four-step path found them inside the transforms (apply_ir needs both), else None.
+        ``scratch_ir``: ``other`` is a throw-away object nobody will look at again (the transform's own
+        copy), so the reference's side effect on it -- padded / truncated to T in place -- is skipped
+        where the native path does not read the padded samples (a 1 GB write at cfg4)."""
         T = self.signal_length
         x = self.audio_data
         ir0 = other.audio_data
@@ -200,7 +203,9 @@ class EffectMixin:
             if start_at_max and raw.shape[1] != 1:
                 raise RuntimeError("start_at_max requires a single-channel impulse response")
         pad_len = T - other.signal_length
-        if pad_len > 0:
+        if room and scratch_ir:
+            pass
+        elif pad_len > 0:
             other.zero_pad(0, pad_len)          # the reference pads / truncates its argument in place
         else:
             other.truncate_samples(T)
@@ -248,7 +253,14 @@ class EffectMixin:
 
     def apply_ir(self, ir, drr=None, ir_eq=None, use_original_phase: bool = False):
         """Room simulation: optional IR EQ and DRR change, convolve, restore
-        the input peak (effects.py:125-179)."""
+        the input peak (effects.py:125-179).  ``ir`` is modified in place (EQ, DRR, padding to the
+        signal's length), as in the reference."""
+        return self._apply_ir(ir, drr, ir_eq, use_original_phase, False)
+
+    def _apply_ir(self, ir, drr, ir_eq, use_original_phase, scratch_ir):
+        """``apply_ir``; with ``scratch_ir`` the caller hands over an ``ir`` OBJECT it will not look at again
+        (it may share its samples with a signal that lives on: nothing below writes into them, the EQ
+        and DRR steps give ``ir`` new sample tensors)."""
         if ir_eq is not None:
             ir = ir.equalizer(ir_eq)
         if drr is not None:
@@ -259,7 +271,7 @@ class EffectMixin:
         # computed when it is used, and ``stft_data`` is left untouched otherwise.
         phase = self.phase if use_original_phase else None
         x_in = self.audio_data
-        peaks = self._convolve(ir, True, want_peaks=True)
+        peaks = self._convolve(ir, True, want_peaks=True, scratch_ir=scratch_ir)
         # max|input| (effects.py:160) and max|output| (:175): from inside the convolution when the
         # native path ran, otherwise by their own passes
         max_spk = peaks[0] if peaks is not None else _peak(x_in)

@@ -28,7 +28,7 @@ from typing import List
 import numpy as np
 import torch
 
-from . import util
+from . import kernels, util
 from .signal import AudioSignal
 
 tt = torch.tensor
@@ -754,6 +754,14 @@ class RoomImpulseResponse(BaseTransform):
                 "mask": _assemble([st.rand() <= self.prob for st in states])}
 
     def _transform(self, signal, ir_signal, drr, eq):
+        # The reference clones the impulse responses because apply_ir edits its argument in place
+        # (transforms.py:1297).  With device-resident samples every one of those edits produces a NEW tensor
+        # (per-item FIR, alter_drr kernel), so a second OBJECT over the same samples protects ``ir_signal``
+        # just as well and saves the copy; the padding of the throw-away object to the signal's length is
+        # skipped with it (0.45 ms of the 5.6 ms apply_ir at cfg4).
+        if kernels.is_native(ir_signal.audio_data) and kernels.is_native(signal.audio_data):
+            scratch = type(ir_signal)(ir_signal.audio_data, ir_signal.sample_rate, stft_params=ir_signal.stft_params)
+            return signal._apply_ir(scratch, drr, eq, self.use_original_phase, True)
         return signal.apply_ir(ir_signal.clone(), drr, eq, use_original_phase=self.use_original_phase)
 
 

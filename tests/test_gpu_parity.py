@@ -1020,6 +1020,10 @@ def test_cfg4_full_size_chain():
     # apply_ir restores the peak of ITS input (effects.py:174-177): peak(out) == peak(after EQ)
     mid = A.AudioSignal(x.clone(), SR).low_pass(c["0.LowPass"]["cutoff"].cuda()).equalizer(c["1.Equalizer"]["eq"].cuda())
     assert float((out.abs().amax(-1) / mid.audio_data.abs().amax(-1) - 1).abs().max()) < 1e-4
+    # the transform works on a second OBJECT over the impulse responses' samples instead of the reference's clone:
+    # the caller's signal keeps its samples and its length
+    ir_after = kwd["Compose"]["2.RoomImpulseResponse"]["ir_signal"].audio_data
+    assert ir_after.shape == (B, 1, 2 * SR) and torch.equal(ir_after[idx].cpu(), ir_subset)
     out2 = chain(A.AudioSignal(x.clone(), SR), **kwd).audio_data
     assert torch.equal(out2, out)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))

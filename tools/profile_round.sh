@@ -8,7 +8,9 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share $*"
 # 1. kernel trace + stats for the bench command
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $CMD > $O/bench_stats.log 2>&1
+# (more steps than the counter passes: the first launches after start-up run 20-40 % slow while clocks ramp, and the
+#  per-kernel AVERAGE of this file is what bench.py's roofline.avg_launch_ms is checked against)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-share $* > $O/bench_stats.log 2>&1
 # 2. HBM traffic counters, each in its own pass (guide: FETCH_SIZE 3 TCC slots, WRITE_SIZE 2)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o bench -- $CMD > $O/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o bench -- $CMD > $O/pmc_write.log 2>&1
@@ -18,7 +20,12 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VME
 python3 - $O <<'PY'
 import csv, glob, sys, collections, json, os, socket
 O = sys.argv[1]
-out = {"box": socket.gethostname(), "command": "bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share (one rocprofv3 pass per counter group)"}
+import subprocess
+try:
+    uid = [l.split(":")[-1].strip() for l in subprocess.run(["rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=30).stdout.splitlines() if "Unique ID" in l][0]
+except Exception:
+    uid = "unknown"
+out = {"box": "MI355X unique id " + uid, "stats_command": "bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-share", "command": "bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share (one rocprofv3 pass per counter group)"}
 st = glob.glob(O + "/stats/**/*kernel_stats.csv", recursive=True)
 if st:
     rows = list(csv.DictReader(open(st[0])))
