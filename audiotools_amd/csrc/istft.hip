@@ -152,6 +152,8 @@ struct IstftFusedArgs {
   const float2* tw;       // (N)
   const float* inv_env;   // ((n_frames-1)*hop + N): 1 / sum_f w^2, 0 where the envelope vanishes
   float* dump;            // 1024 floats behind the envelope table: per-lane, per-q sink of edge-step pair stores (never read)
+  const float2* zeros;    // ZERO_PAGE_FLOATS zero floats behind the dump slots (written by istft_env_kernel): the "spectrum"
+                          // of the virtual all-zero frames
   float* out;             // (rows, length)
   int64_t rows;
   int64_t length;
@@ -185,8 +187,14 @@ struct IstftFusedArgs {
 struct __attribute__((packed, aligned(4))) f2u { float x, y; };  // dword-aligned pair
 
 // envelope: every padded position gathers w^2 of the <= N/hop frames that cover it
+constexpr int DUMP_FLOATS = 1024;
+constexpr int ZERO_PAGE_FLOATS = 2304;   // >= 2 (1024 + 1): one frame of the largest fused size
+
 __global__ __launch_bounds__(256) void istft_env_kernel(const float* __restrict__ window, float* __restrict__ inv_env,
                                                         int n_frames, int N, int hop, int64_t total) {
+  // the zero page behind the envelope table and the dump slots
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ZERO_PAGE_FLOATS; i += (int64_t)gridDim.x * blockDim.x)
+    inv_env[total + DUMP_FLOATS + i] = 0.f;
   for (int64_t pp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pp < total; pp += (int64_t)gridDim.x * blockDim.x) {
     int64_t f_hi = pp / hop;
     if (f_hi > n_frames - 1) f_hi = n_frames - 1;
@@ -229,6 +237,13 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   using P = Plan<M>;
   constexpr int L = P::L, FW = P::FW, N = 2 * M, HOP = 2 * L * SH, R = N / HOP;
   constexpr bool DUMP = !ADJ;   // the inverse transform has a workspace (envelope table + dump slots behind it)
+  // A virtual all-zero frame (match_stride's edge frames, the lead-in / lead-out steps of a run) LOADS zeros from a
+  // zero page of the workspace instead of loading frame 0 and being zeroed afterwards.  At M = 1024 a wave holds one
+  // frame, "dead" is wave-uniform, and the compiler turned the zeroing into 16 uniform branches per frame -- one
+  // around every fold butterfly --, i.e. 16 basic blocks whose two ds_bpermute + one ds_read each had to come back
+  // before the next could be issued.  Without the zeroing the fold is one block: 32 + 16 LDS operations in flight
+  // (1.963 -> 1.954 ms at B = 512, same box interleaved, profiles/r03_notes.md).
+  constexpr bool ZERO_PAGE = !ADJ && !MELB && !EDIT;
   __shared__ float2 lds[4 * WAVE_LDS_SLOTS];
   __shared__ float2 s_win2[M];
   __shared__ float2 s_twf[M];                                     // fold twiddles (cos, -sin)(2 pi k / N), k < M
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   auto issue_loads = [&](int f) __attribute__((always_inline)) -> bool {
     const int fx = f - A.lead;
     const bool live = fx >= 0 && fx < A.n_x && f < h1;
-    const float2* __restrict__ Xf = Xrow + (int64_t)(live ? fx : 0) * (M + 1);
+    const float2* __restrict__ Xf = (ZERO_PAGE && !live) ? A.zeros : Xrow + (int64_t)(live ? fx : 0) * (M + 1);
 #pragma unroll
     for (int q = 0; q < 16; ++q) xa[q] = at::ldg2<AT_NT_ISTFT_LD != 0>(Xf + t + L * q);
     xN = at::ldg2<AT_NT_ISTFT_LD != 0>(Xf + M);
@@ -385,7 +400,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
       const float2 sv = make_float2(__shfl(xa[15 - q].x, src_lane, 64), __shfl(xa[15 - q].y, src_lane, 64));
       const float2 own = q == 0 ? xN : xa[q == 0 ? 0 : 16 - q];
       float2 xm = t == 0 ? own : sv;
-      if (!live) { xk = make_float2(0.f, 0.f); xm = xk; }
+      if constexpr (!ZERO_PAGE) { if (!live) { xk = make_float2(0.f, 0.f); xm = xk; } }
       if (k == 0) {  // c2r ignores the imaginary part of DC and Nyquist
         xk.y = 0.f; xm.y = 0.f;
         if (ADJ) { xk.x *= 2.f; xm.x *= 2.f; }
@@ -499,6 +514,8 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     for (int q = 0; q < 16 - SH; ++q) acc[q] = acc[q + SH];
 #pragma unroll
     for (int q = 16 - SH; q < 16; ++q) acc[q] = make_float2(0.f, 0.f);
+    // (renaming the window instead of shifting it -- the step unrolled over the N / hop phases -- was tried: the four
+    //  copies of the step push the allocation past 256 registers, 93 spilled at M = 1024, 4.93 ms instead of 1.95)
   };
 
   // every slot runs the same trip count; frames outside [lead, lead + n_x) are all-zero
@@ -632,7 +649,8 @@ extern "C" {
 int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft, int hop) {
   if (rows < 0 || n_frames <= 0 || n_fft <= 0 || hop <= 0) return AT_ERR_INVALID;
   const bool fused_size = n_fft >= 32 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0;
-  if (fused_size && fused_shift(n_fft, hop)) return ((n_frames - 1) * hop + n_fft + 1024) * 4;   // envelope table + dump slots
+  if (fused_size && fused_shift(n_fft, hop))     // envelope table + dump slots + zero page
+    return ((n_frames - 1) * hop + n_fft + DUMP_FLOATS + ZERO_PAGE_FLOATS) * 4;
   return rows * n_frames * (int64_t)n_fft * 4;
 }
 
@@ -675,6 +693,7 @@ static int istft_run(const float* X, int64_t rows, int64_t n_x, const float* win
     F.X = reinterpret_cast<const float2*>(X); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
     F.inv_env = reinterpret_cast<const float*>(workspace); F.out = out; F.rows = rows; F.length = length;
     F.dump = reinterpret_cast<float*>(workspace) + ((n_frames - 1) * hop + n_fft);
+    F.zeros = reinterpret_cast<const float2*>(F.dump + DUMP_FLOATS);
     F.n_x = (int)n_x; F.lead = lead; F.n_frames = (int)n_frames;
     F.gmel = nullptr; F.bin_bands = nullptr; F.bin_w = nullptr; F.n_mels = 0;
     F.edit_kind = 0;
@@ -774,7 +793,7 @@ int at_stft_adjoint_f32(const float* G, int64_t rows, int64_t n_frames, const fl
   if (rows == 0) return AT_OK;
   IstftFusedArgs F;
   F.X = reinterpret_cast<const float2*>(G); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
-  F.inv_env = nullptr; F.dump = nullptr; F.out = out; F.rows = rows; F.length = out_len;
+  F.inv_env = nullptr; F.dump = nullptr; F.zeros = nullptr; F.out = out; F.rows = rows; F.length = out_len;
   F.n_x = (int)n_frames; F.lead = 0; F.n_frames = (int)n_frames;
   F.gmel = nullptr; F.bin_bands = nullptr; F.bin_w = nullptr; F.n_mels = 0;
   plan_runs(F, rows, n_fft, hop);
@@ -798,7 +817,7 @@ int at_stft_mel_adjoint_f32(const float* X, const float* gmel, const int* bin_ba
   if (n_mels > 8 * (n_fft / 32) || n_mels >= 0xffff || n_frames >= (1LL << 31) / n_fft) return AT_ERR_UNSUPPORTED;
   IstftFusedArgs F;
   F.X = reinterpret_cast<const float2*>(X); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
-  F.inv_env = nullptr; F.dump = nullptr; F.out = out; F.rows = rows; F.length = out_len;
+  F.inv_env = nullptr; F.dump = nullptr; F.zeros = nullptr; F.out = out; F.rows = rows; F.length = out_len;
   F.n_x = (int)n_frames; F.lead = 0; F.n_frames = (int)n_frames;
   F.gmel = gmel; F.bin_bands = bin_bands; F.bin_w = reinterpret_cast<const float2*>(bin_w); F.n_mels = n_mels;
   plan_runs(F, rows, n_fft, hop);
