@@ -33,7 +33,8 @@ HEADERS = ["at_common.h", "fft_wave.h", "generic_fft.h"]
 _NO_SLP = ["-fno-slp-vectorize"]
 # loudness.hip (round 3): the scalar build of kweight_hop_energy_dma needs 86 VGPRs instead of 113 and its loop has
 # fewer issue slots (803 scalar FP + 74 moves vs 605 scalar + 126 half-rate packed + 121 moves).
-FILE_FLAGS = {"stft.hip": _NO_SLP, "istft.hip": _NO_SLP, "firfft.hip": _NO_SLP, "longconv.hip": _NO_SLP, "loudness.hip": _NO_SLP}
+FILE_FLAGS = {"stft.hip": _NO_SLP, "istft.hip": _NO_SLP, "firfft.hip": _NO_SLP, "longconv.hip": _NO_SLP, "loudness.hip": _NO_SLP,
+              "stft_generic.hip": _NO_SLP}
 LINK_FLAGS = ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
 
 

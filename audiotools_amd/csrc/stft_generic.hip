@@ -351,6 +351,262 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
   }
 }
 
+// =============================================================================================
+// The tile of stft_generic_tiled_kernel for its two power-of-two plans (M = 2048: two frames, radices 16 16 8;
+// M = 4096: one frame, 16 16 16), written out by hand so that EVERY LDS ADDRESS IS A PER-THREAD BASE PLUS AN
+// IMMEDIATE.  The generic passes compute  batch N + (p ^ ((p >> 4) & 15))  per access -- five VALU instructions,
+// ~150 accesses per thread and tile: a third of the ~2000 instructions that made the first tiled kernel VALU-issue
+// bound (profiles/r03_notes.md).  In the XOR-swizzled row layout a(e) = e ^ ((e >> 4) & 15), e = point of the tile:
+//   * offsets that are multiples of 256 commute with the swizzle: sample stores, pass 3, both reads of the split
+//     step are  a(t) + 256 i  resp.  a(256 - t) + 256 i;
+//   * the reads of the radix-16 passes, points j + (M / 16) q: one base for M = 4096, two (even / odd q) for
+//     M = 2048, where the stride 128 flips bit 3 of the swizzle key;
+//   * their writes, points 16 j + q and 256 (j >> 4) + 16 q + (j & 15): the key is j & 15 resp. q, i.e. one XOR
+//     with a per-thread constant per access.
+// One pad slot per 256 points on top of it (slot = a(e) + (e >> 8)): every LDS instruction of the tile touches one
+// 256-block per lane group, so the pad is uniform per instruction (no new conflicts), but the reads of a pass are no
+// longer multiples of 512 bytes apart and the compiler cannot fuse them into ds_read2st64_b64 -- half the rate of two
+// ds_read_b64 and banked mod 32 (MI355X_MICROARCH.md, LDS table); the same trick as PAD256 in fft_wave.h.
+// Pass 3 (NS = 256) reads and writes the SAME slots of the same thread: no barrier inside it.  The split step
+// forms X[k] and X[M - k] from one evaluation of the pair (Z[k], Z[M - k]) (the generic sweep evaluates every
+// bin on its own: twice the arithmetic), k = t + 256 i < M / 2 ascending, M - k descending -- both 512-byte
+// segments per wave --, and k = M / 2 by every thread (same value to the same address: the store count of a tile
+// stays static).  Everything else -- runs, XCD spans, clamped prefetch, chunked mel epilogue -- is the generic tile.
+template <int PLAN>
+__global__ __launch_bounds__(256, 2) void stft_tiled_pow2_kernel(const Gen2Args A) {
+  extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
+  constexpr int M = PLAN == 1 ? 2048 : 4096, FB = PLAN == 1 ? 2 : 1, N = 2 * M;
+  constexpr int R3 = PLAN == 1 ? 8 : 16;          // last radix
+  constexpr int NB3 = PLAN == 1 ? 2 : 1;          // pass-3 butterflies per thread (one per frame)
+  constexpr int NPI = M / 512;                    // pair iterations per frame: k = t + 256 i < M / 2
+  constexpr int NWR = M / 256;                    // distinct window pairs per thread
+  constexpr int NMG = FB * (2 * NPI + 1);         // bins (magnitudes) per thread and tile
+  constexpr int FS = M + M / 256;                 // slots of a frame incl. its pads
+  using at::gfft::dft_r;
+  float2* buf = gbuf;                             // [4096 + 16], swizzled + padded
+  float2* tw = gbuf + 4096 + 16;                  // pass blocks: [0, 240) pass 2, [240, 240 + 257 (R3 - 1)) pass 3
+  float2* stw = tw + M;                           // [M / 2 + 1]: split twiddles w_N^j
+  float* melw = reinterpret_cast<float*>(stw + M / 2 + 2);
+  int* mtab = reinterpret_cast<int*>(melw + 16 * A.n_chunks);
+  float* part = reinterpret_cast<float*>(mtab + A.n_chunks + 2 * A.n_mels);
+  float* mag = reinterpret_cast<float*>(gbuf);    // [FB][M + 1], over the transform buffer once Z is consumed
+  const bool MEL = A.mel != nullptr;
+  // pass 2 (NS = 16): tw[(q - 1) 16 + k] = w_256^(k q);  pass 3 (NS = 256): tw[240 + (q - 1) 257 + k] = w_(256 R3)^(k q)
+  // = w_M^(k q) for both plans (the table is per N = 2 M: w_M^x = A.tw[2 x]); rows of 257 for the same reason as the pads
+  for (int idx = threadIdx.x; idx < 240; idx += 256) {
+    const int q1 = idx >> 4, k = idx & 15;
+    tw[idx] = A.tw[2 * (k * (q1 + 1) * (M / 256))];
+  }
+  for (int idx = threadIdx.x; idx < 256 * (R3 - 1); idx += 256) {
+    const int q1 = idx >> 8, k = idx & 255;
+    tw[240 + 257 * q1 + k] = A.tw[2 * (k * (q1 + 1))];
+  }
+  float2 wreg[NWR];
+#pragma unroll
+  for (int i = 0; i < NWR; ++i) wreg[i] = reinterpret_cast<const float2*>(A.window)[threadIdx.x + 256 * i];
+  for (int i = threadIdx.x; i <= M / 2; i += 256) stw[i] = A.tw[i];
+  if (MEL) {
+    for (int i = threadIdx.x; i < 16 * A.n_chunks; i += 256) melw[i] = A.cw[i];
+    for (int i = threadIdx.x; i < A.n_chunks; i += 256) mtab[i] = A.chunk[i];
+    for (int i = threadIdx.x; i < 2 * A.n_mels; i += 256) mtab[A.n_chunks + i] = A.band[i];
+  }
+  __syncthreads();
+  const at::gfft::RowLayout lay{M, 1};            // the same layout as a function (edge tiles)
+  const int Ti = (int)A.T, n_out = (int)A.n_out, tpr = (int)A.tiles_per_row, hop = A.hop;
+  const int n_x = (int)gridDim.x < A.n_xcd ? (int)gridDim.x : A.n_xcd;
+  const int xcd = blockIdx.x % n_x, lblk = blockIdx.x / n_x;
+  const int nblk_x = ((int)gridDim.x - xcd + n_x - 1) / n_x;
+  const int64_t g_lo = A.total_tiles * xcd / n_x, g_hi = A.total_tiles * (xcd + 1) / n_x;
+
+  auto geom = [&](int64_t g, int& row, int& f0, int& s0) {
+    row = (int)(g / tpr);
+    f0 = min((int)(g - (int64_t)row * tpr) * FB, n_out - FB);
+    s0 = (f0 + A.frame_lo) * hop - M;
+  };
+  auto interior = [&](int s0) { return A.vec2 && A.pad == 0 && s0 >= 0 && s0 + (FB - 1) * hop + N <= Ti; };
+  float2 r[16];
+  auto fetch = [&](int64_t g, bool valid, int tid) __attribute__((always_inline)) {
+    int row = 0, f0 = 0, s0 = 0;
+    if (valid) geom(g, row, f0, s0);
+    const bool ok = valid && interior(s0);
+    const float* __restrict__ xs = A.x + (int64_t)row * A.T + (ok ? s0 : 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i;
+      const int fi = PLAN == 1 ? (i >> 3) : 0, n = e - fi * M;
+      r[i] = *reinterpret_cast<const float2*>(xs + fi * hop + 2 * n);
+    }
+  };
+
+  auto tile = [&](int64_t g, int64_t g_end) __attribute__((always_inline)) {
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));                   // per tile: nothing indexed by it leaves the persistent loops
+    const int st = t ^ ((t >> 4) & 15);           // a(t)
+    int row, f0, s0;
+    geom(g, row, f0, s0);
+    const float* __restrict__ xr = A.x + (int64_t)row * A.T;
+    // ---- windowed samples -> LDS
+    if (interior(s0)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float2 w = wreg[i & (NWR - 1)];
+        buf[st + 257 * i] = make_float2(r[i].x * w.x, r[i].y * w.y);
+      }
+    } else {
+#pragma unroll 1
+      for (int e = t; e < 4096; e += 256) {
+        const int fi = e >= M ? 1 : 0, n = e - fi * M;
+        const int64_t sidx = (int64_t)s0 + fi * hop + 2 * n;
+        const float2 w = reinterpret_cast<const float2*>(A.window)[n];
+        buf[lay.addr(fi, n) + (e >> 8)] = make_float2(at::fetch_padded(xr, sidx, A.T, A.T2, A.pad, A.pad_mode) * w.x,
+                                           at::fetch_padded(xr, sidx + 1, A.T, A.T2, A.pad, A.pad_mode) * w.y);
+      }
+    }
+    __syncthreads();
+    fetch(g + 1, g + 1 < g_end, t);               // the next tile's samples: in flight during the passes
+
+    // ---- passes 1 and 2 (radix 16): butterfly j of frame fj
+    const int fj = PLAN == 1 ? (t >> 7) : 0, j = PLAN == 1 ? (t & 127) : t;
+    const int jl = j & 15;
+    const int rb0 = fj * FS + (j ^ ((j >> 4) & 15));                    // reads, even q (M = 4096: every q)
+    const int rb1 = PLAN == 1 ? fj * FS + (j ^ ((j >> 4) | 8)) : rb0;   // M = 2048: odd q (stride 128 sets key bit 3)
+    const int wb1 = fj * FS + 16 * j + (j >> 4);                        // pass-1 writes: + (q ^ jl); block 16 j >> 8
+    const int wb2 = fj * FS + 257 * (j >> 4);                           // pass-2 writes: + 16 q + (jl ^ q)
+    // point stride of the reads incl. pads: 128 q + (q >> 1) resp. 257 q
+    auto rq = [](int q) constexpr { return PLAN == 1 ? 128 * q + (q >> 1) : 257 * q; };
+    float2 v[at::gfft::MAX_RADIX];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = buf[((q & 1) ? rb1 : rb0) + rq(q)];
+    dft_r<16>(v);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) buf[wb1 + (q ^ jl)] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = buf[((q & 1) ? rb1 : rb0) + rq(q)];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmulf(v[q], tw[(q - 1) * 16 + jl]);
+    dft_r<16>(v);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) buf[wb2 + 16 * q + (jl ^ q)] = v[q];
+    __syncthreads();
+    // ---- pass 3 (NS = 256), in place on the thread's own slots
+#pragma unroll
+    for (int b = 0; b < NB3; ++b) {
+#pragma unroll
+      for (int q = 0; q < R3; ++q) v[q] = buf[st + FS * b + 257 * q];
+#pragma unroll
+      for (int q = 1; q < R3; ++q) v[q] = cmulf(v[q], tw[240 + (q - 1) * 257 + t]);
+      dft_r<R3>(v);
+#pragma unroll
+      for (int q = 0; q < R3; ++q) buf[st + FS * b + 257 * q] = v[q];
+    }
+    __syncthreads();
+
+    // ---- split step: pairs (k, M - k), k = t + 256 i; then k = M / 2
+    const int tm = (256 - t) & 255;                                     // low byte of M - k
+    const int sm = (tm ^ ((tm >> 4) & 15)) + (t == 0 ? 257 : 0);        // a(256 - t): t = 0 sits one 256-block (+ its pad) up
+    float mg[NMG];
+    char* __restrict__ obase = reinterpret_cast<char*>(A.out + ((int64_t)row * n_out + f0) * (M + 1));
+    auto split = [&](float2 zk, float2 zm, float2 w, float2& xa, float2& xb) __attribute__((always_inline)) {
+      const float c = w.x, sn = -w.y;
+      const float sr = zk.x + zm.x, si = zk.y - zm.y;
+      const float dr = zk.x - zm.x, di = zk.y + zm.y;
+      const float pp = fmaf(sn, dr, -c * di);
+      const float qq = fmaf(sn, di, c * dr);
+      xa = make_float2(0.5f * (sr - pp), 0.5f * (si - qq));             // X[k]
+      xb = make_float2(0.5f * (sr + pp), 0.5f * (-si - qq));            // X[M - k]
+    };
+#pragma unroll
+    for (int fi = 0; fi < FB; ++fi) {
+      char* __restrict__ ofr = obase + (size_t)fi * (M + 1) * sizeof(float2);
+#pragma unroll
+      for (int i = 0; i < NPI; ++i) {
+        const float2 zk = buf[fi * FS + st + 257 * i];
+        // Z[M - k]: slot a(256 - t) + 257 (2 NPI - 1 - i); k = 0 pairs with Z[0] itself
+        int am = fi * FS + sm + 257 * (2 * NPI - 1 - i);
+        if (i == 0) am = t == 0 ? fi * FS : am;
+        const float2 zm = buf[am];
+        float2 xa, xb;
+        split(zk, zm, stw[t + 256 * i], xa, xb);
+        if (i == 0) { if (t == 0) { xa.y = 0.f; xb.y = 0.f; } }         // DC and Nyquist: exactly real
+        *reinterpret_cast<float2*>(ofr + (size_t)(t + 256 * i) * sizeof(float2)) = xa;
+        *reinterpret_cast<float2*>(ofr + (size_t)(M - 256 * i - 255) * sizeof(float2) + (size_t)(255 - t) * sizeof(float2)) = xb;
+        mg[fi * (2 * NPI + 1) + 2 * i] = __builtin_amdgcn_sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
+        mg[fi * (2 * NPI + 1) + 2 * i + 1] = __builtin_amdgcn_sqrtf(fmaf(xb.x, xb.x, xb.y * xb.y));
+      }
+      {
+        const float2 z = buf[fi * FS + M / 2 + M / 512];                // a(M / 2) = M / 2, + its pads
+        float2 xa, xb;
+        split(z, z, stw[M / 2], xa, xb);
+        *reinterpret_cast<float2*>(ofr + (size_t)(M / 2) * sizeof(float2)) = xa;      // every thread, one address
+        mg[fi * (2 * NPI + 1) + 2 * NPI] = __builtin_amdgcn_sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
+      }
+    }
+    if (MEL) {
+      __syncthreads();                                    // every Z has been read: the buffer becomes |X|
+#pragma unroll
+      for (int fi = 0; fi < FB; ++fi) {
+        float* __restrict__ mf = mag + fi * (M + 1);
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+          mf[t + 256 * i] = mg[fi * (2 * NPI + 1) + 2 * i];
+          mf[(M - 256 * i - 255) + (255 - t)] = mg[fi * (2 * NPI + 1) + 2 * i + 1];
+        }
+        if (t == 0) mf[M / 2] = mg[fi * (2 * NPI + 1) + 2 * NPI];
+      }
+      __syncthreads();
+      const int nch = A.n_chunks;
+#pragma unroll 1
+      for (int task = t; task < FB * nch; task += 256) {
+        const int fi = task >= nch ? 1 : 0, c = task - fi * nch;
+        const float* __restrict__ mrow = mag + fi * (M + 1) + mtab[c];
+        const float4* __restrict__ wq = reinterpret_cast<const float4*>(melw + 16 * c);
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 w = wq[q];
+          acc = fmaf(w.x, mrow[4 * q], acc);
+          acc = fmaf(w.y, mrow[4 * q + 1], acc);
+          acc = fmaf(w.z, mrow[4 * q + 2], acc);
+          acc = fmaf(w.w, mrow[4 * q + 3], acc);
+        }
+        part[task] = acc;
+      }
+      __syncthreads();
+      float* __restrict__ mel0 = A.mel + ((int64_t)row * n_out + f0) * A.n_mels;
+      const int ntask = FB * A.n_mels;
+      if (ntask <= 256) {
+        // one band sum per thread, ALWAYS stored (threads past the end repeat the last one): a static store count
+        const int task = min(t, ntask - 1);
+        const int fi = task >= A.n_mels ? 1 : 0, m = task - fi * A.n_mels;
+        const int c0 = mtab[nch + 2 * m], cn = mtab[nch + 2 * m + 1];
+        float acc = 0.f;
+        for (int c = 0; c < cn; ++c) acc += part[fi * nch + c0 + c];
+        mel0[task] = acc;
+      } else {
+        for (int task = t; task < ntask; task += 256) {
+          const int fi = task >= A.n_mels ? 1 : 0, m = task - fi * A.n_mels;
+          const int c0 = mtab[nch + 2 * m], cn = mtab[nch + 2 * m + 1];
+          float acc = 0.f;
+          for (int c = 0; c < cn; ++c) acc += part[fi * nch + c0 + c];
+          mel0[task] = acc;
+        }
+      }
+    } else {
+      __syncthreads();                                    // every Z has been read: the buffer is free for the next tile
+    }
+  };
+
+  for (int64_t gbase = g_lo + (int64_t)lblk * A.run; gbase < g_hi; gbase += (int64_t)nblk_x * A.run) {
+    const int64_t g_end = min(gbase + A.run, g_hi);
+    fetch(gbase, true, (int)threadIdx.x);
+    tile(gbase, g_end);                                   // peeled: both edges of the loop below carry "loads, then stores"
+    for (int64_t g = gbase + 1; g < g_end; ++g) tile(g, g_end);
+  }
+}
+
 __global__ __launch_bounds__(256) void istft_frames_generic_kernel(const GenInvArgs A) {
   extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
   const int M = A.M, N = 2 * M;
@@ -428,10 +684,14 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
     G.vec2 = ((T % 2) == 0 && (hop % 2) == 0 && (M % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 8) == 0) ? 1 : 0;
     const int plan = (M == 2048 && G.FB == 2) ? 1 : (M == 4096 ? 2 : 0);
     // transform buffer (+ |X| slack), pass twiddles, [window: run-time plans only], split twiddles
-    size_t lds = ((size_t)G.FB * M + (plan == 0 ? 2 : 1) * (size_t)M + M / 2 + 2) * sizeof(float2) + 64;
+    size_t lds = ((size_t)G.FB * M + (plan == 0 ? 2 : 1) * (size_t)M + M / 2 + 2) * sizeof(float2) + 64 + 128;
     if (mel_out) lds += (size_t)G.n_chunks * (16 + 1 + G.FB) * 4 + (size_t)2 * n_mels * 4;
     if (lds > 160 * 1024) return AT_ERR_UNSUPPORTED;
-    const void* kfn = plan == 1 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<1>)
+    static const int old_tile = env_int_once("AT_STFT_TILED_OLD", 0);      // A/B: the generic tile for the fixed plans
+    const bool pow2 = plan != 0 && !old_tile;
+    const void* kfn = pow2 ? (plan == 1 ? reinterpret_cast<const void*>(stft_tiled_pow2_kernel<1>)
+                                        : reinterpret_cast<const void*>(stft_tiled_pow2_kernel<2>))
+                    : plan == 1 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<1>)
                     : plan == 2 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<2>)
                                 : reinterpret_cast<const void*>(stft_generic_tiled_kernel<0>);
     int e = allow_big_lds(kfn);
@@ -453,7 +713,9 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
       int64_t run = (per_wg + runs - 1) / (runs > 0 ? runs : 1);
       G.run = (int)(run < 1 ? 1 : run);
     }
-    if (plan == 1) hipLaunchKernelGGL(stft_generic_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+    if (pow2 && plan == 1) hipLaunchKernelGGL(stft_tiled_pow2_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+    else if (pow2) hipLaunchKernelGGL(stft_tiled_pow2_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+    else if (plan == 1) hipLaunchKernelGGL(stft_generic_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, G);
     else if (plan == 2) hipLaunchKernelGGL(stft_generic_tiled_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, G);
     else hipLaunchKernelGGL(stft_generic_tiled_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, st, G);
     AT_LAUNCH_CHECK();
