@@ -1037,7 +1037,7 @@ int at_mel_units_host(const float* basis, int n_mels, int n_bins, int* unit_info
 }
 
 // Host helper: the BANDED form of a dense (n_mels, n_bins) filterbank for the generic-size kernel: every row is cut to
-// its non-zero span and the span into CHUNKS of 16 bins.  Call with info == NULL to get the chunk count n; then
+// its non-zero span (start rounded down to a multiple of 4 bins) and the span into CHUNKS of 16 bins.  Call with info == NULL to get the chunk count n; then
 // info[n + 2 * n_mels] = {first bin of every chunk} followed by {first chunk, chunk count} per band, and w[16 * n] = the
 // chunk weights, zero padded (an all-zero row has no chunk).
 int at_mel_bands_host(const float* basis, int n_mels, int n_bins, int* info, float* w) {
@@ -1052,6 +1052,7 @@ int at_mel_bands_host(const float* basis, int n_mels, int n_bins, int* info, flo
       int lo = -1, hi = -1;
       for (int k = 0; k < n_bins; ++k)
         if (b[k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+      if (lo >= 0) lo &= ~3;              // chunks start at multiples of 4 bins: 16-byte LDS reads of the magnitudes
       const int cnt = lo < 0 ? 0 : (hi - lo + 16) / 16;
       if (fill) { info[total + 2 * m] = n; info[total + 2 * m + 1] = cnt; }
       for (int c = 0; c < cnt; ++c, ++n) {

@@ -372,7 +372,16 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
 // bin on its own: twice the arithmetic), k = t + 256 i < M / 2 ascending, M - k descending -- both 512-byte
 // segments per wave --, and k = M / 2 by every thread (same value to the same address: the store count of a tile
 // stays static).  Everything else -- runs, XCD spans, clamped prefetch, chunked mel epilogue -- is the generic tile.
-template <int PLAN>
+#define POW2_MAG_STRIDE(M) ((M) + 20)
+// float2 slots of the pass-twiddle region.  The mel variant at M = 2048 keeps only w^k, w^2k, w^4k of the third pass
+// (the other four powers are one product each): 8 KB less LDS, which is what lets two workgroups share a CU.
+#define POW2_TW_SLOTS(PLAN, MELT) (((PLAN) == 1 && (MELT)) ? 240 + 3 * 257 + 13 : ((PLAN) == 1 ? 2048 : 4096))
+constexpr int POW2_MEL_SLOTS = 3;     // chunk dot products per thread and tile: FB n_chunks <= 768
+// piece sums per band: a band's chunks are consecutive tasks, i.e. lanes of consecutive waves -- at most
+// (63 + (M + 1 + 18) / 16) / 64 + 1 of them (a bank with a handful of bands has bands hundreds of bins wide)
+#define POW2_MEL_PIECES(PLAN) ((PLAN) == 1 ? 4 : 8)
+
+template <int PLAN, bool MELT>
 __global__ __launch_bounds__(256, 2) void stft_tiled_pow2_kernel(const Gen2Args A) {
   extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
   constexpr int M = PLAN == 1 ? 2048 : 4096, FB = PLAN == 1 ? 2 : 1, N = 2 * M;
@@ -380,35 +389,77 @@ __global__ __launch_bounds__(256, 2) void stft_tiled_pow2_kernel(const Gen2Args 
   constexpr int NB3 = PLAN == 1 ? 2 : 1;          // pass-3 butterflies per thread (one per frame)
   constexpr int NPI = M / 512;                    // pair iterations per frame: k = t + 256 i < M / 2
   constexpr int NWR = M / 256;                    // distinct window pairs per thread
-  constexpr int NMG = FB * (2 * NPI + 1);         // bins (magnitudes) per thread and tile
   constexpr int FS = M + M / 256;                 // slots of a frame incl. its pads
+  constexpr int MS = POW2_MAG_STRIDE(M);          // floats of a |X| row: M + 1 bins, zero slack for the last chunk, 16-byte rows
+  constexpr bool TW3S = PLAN == 1 && MELT;        // third-pass twiddles from three stored powers
+  constexpr bool MEL = MELT;
+  constexpr int NSL = POW2_MEL_SLOTS, NPC = POW2_MEL_PIECES(PLAN);
   using at::gfft::dft_r;
   float2* buf = gbuf;                             // [4096 + 16], swizzled + padded
-  float2* tw = gbuf + 4096 + 16;                  // pass blocks: [0, 240) pass 2, [240, 240 + 257 (R3 - 1)) pass 3
-  float2* stw = tw + M;                           // [M / 2 + 1]: split twiddles w_N^j
-  float* melw = reinterpret_cast<float*>(stw + M / 2 + 2);
-  int* mtab = reinterpret_cast<int*>(melw + 16 * A.n_chunks);
-  float* part = reinterpret_cast<float*>(mtab + A.n_chunks + 2 * A.n_mels);
-  float* mag = reinterpret_cast<float*>(gbuf);    // [FB][M + 1], over the transform buffer once Z is consumed
-  const bool MEL = A.mel != nullptr;
-  // pass 2 (NS = 16): tw[(q - 1) 16 + k] = w_256^(k q);  pass 3 (NS = 256): tw[240 + (q - 1) 257 + k] = w_(256 R3)^(k q)
-  // = w_M^(k q) for both plans (the table is per N = 2 M: w_M^x = A.tw[2 x]); rows of 257 for the same reason as the pads
+  float2* tw = gbuf + 4096 + 16;                  // pass blocks: [0, 240) pass 2, then rows of 257 for pass 3
+  float* magbuf = reinterpret_cast<float*>(tw + POW2_TW_SLOTS(PLAN, MELT));   // [FB][MS] |X| of the PREVIOUS tile (mel only)
+  float* melw = magbuf + (MEL ? FB * MS : 0);     // [n_chunks][16] chunk weights
+  float* part = melw + 16 * A.n_chunks;           // [FB][n_mels][NPC]: a band's chunk sums, one slot per wave piece
+  // pass 2 (NS = 16): tw[(q - 1) 16 + k] = w_256^(k q);  pass 3 (NS = 256): row q - 1 of 257 = w_(256 R3)^(k q) = w_M^(k q)
+  // for both plans (the table is per N = 2 M: w_M^x = A.tw[2 x]); rows of 257 for the same reason as the pads.
+  // TW3S: rows 0, 1, 2 = w^k, w^2k, w^4k.
   for (int idx = threadIdx.x; idx < 240; idx += 256) {
     const int q1 = idx >> 4, k = idx & 15;
     tw[idx] = A.tw[2 * (k * (q1 + 1) * (M / 256))];
   }
-  for (int idx = threadIdx.x; idx < 256 * (R3 - 1); idx += 256) {
+  for (int idx = threadIdx.x; idx < 256 * (TW3S ? 3 : R3 - 1); idx += 256) {
     const int q1 = idx >> 8, k = idx & 255;
-    tw[240 + 257 * q1 + k] = A.tw[2 * (k * (q1 + 1))];
+    tw[240 + 257 * q1 + k] = A.tw[2 * (k * (TW3S ? (1 << q1) : q1 + 1))];
   }
-  float2 wreg[NWR];
+  // window pairs and split twiddles w_N^k of this thread's points / bins: the same for every tile, in registers
+  float2 wreg[NWR], swr[NPI];
 #pragma unroll
   for (int i = 0; i < NWR; ++i) wreg[i] = reinterpret_cast<const float2*>(A.window)[threadIdx.x + 256 * i];
-  for (int i = threadIdx.x; i <= M / 2; i += 256) stw[i] = A.tw[i];
-  if (MEL) {
-    for (int i = threadIdx.x; i < 16 * A.n_chunks; i += 256) melw[i] = A.cw[i];
-    for (int i = threadIdx.x; i < A.n_chunks; i += 256) mtab[i] = A.chunk[i];
-    for (int i = threadIdx.x; i < 2 * A.n_mels; i += 256) mtab[A.n_chunks + i] = A.band[i];
+#pragma unroll
+  for (int i = 0; i < NPI; ++i) swr[i] = A.tw[threadIdx.x + 256 * i];
+  const float2 wmid = A.tw[M / 2];
+  // ---- mel: this thread's chunk tasks T = t + 256 s (task = frame * n_chunks + chunk), tile-invariant, in registers:
+  //      where the 16 magnitudes and weights live, which of the lanes T + 2^i continue the same band inside this
+  //      wave (bits 0..5), whether the lane heads its band's piece in this wave (bit 6) and where the piece sum goes;
+  //      bit 7: the slot holds a task at all
+  int m_off[MEL ? NSL : 1], w_off[MEL ? NSL : 1], m_fl[MEL ? NSL : 1], m_dst[MEL ? NSL : 1];
+  if constexpr (MEL) {
+    const int nch = A.n_chunks, ntask = FB * nch;
+    int* cb = reinterpret_cast<int*>(buf);        // scratch: band of every chunk
+    for (int m = threadIdx.x; m < A.n_mels; m += 256) {
+      const int c0 = A.band[2 * m], cn = A.band[2 * m + 1];
+      for (int c = 0; c < cn; ++c) cb[c0 + c] = m;
+    }
+    for (int i = threadIdx.x; i < 16 * nch; i += 256) melw[i] = A.cw[i];
+    for (int i = threadIdx.x; i < FB * MS; i += 256) magbuf[i] = 0.f;         // the slack behind bin M stays zero
+    for (int i = threadIdx.x; i < NPC * FB * A.n_mels; i += 256) part[i] = 0.f; // slots no piece writes stay zero
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s2 = 0; s2 < NSL; ++s2) {
+      const int T = (int)threadIdx.x + 256 * s2;
+      const bool valid = T < ntask;
+      const int Tc = valid ? T : 0;
+      const int fi = Tc >= nch ? 1 : 0, c = Tc - fi * nch;
+      const int band = cb[c];
+      auto same = [&](int T2) {                   // task T2 is a chunk of the same band of the same frame
+        if (T2 < 0 || T2 >= ntask) return false;
+        const int f2 = T2 >= nch ? 1 : 0;
+        return f2 == fi && cb[T2 - f2 * nch] == band;
+      };
+      int fl = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (valid && lane + (1 << i) < 64 && same(T + (1 << i))) fl |= 1 << i;
+      const bool cont = valid && same(T - 1);     // the band began in an earlier task
+      if (valid && (lane == 0 || !cont)) fl |= 64;
+      m_off[s2] = fi * MS + A.chunk[c];
+      w_off[s2] = 16 * c;
+      m_fl[s2] = valid ? (fl | 128) : 0;
+      // piece = waves between the band's first task and this one
+      const int piece = (Tc >> 6) - ((fi * nch + A.band[2 * band]) >> 6);
+      m_dst[s2] = NPC * (fi * A.n_mels + band) + (piece < NPC ? piece : NPC - 1);
+    }
   }
   __syncthreads();
   const at::gfft::RowLayout lay{M, 1};            // the same layout as a function (edge tiles)
@@ -438,7 +489,69 @@ __global__ __launch_bounds__(256, 2) void stft_tiled_pow2_kernel(const Gen2Args 
     }
   };
 
-  auto tile = [&](int64_t g, int64_t g_end) __attribute__((always_inline)) {
+  // ---- mel epilogue of a tile, in two halves that ride on the NEXT tile's barriers (the |X| rows have their own LDS
+  //      region).  The first version ran behind the split step with three barriers of its own, chunk sums by a loop
+  //      and band sums by one thread walking up to 15 chunk sums: +1.05 ms on 2.80 at n_fft 4096, all of it latency.
+  //  first half: every thread's <= 3 chunk dot products (16 bins x 16 weights, all reads issued together), then the
+  //  chunks of a band are summed across the lanes (they are consecutive tasks; doubling steps through the LDS
+  //  crossbar, fixed order) and the head lane of every piece (the part of a band inside one wave) stores its sum.
+  auto chunk_dots = [&]() __attribute__((always_inline)) {
+    float acc[NSL];
+    float4 wv[NSL][4], mv[NSL][4];
+#pragma unroll
+    for (int s2 = 0; s2 < NSL; ++s2) {
+      const float4* __restrict__ mq = reinterpret_cast<const float4*>(magbuf + m_off[s2]);
+      const float4* __restrict__ wq = reinterpret_cast<const float4*>(melw + w_off[s2]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { wv[s2][q] = wq[q]; mv[s2][q] = mq[q]; }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NSL; ++s2) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a0 = fmaf(wv[s2][q].x, mv[s2][q].x, a0);
+        a1 = fmaf(wv[s2][q].y, mv[s2][q].y, a1);
+        a0 = fmaf(wv[s2][q].z, mv[s2][q].z, a0);
+        a1 = fmaf(wv[s2][q].w, mv[s2][q].w, a1);
+      }
+      acc[s2] = (m_fl[s2] & 128) ? a0 + a1 : 0.f;                // bit 7: the slot holds a task
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int s2 = 0; s2 < NSL; ++s2) {
+        const float sh = __shfl_down(acc[s2], 1 << i, 64);
+        acc[s2] += ((m_fl[s2] >> i) & 1) ? sh : 0.f;
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NSL; ++s2)
+      if (m_fl[s2] & 64) part[m_dst[s2]] = acc[s2];
+  };
+  // second half: mel[band] = sum of its pieces in order, stored by one thread per (frame, band) -- ALWAYS (threads past
+  // the end repeat the last band): a static store count
+  auto band_total = [&](int task) __attribute__((always_inline)) -> float {
+    const float4* __restrict__ pp = reinterpret_cast<const float4*>(part + NPC * task);
+    float4 p = pp[0];
+    float tot = (p.x + p.y) + (p.z + p.w);
+    if constexpr (NPC == 8) { p = pp[1]; tot += (p.x + p.y) + (p.z + p.w); }
+    return tot;
+  };
+  auto band_sums = [&](int t, int row, int f0) __attribute__((always_inline)) {
+    float* __restrict__ mel0 = A.mel + ((int64_t)row * n_out + f0) * A.n_mels;
+    const int ntask = FB * A.n_mels;
+    if (ntask <= 256) {
+      const int task = min(t, ntask - 1);
+      mel0[task] = band_total(task);
+    } else {
+      for (int task = t; task < ntask; task += 256) mel0[task] = band_total(task);
+    }
+  };
+
+  int prow = 0, pf0 = 0;                          // the tile whose |X| sits in magbuf
+  auto tile = [&](auto pending_c, int64_t g, int64_t g_end) __attribute__((always_inline)) {
+    constexpr bool PENDING = decltype(pending_c)::value;      // a previous tile of this run waits for its mel epilogue
     int t = (int)threadIdx.x;
     asm volatile("" : "+v"(t));                   // per tile: nothing indexed by it leaves the persistent loops
     const int st = t ^ ((t >> 4) & 15);           // a(t)
@@ -459,11 +572,12 @@ __global__ __launch_bounds__(256, 2) void stft_tiled_pow2_kernel(const Gen2Args 
         const int64_t sidx = (int64_t)s0 + fi * hop + 2 * n;
         const float2 w = reinterpret_cast<const float2*>(A.window)[n];
         buf[lay.addr(fi, n) + (e >> 8)] = make_float2(at::fetch_padded(xr, sidx, A.T, A.T2, A.pad, A.pad_mode) * w.x,
-                                           at::fetch_padded(xr, sidx + 1, A.T, A.T2, A.pad, A.pad_mode) * w.y);
+                                                      at::fetch_padded(xr, sidx + 1, A.T, A.T2, A.pad, A.pad_mode) * w.y);
       }
     }
-    __syncthreads();
+    __syncthreads();                              // (also: every |X| of the previous tile is in magbuf)
     fetch(g + 1, g + 1 < g_end, t);               // the next tile's samples: in flight during the passes
+    if constexpr (PENDING && MEL) chunk_dots();
 
     // ---- passes 1 and 2 (radix 16): butterfly j of frame fj
     const int fj = PLAN == 1 ? (t >> 7) : 0, j = PLAN == 1 ? (t & 127) : t;
@@ -478,7 +592,8 @@ __global__ __launch_bounds__(256, 2) void stft_tiled_pow2_kernel(const Gen2Args 
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = buf[((q & 1) ? rb1 : rb0) + rq(q)];
     dft_r<16>(v);
-    __syncthreads();
+    __syncthreads();                              // (also: the piece sums of the previous tile are in part[])
+    if constexpr (PENDING && MEL) band_sums(t, prow, pf0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) buf[wb1 + (q ^ jl)] = v[q];
     __syncthreads();
@@ -492,22 +607,33 @@ __global__ __launch_bounds__(256, 2) void stft_tiled_pow2_kernel(const Gen2Args 
     for (int q = 0; q < 16; ++q) buf[wb2 + 16 * q + (jl ^ q)] = v[q];
     __syncthreads();
     // ---- pass 3 (NS = 256), in place on the thread's own slots
+    {
+      float2 w3[R3];
+      if constexpr (TW3S) {
+        const float2 w1 = tw[240 + t], w2 = tw[240 + 257 + t], w4 = tw[240 + 2 * 257 + t];
+        const float2 w3_ = cmulf(w1, w2);
+        w3[1] = w1; w3[2] = w2; w3[3] = w3_; w3[4] = w4;
+        w3[5] = cmulf(w1, w4); w3[6] = cmulf(w2, w4); w3[7] = cmulf(w3_, w4);
+      } else {
 #pragma unroll
-    for (int b = 0; b < NB3; ++b) {
+        for (int q = 1; q < R3; ++q) w3[q] = tw[240 + (q - 1) * 257 + t];
+      }
 #pragma unroll
-      for (int q = 0; q < R3; ++q) v[q] = buf[st + FS * b + 257 * q];
+      for (int b = 0; b < NB3; ++b) {
 #pragma unroll
-      for (int q = 1; q < R3; ++q) v[q] = cmulf(v[q], tw[240 + (q - 1) * 257 + t]);
-      dft_r<R3>(v);
+        for (int q = 0; q < R3; ++q) v[q] = buf[st + FS * b + 257 * q];
 #pragma unroll
-      for (int q = 0; q < R3; ++q) buf[st + FS * b + 257 * q] = v[q];
+        for (int q = 1; q < R3; ++q) v[q] = cmulf(v[q], w3[q]);
+        dft_r<R3>(v);
+#pragma unroll
+        for (int q = 0; q < R3; ++q) buf[st + FS * b + 257 * q] = v[q];
+      }
     }
     __syncthreads();
 
-    // ---- split step: pairs (k, M - k), k = t + 256 i; then k = M / 2
+    // ---- split step: pairs (k, M - k), k = t + 256 i; then k = M / 2.  |X| goes straight to its row buffer.
     const int tm = (256 - t) & 255;                                     // low byte of M - k
     const int sm = (tm ^ ((tm >> 4) & 15)) + (t == 0 ? 257 : 0);        // a(256 - t): t = 0 sits one 256-block (+ its pad) up
-    float mg[NMG];
     char* __restrict__ obase = reinterpret_cast<char*>(A.out + ((int64_t)row * n_out + f0) * (M + 1));
     auto split = [&](float2 zk, float2 zm, float2 w, float2& xa, float2& xb) __attribute__((always_inline)) {
       const float c = w.x, sn = -w.y;
@@ -521,6 +647,7 @@ __global__ __launch_bounds__(256, 2) void stft_tiled_pow2_kernel(const Gen2Args 
 #pragma unroll
     for (int fi = 0; fi < FB; ++fi) {
       char* __restrict__ ofr = obase + (size_t)fi * (M + 1) * sizeof(float2);
+      float* __restrict__ mf = magbuf + fi * MS;
 #pragma unroll
       for (int i = 0; i < NPI; ++i) {
         const float2 zk = buf[fi * FS + st + 257 * i];
@@ -529,81 +656,37 @@ __global__ __launch_bounds__(256, 2) void stft_tiled_pow2_kernel(const Gen2Args 
         if (i == 0) am = t == 0 ? fi * FS : am;
         const float2 zm = buf[am];
         float2 xa, xb;
-        split(zk, zm, stw[t + 256 * i], xa, xb);
+        split(zk, zm, swr[i], xa, xb);
         if (i == 0) { if (t == 0) { xa.y = 0.f; xb.y = 0.f; } }         // DC and Nyquist: exactly real
         *reinterpret_cast<float2*>(ofr + (size_t)(t + 256 * i) * sizeof(float2)) = xa;
         *reinterpret_cast<float2*>(ofr + (size_t)(M - 256 * i - 255) * sizeof(float2) + (size_t)(255 - t) * sizeof(float2)) = xb;
-        mg[fi * (2 * NPI + 1) + 2 * i] = __builtin_amdgcn_sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
-        mg[fi * (2 * NPI + 1) + 2 * i + 1] = __builtin_amdgcn_sqrtf(fmaf(xb.x, xb.x, xb.y * xb.y));
+        if constexpr (MEL) {
+          mf[t + 256 * i] = __builtin_amdgcn_sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
+          mf[(M - 256 * i - 255) + (255 - t)] = __builtin_amdgcn_sqrtf(fmaf(xb.x, xb.x, xb.y * xb.y));
+        }
       }
       {
         const float2 z = buf[fi * FS + M / 2 + M / 512];                // a(M / 2) = M / 2, + its pads
         float2 xa, xb;
-        split(z, z, stw[M / 2], xa, xb);
+        split(z, z, wmid, xa, xb);
         *reinterpret_cast<float2*>(ofr + (size_t)(M / 2) * sizeof(float2)) = xa;      // every thread, one address
-        mg[fi * (2 * NPI + 1) + 2 * NPI] = __builtin_amdgcn_sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y));
+        if constexpr (MEL) { if (t == 0) mf[M / 2] = __builtin_amdgcn_sqrtf(fmaf(xa.x, xa.x, xa.y * xa.y)); }
       }
     }
-    if (MEL) {
-      __syncthreads();                                    // every Z has been read: the buffer becomes |X|
-#pragma unroll
-      for (int fi = 0; fi < FB; ++fi) {
-        float* __restrict__ mf = mag + fi * (M + 1);
-#pragma unroll
-        for (int i = 0; i < NPI; ++i) {
-          mf[t + 256 * i] = mg[fi * (2 * NPI + 1) + 2 * i];
-          mf[(M - 256 * i - 255) + (255 - t)] = mg[fi * (2 * NPI + 1) + 2 * i + 1];
-        }
-        if (t == 0) mf[M / 2] = mg[fi * (2 * NPI + 1) + 2 * NPI];
-      }
-      __syncthreads();
-      const int nch = A.n_chunks;
-#pragma unroll 1
-      for (int task = t; task < FB * nch; task += 256) {
-        const int fi = task >= nch ? 1 : 0, c = task - fi * nch;
-        const float* __restrict__ mrow = mag + fi * (M + 1) + mtab[c];
-        const float4* __restrict__ wq = reinterpret_cast<const float4*>(melw + 16 * c);
-        float acc = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 w = wq[q];
-          acc = fmaf(w.x, mrow[4 * q], acc);
-          acc = fmaf(w.y, mrow[4 * q + 1], acc);
-          acc = fmaf(w.z, mrow[4 * q + 2], acc);
-          acc = fmaf(w.w, mrow[4 * q + 3], acc);
-        }
-        part[task] = acc;
-      }
-      __syncthreads();
-      float* __restrict__ mel0 = A.mel + ((int64_t)row * n_out + f0) * A.n_mels;
-      const int ntask = FB * A.n_mels;
-      if (ntask <= 256) {
-        // one band sum per thread, ALWAYS stored (threads past the end repeat the last one): a static store count
-        const int task = min(t, ntask - 1);
-        const int fi = task >= A.n_mels ? 1 : 0, m = task - fi * A.n_mels;
-        const int c0 = mtab[nch + 2 * m], cn = mtab[nch + 2 * m + 1];
-        float acc = 0.f;
-        for (int c = 0; c < cn; ++c) acc += part[fi * nch + c0 + c];
-        mel0[task] = acc;
-      } else {
-        for (int task = t; task < ntask; task += 256) {
-          const int fi = task >= A.n_mels ? 1 : 0, m = task - fi * A.n_mels;
-          const int c0 = mtab[nch + 2 * m], cn = mtab[nch + 2 * m + 1];
-          float acc = 0.f;
-          for (int c = 0; c < cn; ++c) acc += part[fi * nch + c0 + c];
-          mel0[task] = acc;
-        }
-      }
-    } else {
-      __syncthreads();                                    // every Z has been read: the buffer is free for the next tile
-    }
+    prow = row; pf0 = f0;
+    __syncthreads();                                      // every Z has been read: the buffer is free for the next tile
   };
 
   for (int64_t gbase = g_lo + (int64_t)lblk * A.run; gbase < g_hi; gbase += (int64_t)nblk_x * A.run) {
     const int64_t g_end = min(gbase + A.run, g_hi);
     fetch(gbase, true, (int)threadIdx.x);
-    tile(gbase, g_end);                                   // peeled: both edges of the loop below carry "loads, then stores"
-    for (int64_t g = gbase + 1; g < g_end; ++g) tile(g, g_end);
+    tile(std::false_type{}, gbase, g_end);                // peeled: both edges of the loop below carry "loads, then stores"
+    for (int64_t g = gbase + 1; g < g_end; ++g) tile(std::true_type{}, g, g_end);
+    if constexpr (MEL) {                                  // the last tile's epilogue (its |X| are complete: barrier above)
+      chunk_dots();
+      __syncthreads();
+      band_sums((int)threadIdx.x, prow, pf0);
+    }
   }
 }
 
@@ -684,13 +767,21 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
     G.vec2 = ((T % 2) == 0 && (hop % 2) == 0 && (M % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 8) == 0) ? 1 : 0;
     const int plan = (M == 2048 && G.FB == 2) ? 1 : (M == 4096 ? 2 : 0);
     // transform buffer (+ |X| slack), pass twiddles, [window: run-time plans only], split twiddles
-    size_t lds = ((size_t)G.FB * M + (plan == 0 ? 2 : 1) * (size_t)M + M / 2 + 2) * sizeof(float2) + 64 + 128;
-    if (mel_out) lds += (size_t)G.n_chunks * (16 + 1 + G.FB) * 4 + (size_t)2 * n_mels * 4;
-    if (lds > 160 * 1024) return AT_ERR_UNSUPPORTED;
     static const int old_tile = env_int_once("AT_STFT_TILED_OLD", 0);      // A/B: the generic tile for the fixed plans
-    const bool pow2 = plan != 0 && !old_tile;
-    const void* kfn = pow2 ? (plan == 1 ? reinterpret_cast<const void*>(stft_tiled_pow2_kernel<1>)
-                                        : reinterpret_cast<const void*>(stft_tiled_pow2_kernel<2>))
+    // hand-addressed tile (its mel stage holds <= 3 chunk tasks per thread)
+    const bool pow2 = plan != 0 && !old_tile && (!mel_out || (int64_t)G.FB * G.n_chunks <= 256 * POW2_MEL_SLOTS);
+    size_t lds = ((size_t)G.FB * M + (plan == 0 ? 2 : 1) * (size_t)M + M / 2 + 2) * sizeof(float2) + 64;
+    if (mel_out) lds += (size_t)G.n_chunks * (16 + 1 + G.FB) * 4 + (size_t)2 * n_mels * 4;
+    // padded transform buffer, pass twiddles; window and split twiddles in registers; mel: |X| rows, chunk weights, piece sums
+    if (pow2) {
+      lds = ((size_t)4096 + 16 + (mel_out ? POW2_TW_SLOTS(plan, true) : POW2_TW_SLOTS(plan, false))) * sizeof(float2) + 64;
+      if (mel_out) lds += ((size_t)G.FB * POW2_MAG_STRIDE(M) + (size_t)16 * G.n_chunks + (size_t)POW2_MEL_PIECES(plan) * G.FB * n_mels) * 4;
+    }
+    if (lds > 160 * 1024) return AT_ERR_UNSUPPORTED;
+    const void* kfn = pow2 ? (plan == 1 ? (mel_out ? reinterpret_cast<const void*>(stft_tiled_pow2_kernel<1, true>)
+                                                   : reinterpret_cast<const void*>(stft_tiled_pow2_kernel<1, false>))
+                                        : (mel_out ? reinterpret_cast<const void*>(stft_tiled_pow2_kernel<2, true>)
+                                                   : reinterpret_cast<const void*>(stft_tiled_pow2_kernel<2, false>)))
                     : plan == 1 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<1>)
                     : plan == 2 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<2>)
                                 : reinterpret_cast<const void*>(stft_generic_tiled_kernel<0>);
@@ -713,8 +804,10 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
       int64_t run = (per_wg + runs - 1) / (runs > 0 ? runs : 1);
       G.run = (int)(run < 1 ? 1 : run);
     }
-    if (pow2 && plan == 1) hipLaunchKernelGGL(stft_tiled_pow2_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, G);
-    else if (pow2) hipLaunchKernelGGL(stft_tiled_pow2_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+    if (pow2 && plan == 1 && mel_out) hipLaunchKernelGGL((stft_tiled_pow2_kernel<1, true>), dim3((unsigned)blocks), dim3(256), lds, st, G);
+    else if (pow2 && plan == 1) hipLaunchKernelGGL((stft_tiled_pow2_kernel<1, false>), dim3((unsigned)blocks), dim3(256), lds, st, G);
+    else if (pow2 && mel_out) hipLaunchKernelGGL((stft_tiled_pow2_kernel<2, true>), dim3((unsigned)blocks), dim3(256), lds, st, G);
+    else if (pow2) hipLaunchKernelGGL((stft_tiled_pow2_kernel<2, false>), dim3((unsigned)blocks), dim3(256), lds, st, G);
     else if (plan == 1) hipLaunchKernelGGL(stft_generic_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, G);
     else if (plan == 2) hipLaunchKernelGGL(stft_generic_tiled_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, G);
     else hipLaunchKernelGGL(stft_generic_tiled_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, st, G);

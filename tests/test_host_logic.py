@@ -74,6 +74,33 @@ def test_mel_units_reconstruct_basis():
             assert acc[us[0]] == vals[us].sum()
 
 
+def test_mel_bands_reconstruct_basis():
+    """Banded form for the generic-size fused mel stage (at_mel_bands_host): 16-bin chunks starting at multiples of 4
+    bins (16-byte LDS reads of the magnitudes), every band's chunks consecutive; the chunks rebuild the dense basis and
+    never reach past bin n_bins - 1 + 15 (the zero slack of the kernel's |X| rows)."""
+    from audiotools_amd import _native
+
+    _native.build()
+    for sr, n_fft, nm in [(96000, 4096, 80), (192000, 8192, 128), (16000, 400, 40), (48000, 1920, 64)]:
+        basis = tables.mel_filters_np(sr, n_fft, nm)
+        F = basis.shape[1]
+        info, w = tables.mel_bands_np(basis)
+        n = w.shape[0]
+        first, bands = info[:n], info[n:].reshape(nm, 2)
+        assert np.all(first % 4 == 0) and np.all(first >= 0) and np.all(first + 15 <= F - 1 + 15)
+        rec = np.zeros((nm, F + 16), dtype=np.float32)
+        nxt = 0
+        for m in range(nm):
+            c0, cn = bands[m]
+            assert c0 == nxt
+            nxt += cn
+            for c in range(c0, c0 + cn):
+                assert first[c] == first[c0] + 16 * (c - c0)
+                rec[m, first[c]: first[c] + 16] += w[c]
+        assert nxt == n
+        assert np.array_equal(rec[:, :F], basis) and not rec[:, F:].any()
+
+
 def test_cpu_path_matches_oracle():
     x = synth.audio_batch(3, 2, 22050, seed=3, gaps=False)
     s = A.AudioSignal(x.clone(), 44100)

@@ -153,3 +153,67 @@ def run(plan, seed=0):
 if __name__ == "__main__":
     run(1)
     run(2)
+
+
+def mel_reduction(sr, n_fft, n_mels, FB, NPC, seed=0):
+    """The lane-level segmented sum of the mel epilogue: tasks T = t + 256 s (task = frame * n_chunks + chunk), flags as
+    the kernel builds them, six doubling steps inside 64-lane waves, head lanes store one of two pieces per band."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from audiotools_amd import tables
+    basis = tables.mel_filters_np(sr, n_fft, n_mels)
+    info, w = tables.mel_bands_np(basis)
+    nch = w.shape[0]
+    bands = info[nch:].reshape(n_mels, 2)
+    cb = np.zeros(nch, dtype=int)
+    for m in range(n_mels):
+        cb[bands[m, 0]: bands[m, 0] + bands[m, 1]] = m
+    ntask = FB * nch
+    assert ntask <= 768
+    rng = np.random.default_rng(seed)
+    vals = rng.standard_normal(ntask)
+    part = np.zeros((FB, n_mels, NPC))
+    writes = np.zeros((FB, n_mels, NPC), dtype=int)
+
+    def same(T, T2):
+        if T2 < 0 or T2 >= ntask:
+            return False
+        f, f2 = T // nch, T2 // nch
+        return f == f2 and cb[T2 - f2 * nch] == cb[T - f * nch]
+
+    for s in range(3):
+        for wave in range(4):
+            T0 = 256 * s + 64 * wave
+            acc = np.array([vals[T0 + l] if T0 + l < ntask else 0.0 for l in range(64)])
+            fl = [[(T0 + l < ntask) and l + (1 << i) < 64 and same(T0 + l, T0 + l + (1 << i)) for i in range(6)] for l in range(64)]
+            for i in range(6):
+                sh = np.concatenate([acc[1 << i:], acc[-(1 << i):]])      # out-of-range lanes: any value, masked by the flag
+                acc = acc + np.where([fl[l][i] for l in range(64)], sh, 0.0)
+            for l in range(64):
+                T = T0 + l
+                if T >= ntask:
+                    continue
+                cont = same(T, T - 1)
+                if l == 0 or not cont:
+                    f, c = T // nch, T % nch
+                    piece = (T >> 6) - ((f * nch + bands[cb[c], 0]) >> 6)
+                    assert piece < NPC
+                    part[f, cb[c], piece] = acc[l]
+                    writes[f, cb[c], piece] += 1
+    assert writes.max() <= 1
+    for f in range(FB):
+        for m in range(n_mels):
+            c0, cn = bands[m]
+            ref = vals[f * nch + c0: f * nch + c0 + cn].sum()
+            assert abs(part[f, m].sum() - ref) < 1e-9, (f, m)
+    print("mel reduction", sr, n_fft, n_mels, "chunks", nch, "ok")
+
+
+if __name__ == "__main__":
+    mel_reduction(96000, 4096, 80, 2, 4)
+    mel_reduction(96000, 4096, 128, 2, 4)
+    mel_reduction(96000, 4096, 7, 2, 4)
+    mel_reduction(96000, 4096, 2, 2, 4)
+    mel_reduction(192000, 8192, 80, 1, 8)
+    mel_reduction(192000, 8192, 128, 1, 8)
+    mel_reduction(192000, 8192, 3, 1, 8)
