@@ -789,7 +789,10 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
     if (e != AT_OK) return e;
     const int n_cu = device_cu_count();
     int per_cu = (int)((160 * 1024) / lds);
-    per_cu = per_cu > 2 ? 2 : (per_cu < 1 ? 1 : per_cu);
+    // the hand-addressed tile needs ~155 registers: three workgroups (12 waves) per CU where the LDS allows it (M = 2048 without mel)
+    static const int cap_env = env_int_once("AT_STFT_TILED_WGS", 0);         // A/B
+    const int cap = cap_env > 0 ? cap_env : (pow2 ? 3 : 2);
+    per_cu = per_cu > cap ? cap : (per_cu < 1 ? 1 : per_cu);
     int64_t blocks = (int64_t)n_cu * per_cu;
     if (blocks > G.total_tiles) blocks = G.total_tiles;
     int auto_x = n_cu / 32;

@@ -22,7 +22,7 @@ import csv, glob, sys, collections, json, os, socket
 O = sys.argv[1]
 import subprocess
 try:
-    uid = [l.split(":")[-1].strip() for l in subprocess.run(["rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=30).stdout.splitlines() if "Unique ID" in l][0]
+    uid = [l.split(":")[-1].strip() for l in subprocess.run(["rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=30).stdout.splitlines() if "Unique ID" in l and "GPU[" in l][0]
 except Exception:
     uid = "unknown"
 out = {"box": "MI355X unique id " + uid, "stats_command": "bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-share", "command": "bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share (one rocprofv3 pass per counter group)"}
