@@ -141,45 +141,62 @@ __global__ __launch_bounds__(THREADS, 4) void colfft_kernel(const ColArgs A) {
   float2* __restrict__ dst = A.dst + row * (int64_t)A.N1 * A.N2;
   unsigned pk = 0;
   at::gfft::build_pass_twiddles<THREADS>(tw, A.tw1, 1, A.N1, A.pl);     // per-pass blocks (conflict-free reads)
+  // The tile's points are loaded by a FIXED number of unconditional, address-clamped loads per thread into registers and
+  // only then written to LDS: with a predicated loop every iteration was its own basic block (load, wait, ds_write), i.e.
+  // ONE 512-byte segment in flight per wave -- 8 KB per CU where HBM latency x bandwidth needs ~60 (the kernel ran at
+  // 39 % of 8 TB/s with 72 % of its wave cycles waiting, profiles/r03_notes.md).
+  constexpr int CPT = TILE_POINTS / THREADS;       // points per thread
+  // point e = tid + THREADS i of the tile is (row n1_0 + step i, column col): cw divides THREADS
+  const int step = THREADS >> A.lcw, n1_0 = (int)threadIdx.x >> A.lcw;
+  const int n2 = n2_0 + ((int)threadIdx.x & cmask);
+  const bool inside = n2 < A.N2;
+  const int n2c = inside ? n2 : A.N2 - 1;
+  float2 r[CPT];
   if constexpr (MODE & COL_ROLLED) {
     const float* __restrict__ rs = A.rsrc + row * A.src_pitch;
     const int64_t T = 2 * (int64_t)A.N1 * A.N2;
     int64_t sh = A.shift ? A.shift[row] % T : 0;
     if (sh < 0) sh += T;
-#pragma unroll 4
-    for (int e = threadIdx.x; e < npts; e += THREADS) {
-      const int n1 = e >> A.lcw, n2 = n2_0 + (e & cmask);
-      float2 v = make_float2(0.f, 0.f);
-      if (n2 < A.N2) {
-        int64_t i0 = 2 * ((int64_t)n1 * A.N2 + n2) + sh;
-        if (i0 >= T) i0 -= T;
-        int64_t i1 = i0 + 1;
-        if (i1 >= T) i1 -= T;
-        if (i0 < A.src_len) v.x = rs[i0];
-        if (i1 < A.src_len) v.y = rs[i1];
-      }
-      tile[e] = v;
+    const int64_t last = A.src_len > 0 ? A.src_len - 1 : 0;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int n1 = min(n1_0 + step * i, A.N1 - 1);
+      int64_t i0 = 2 * (int64_t)(__mul24(n1, A.N2) + n2c) + sh;
+      if (i0 >= T) i0 -= T;
+      int64_t i1 = i0 + 1;
+      if (i1 >= T) i1 -= T;
+      const float a = rs[i0 < last ? i0 : last], b = rs[i1 < last ? i1 : last];
+      r[i] = make_float2(i0 < A.src_len ? a : 0.f, i1 < A.src_len ? b : 0.f);
     }
   } else {
     const float2* __restrict__ src = A.src + row * (int64_t)A.N1 * A.N2;
-#pragma unroll 4
-    for (int e = threadIdx.x; e < npts; e += THREADS) {
-      const int n1 = e >> A.lcw, n2 = n2_0 + (e & cmask);
-      const float2 v = n2 < A.N2 ? src[(int64_t)n1 * A.N2 + n2] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int n1 = min(n1_0 + step * i, A.N1 - 1);
+      r[i] = src[__mul24(n1, A.N2) + n2c];        // (32-bit offset from the row: N1 N2 <= 2^20 points)
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    if (n1_0 + step * i < A.N1) {
+      const float2 v = inside ? r[i] : make_float2(0.f, 0.f);
       if constexpr ((MODE & COL_PEAK) && !(MODE & COL_CONJ)) { pk = max(pk, max(absbits(v.x), absbits(v.y))); }
-      tile[e] = v;
+      tile[(int)threadIdx.x + THREADS * i] = v;
     }
   }
   __syncthreads();
   run_passes<THREADS>(tile, tw, A.N1, A.pl, A.cw, ColLayout{A.lcw, cmask});
-#pragma unroll 4
-  for (int e = threadIdx.x; e < npts; e += THREADS) {
-    const int k1 = e >> A.lcw, n2 = n2_0 + (e & cmask);
-    if (n2 < A.N2) {
-      float2 v = tile[e];
+  // results: LDS -> registers (all reads in flight), then the guarded stores
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) r[i] = tile[min((int)threadIdx.x + THREADS * i, npts - 1)];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int k1 = n1_0 + step * i;
+    if (k1 < A.N1 && inside) {
+      float2 v = r[i];
       if constexpr (MODE & COL_CONJ) v.y = -v.y;
       if constexpr ((MODE & COL_PEAK) && (MODE & COL_CONJ)) { pk = max(pk, max(absbits(v.x), absbits(v.y))); }
-      dst[(int64_t)k1 * A.N2 + n2] = v;
+      dst[__mul24(k1, A.N2) + n2] = v;
     }
   }
   if constexpr (MODE & COL_PEAK) peak_commit(__uint_as_float(pk), A.peak + row);
