@@ -28,6 +28,7 @@
 #include "generic_fft.h"
 
 #include <cmath>
+#include <type_traits>
 #include <cstring>
 
 namespace {
@@ -270,95 +271,102 @@ __global__ __launch_bounds__(RTHREADS, ROW_WGS * RTHREADS / 256) void rowconv_ke
   const float2* __restrict__ gh = A.ah + hrow * MM;
   const int npts = nrow * N2;
 
-  float2 r[ROW_LOADS];
-  auto fetch = [&](const float2* __restrict__ g) {
-#pragma unroll
-    for (int i = 0; i < ROW_LOADS; ++i) {
-      if (RTHREADS * i < npts) {             // uniform; lanes past the end repeat the last point
-        const int e = min((int)threadIdx.x + RTHREADS * i, npts - 1);
-        const int s = e >= N2 ? 1 : 0;
-        r[i] = g[(int64_t)(s ? k1b : k1a) * N2 + (e - s * N2)];
-      }
-    }
-  };
-  fetch(gx);
-  at::gfft::build_pass_twiddles<RTHREADS>(tw, A.tw2, 1, N2, A.pl);       // per-pass blocks (conflict-free reads)
-  for (int i = threadIdx.x; i < nrow * A.rt; i += RTHREADS) {
-    const int s = i >= A.rt ? 1 : 0;
-    rt[i] = A.rowtw[(int64_t)(s ? k1b : k1a) * A.rt + (i - s * A.rt)];
-  }
-  __syncthreads();
-
   const RowLayout lay{N2, 0};
   const float2 wlo = A.sp_lo[k1a];
   const int slot_b = self ? 0 : N2;
   const float sc = (A.scale ? A.scale[hrow] : 1.0f) * A.inv_m;
-  float2 Xk[SPEC_ITERS], Xm[SPEC_ITERS];
 
-  // phase 0: signal rows -> X;  phase 1: IR rows -> H, Y = X H, Z' (conjugated) back into the
-  // slots;  phase 2: the transform back.  One copy of the pass code serves all three.
-  for (int ph = 0; ph < 3; ++ph) {
-    int tid = (int)threadIdx.x;             // opaque per phase: nothing below is hoisted out of the loop
-    asm volatile("" : "+v"(tid));
-    if (ph < 2) {                           // twiddle w_M^{k1 n2} and into LDS
+  // The load / twiddle / store loops have a compile-time trip count (NI = 16 points per thread) and clamped indices
+  // instead of a run-time "is this iteration inside the row pair" test per iteration: that test (uniform) made every
+  // iteration its own basic block, so the LDS reads of the row twiddles and the multiplication of one point had to
+  // finish before the next point's reads were issued.  Surplus iterations (N2 < 2048, the two self-paired rows)
+  // repeat the last point: same value to the same slot / address.
+  auto body = [&](auto ni_c) __attribute__((always_inline)) {
+    constexpr int NI = decltype(ni_c)::value;
+    float2 r[NI];
+    auto fetch = [&](const float2* __restrict__ g) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < ROW_LOADS; ++i) {
-        if (RTHREADS * i < npts) {
+      for (int i = 0; i < NI; ++i) {
+        const int e = min((int)threadIdx.x + RTHREADS * i, npts - 1);
+        const int s = e >= N2 ? 1 : 0;
+        r[i] = g[__mul24(s ? k1b : k1a, N2) + (e - s * N2)];
+      }
+    };
+    fetch(gx);
+    at::gfft::build_pass_twiddles<RTHREADS>(tw, A.tw2, 1, N2, A.pl);       // per-pass blocks (conflict-free reads)
+    for (int i = threadIdx.x; i < nrow * A.rt; i += RTHREADS) {
+      const int s = i >= A.rt ? 1 : 0;
+      rt[i] = A.rowtw[(int64_t)(s ? k1b : k1a) * A.rt + (i - s * A.rt)];
+    }
+    __syncthreads();
+    float2 Xk[SPEC_ITERS], Xm[SPEC_ITERS];
+
+    // phase 0: signal rows -> X;  phase 1: IR rows -> H, Y = X H, Z' (conjugated) back into the
+    // slots;  phase 2: the transform back.  One copy of the pass code serves all three.
+    for (int ph = 0; ph < 3; ++ph) {
+      int tid = (int)threadIdx.x;             // opaque per phase: nothing below is hoisted out of the loop
+      asm volatile("" : "+v"(tid));
+      if (ph < 2) {                           // twiddle w_M^{k1 n2} and into LDS
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
           const int e = min(tid + RTHREADS * i, npts - 1);
           const int s = e >= N2 ? 1 : 0;
           const int n2 = e - s * N2;
           const float2 w = cmulf(rt[s * A.rt + (n2 & 63)], rt[s * A.rt + 64 + (n2 >> 6)]);
           buf[e] = cmulf(r[i], w);
+          if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // batches of four: all sixteen at once spill
+        }
+        __syncthreads();
+        if (ph == 0) fetch(gh);               // the IR rows arrive while the signal rows are transformed
+      }
+      run_passes<RTHREADS>(buf, tw, N2, A.pl, nrow, lay);
+      if (ph == 2) break;
+      // Every bin pair (k, M - k) is read (and in phase 1 rewritten) by exactly one thread, so the
+      // product spectrum goes straight back into the slots it came from.  The inverse transform
+      // runs as a forward one on conj(Z'); colfft<true> conjugates at the end.
+#pragma unroll
+      for (int i = 0; i < SPEC_ITERS; ++i) {
+        const int k2 = tid + RTHREADS * i;
+        const int k2m = k1a == 0 ? (k2 == 0 ? 0 : N2 - k2) : N2 - 1 - k2;
+        if (k2 < N2 && (!self || k2 <= k2m)) {
+          const float2 zk = buf[k2], zm = buf[slot_b + k2m];
+          const bool dc = k1a == 0 && k2 == 0;            // DC and Nyquist, both real, packed in Z[0]
+          const float2 w = cmulf(wlo, A.sp_hi[k2]);
+          float2 sk, sm;
+          if (dc) { sk = make_float2(zk.x + zk.y, 0.f); sm = make_float2(zk.x - zk.y, 0.f); }
+          else real_split(zk, zm, w, sk, sm);
+          if (ph == 0) { Xk[i] = sk; Xm[i] = sm; }
+          else {
+            float2 ok, om;
+            if (dc) {
+              const float y0 = Xk[i].x * sk.x * sc, ym = Xm[i].x * sm.x * sc;
+              ok = make_float2(0.5f * (y0 + ym), 0.5f * (y0 - ym));
+              om = ok;
+            } else {
+              float2 yk = cmulf(Xk[i], sk), ym = cmulf(Xm[i], sm);
+              yk.x *= sc; yk.y *= sc; ym.x *= sc; ym.y *= sc;
+              real_merge(yk, ym, w, ok, om);
+            }
+            buf[k2] = make_float2(ok.x, -ok.y);
+            if (!(self && k2 == k2m)) buf[slot_b + k2m] = make_float2(om.x, -om.y);
+          }
         }
       }
       __syncthreads();
-      if (ph == 0) fetch(gh);               // the IR rows arrive while the signal rows are transformed
     }
-    run_passes<RTHREADS>(buf, tw, N2, A.pl, nrow, lay);
-    if (ph == 2) break;
-    // Every bin pair (k, M - k) is read (and in phase 1 rewritten) by exactly one thread, so the
-    // product spectrum goes straight back into the slots it came from.  The inverse transform
-    // runs as a forward one on conj(Z'); colfft<true> conjugates at the end.
+    int tid2 = (int)threadIdx.x;              // opaque: the store addresses equal the first fetch's, and the compiler
+    asm volatile("" : "+v"(tid2));            // kept all sixteen alive (spilled) across the whole kernel
 #pragma unroll
-    for (int i = 0; i < SPEC_ITERS; ++i) {
-      const int k2 = tid + RTHREADS * i;
-      const int k2m = k1a == 0 ? (k2 == 0 ? 0 : N2 - k2) : N2 - 1 - k2;
-      if (k2 < N2 && (!self || k2 <= k2m)) {
-        const float2 zk = buf[k2], zm = buf[slot_b + k2m];
-        const bool dc = k1a == 0 && k2 == 0;            // DC and Nyquist, both real, packed in Z[0]
-        const float2 w = cmulf(wlo, A.sp_hi[k2]);
-        float2 sk, sm;
-        if (dc) { sk = make_float2(zk.x + zk.y, 0.f); sm = make_float2(zk.x - zk.y, 0.f); }
-        else real_split(zk, zm, w, sk, sm);
-        if (ph == 0) { Xk[i] = sk; Xm[i] = sm; }
-        else {
-          float2 ok, om;
-          if (dc) {
-            const float y0 = Xk[i].x * sk.x * sc, ym = Xm[i].x * sm.x * sc;
-            ok = make_float2(0.5f * (y0 + ym), 0.5f * (y0 - ym));
-            om = ok;
-          } else {
-            float2 yk = cmulf(Xk[i], sk), ym = cmulf(Xm[i], sm);
-            yk.x *= sc; yk.y *= sc; ym.x *= sc; ym.y *= sc;
-            real_merge(yk, ym, w, ok, om);
-          }
-          buf[k2] = make_float2(ok.x, -ok.y);
-          if (!(self && k2 == k2m)) buf[slot_b + k2m] = make_float2(om.x, -om.y);
-        }
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < ROW_LOADS; ++i) {
-    if (RTHREADS * i < npts) {
-      const int e = min((int)threadIdx.x + RTHREADS * i, npts - 1);
+    for (int i = 0; i < NI; ++i) {
+      const int e = min(tid2 + RTHREADS * i, npts - 1);
       const int s = e >= N2 ? 1 : 0;
       const int n2 = e - s * N2;
       const float2 w = cmulf(rt[s * A.rt + (n2 & 63)], rt[s * A.rt + 64 + (n2 >> 6)]);
-      gx[(int64_t)(s ? k1b : k1a) * N2 + n2] = cmulf(buf[e], w);
+      gx[__mul24(s ? k1b : k1a, N2) + n2] = cmulf(buf[e], w);
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
-  }
+  };
+  body(std::integral_constant<int, ROW_LOADS>{});
 }
 
 inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
