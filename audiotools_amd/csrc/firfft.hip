@@ -242,11 +242,16 @@ __global__ __launch_bounds__(FF_NW * 64, FF_WPS) void fir_fft_kernel(const FirFf
     fft(a);
     // ---- z'[n] = conj(F[n]): outputs o0 + 2n, o0 + 2n + 1 for 2n < lim
     const int lim = min(Ti - o0, V);
+    // all sixteen slab reads first: inside the (wave-uniform) range tests below every q was its own basic block,
+    // i.e. sixteen LDS round trips one after the other
+    float2 yv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) yv[q] = fbuf[phys<L>(t + L * q)];
     if (!A.accumulate) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int n = t + L * q;
-        const float2 y = fbuf[phys<L>(n)];
+        const float2 y = yv[q];
         float* __restrict__ po = orow + o0 + 2 * n;
         if (2 * L * (q + 1) <= lim) {            // the whole wave is inside: wave-uniform, no exec masking
           f2u o; o.x = y.x; o.y = -y.y;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(FF_NW * 64, FF_WPS) void fir_fft_kernel(const FirFf
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int n = t + L * q;
-        const float2 y = fbuf[phys<L>(n)];
+        const float2 y = yv[q];
         float* __restrict__ po = orow + o0 + 2 * n;
         if (2 * L * q < lim) {
           if (2 * n < lim) po[0] += y.x;
