@@ -313,6 +313,13 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResMfmaArgs A
 //   * one __syncthreads() per tile swaps the buffers.
 // Tiles are 16 frames (one MFMA row block): two buffers of ~30 KB, two workgroups per CU, and
 // 2 x NPB MFMA waves per CU spread evenly over the four SIMDs.
+// Where its time goes (round 3, profiles/r03_notes.md): 375 tiles per CU at 3.3 us each against 1.8 us of matrix-pipe
+// work.  With 85 registers per wave (48 of them the weights) the compiler single-buffers the A operands --
+// ds_read2_b32, s_waitcnt lgkmcnt(0), two MFMAs, next read --, and a workgroup has ONE tile load in flight: issued after
+// the barrier, ~28 DMA pieces plus an HBM round trip before the next barrier can fall.  Tried: 2 - 4 loader waves
+// (AT_RESAMPLE_LOADERS: 1.19 / 1.41 / 1.40 ms against 1.21), and one workgroup per CU with a 170-register budget
+// and all 48 operands of a tile read before the first MFMA (1.48 ms against 1.27-1.32: the second workgroup hides
+// more than the deeper pipeline gains).  A ring of three tile buffers does not fit twice into 160 KB.
 constexpr int WS_NC = 6;          // 32-tap chunks a wave keeps in registers (441 -> 160 needs 6)
 
 template <int NC>
