@@ -163,3 +163,37 @@ def test_oracle_apply_ir_and_alter_drr_match_reference(reference):
     got = restate.apply_ir(x.clone(), ir.clone(), sr, drr, eq)
     ref = reference.AudioSignal(x.clone(), sr).apply_ir(reference.AudioSignal(ir.clone(), sr), drr, eq).audio_data
     assert torch.allclose(got, ref, atol=1e-7), float((got - ref).abs().max())
+
+
+# ------------------------------------------------------------------ signal arithmetic
+@pytest.mark.parametrize("op", ["add", "sub", "mul"])
+def test_signal_arithmetic_equals_reference(reference, op):
+    """`a + b`, `a - b`, `a * b` (audio_signal.py:1385-1415 = clone, then the in-place operator) write the new signal's
+    samples in ONE pass here; values, the untouched operand, the copied `stft_data` and the reset loudness cache must be
+    those of the reference, for scalar, 0-dim, per-item, full-size, float64 and signal operands."""
+    import operator
+    f = getattr(operator, op)
+    a, r, x = _pair(reference)
+    a.stft(); r.stft()
+    a.loudness(); r.loudness()
+    g = torch.Generator().manual_seed(1)
+    other_sig = torch.randn(x.shape, generator=g)
+    operands = [2.0, 3, torch.tensor(0.5), torch.randn(3, 1, 1, generator=g), torch.randn(x.shape, generator=g),
+                torch.randn(3, 1, 1, generator=g).double()]
+    for v in operands:
+        ya, yr = f(a, v), f(r, v)
+        assert torch.equal(ya.audio_data, yr.audio_data) and ya.audio_data.dtype == yr.audio_data.dtype
+        assert torch.equal(a.audio_data, x) and ya.audio_data.data_ptr() != a.audio_data.data_ptr()
+        assert torch.equal(ya.stft_data, yr.stft_data) and ya.stft_data.data_ptr() != a.stft_data.data_ptr()
+        assert ya._loudness is None and yr._loudness is None and a._loudness is not None
+    ya, yr = f(a, A.AudioSignal(other_sig.clone(), 16000)), f(r, reference.AudioSignal(other_sig.clone(), 16000))
+    assert torch.equal(ya.audio_data, yr.audio_data)
+    # an operand that would broadcast the samples UP is an error in both (in-place semantics)
+    with pytest.raises(RuntimeError):
+        f(a, torch.randn(2, 3, 2, 12000))
+    with pytest.raises(RuntimeError):
+        f(r, torch.randn(2, 3, 2, 12000))
+    # gradients flow through the clone path
+    xg = x.clone().requires_grad_()
+    (f(A.AudioSignal(xg, 16000), 2.0).audio_data.sum()).backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()

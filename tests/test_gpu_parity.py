@@ -1148,11 +1148,13 @@ def test_stft_generic_match_stride_and_mel():
 
 @pytest.mark.parametrize("sr,n_fft,hop,n_mels", [(96000, 4096, 1024, 80), (192000, 8192, 2048, 128), (16000, 400, 160, 40),
                                                  (24000, 1200, 300, 80), (48000, 1920, 480, 64), (44100, 882, 441, 20),
-                                                 (96000, 4096, 1000, 7)])
+                                                 (96000, 4096, 1000, 7), (96000, 4096, 1024, 256)])
 def test_generic_sizes_fused_mel(sr, n_fft, hop, n_mels):
     """mel_spectrogram at the transform sizes of csrc/stft_generic.hip: the banded filterbank is applied inside the
     tiled mixed-radix kernel (audio_signal.py:1355-1368 is abs + a dense matmul over the stored spectrum); odd
-    lengths, edge tiles, band counts from 7 (bands hundreds of bins wide) to 128."""
+    lengths, edge tiles, band counts from 7 (bands hundreds of bins wide: several per-wave pieces per band in the
+    hand-addressed tile's lane-level sums) to 256 (854 chunk tasks per tile: more than that tile's three per thread, so the
+    launcher falls back to the generic tile)."""
     T = 9 * n_fft + 211
     x = synth.audio_batch(3, 2, T, seed=n_fft + n_mels, gaps=False, sample_rate=sr)
     s = A.AudioSignal(x.clone(), sr).to("cuda")
