@@ -365,6 +365,13 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
                  const int* mel_chunk, const int* mel_band, const float* mel_w, int n_chunks, int n_mels, float* mel_out,
                  hipStream_t st);
 
+// Fused inverse transform for n_fft 4096 / 8192 with hop = n_fft / 4 (stft_generic.hip: the hand-addressed tile run
+// backwards, overlap-add in an LDS ring).  Argument meaning as at_istft_f32; `workspace`: istft_tiled_workspace_floats floats.
+bool istft_tiled_supported(int n_fft, int hop);
+int64_t istft_tiled_workspace_floats(int64_t n_frames, int n_fft, int hop);
+int istft_tiled(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft, int hop,
+                int lead, int64_t n_frames, int64_t length, float* out, float* workspace, hipStream_t st);
+
 // Inverse transform of every frame: X (rows, n_frames, n_fft/2+1) -> windowed frames (rows, n_frames, n_fft),
 // the input of istft_ola_kernel.
 int istft_frames_generic(const float* X, int64_t rows, int64_t n_frames, const float* window, const float* twiddles,

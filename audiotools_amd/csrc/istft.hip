@@ -651,6 +651,8 @@ int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft, int 
   const bool fused_size = n_fft >= 32 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0;
   if (fused_size && fused_shift(n_fft, hop))     // envelope table + dump slots + zero page
     return ((n_frames - 1) * hop + n_fft + DUMP_FLOATS + ZERO_PAGE_FLOATS) * 4;
+  static const int tiled_off = at::env_int_once("AT_ISTFT_TILED_OFF", 0);       // A/B: frame buffer + gather for 4096 / 8192
+  if (!tiled_off && at::istft_tiled_supported(n_fft, hop)) return at::istft_tiled_workspace_floats(n_frames, n_fft, hop) * 4;
   return rows * n_frames * (int64_t)n_fft * 4;
 }
 
@@ -673,6 +675,10 @@ static int istft_run(const float* X, int64_t rows, int64_t n_x, const float* win
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!fused_size) {
     if (edit) return AT_ERR_UNSUPPORTED;
+    static const int tiled_off = at::env_int_once("AT_ISTFT_TILED_OFF", 0);
+    if (!tiled_off && at::istft_tiled_supported(n_fft, hop))
+      return at::istft_tiled(X, rows, n_x, window, twiddles, n_fft, hop, lead, n_frames, length, out,
+                             reinterpret_cast<float*>(workspace), st);
     // generic sizes (4096 ..., non powers of two): mixed-radix frames + the gather kernel
     if (lead != 0 || n_frames != n_x) return AT_ERR_UNSUPPORTED;
     int rc = at::istft_frames_generic(X, rows, n_frames, window, twiddles, n_fft, reinterpret_cast<float*>(workspace), st);

@@ -690,6 +690,235 @@ __global__ __launch_bounds__(256, 2) void stft_tiled_pow2_kernel(const Gen2Args 
   }
 }
 
+// =============================================================================================
+// Inverse transform for the same two sizes (n_fft 4096 / 8192, hop = n_fft / 4): the hand-addressed tile run backwards,
+// with the overlap-add in an LDS ring instead of a (rows, frames, n_fft) frame buffer in HBM + a gather kernel
+// (11.8 ms at 256 x 2ch x 10 s @ 96 kHz: 8.8 + 3.1; the forward transform takes 2.7).
+//   * a workgroup walks a run of output segments (hops) of one row, two frames (one for M = 4096) per tile, the next
+//     tile's bins prefetched into registers; frames outside [lead, lead + n_x) -- match_stride's virtual edge frames,
+//     the lead-in of a run, the tail behind the last frame -- load a zero page;
+//   * fold: conj(Z[k]) and conj(Z[M - k]) of the half-length transform from one evaluation of the pair (X[k], X[M - k]),
+//     k ascending, M - k descending (512-byte segments), straight into the slots the forward split step reads;
+//   * the three passes of the forward tile (a forward transform of the conjugate = the inverse); the third leaves
+//     point t + 256 q in register q of thread t, which is exactly the sample pair the thread's window register q belongs to;
+//   * window (1 / N folded in) and overlap-add: sample pair n of frame f goes to ring slot (f hop / 2 + n) mod M.  Slot s
+//     is only ever touched by thread s mod 256 -- accumulate, emit, clear --, so the ring needs no barrier; segment f is
+//     complete once frame f has been added and leaves as hop / 512 pair stores per thread, times 1 / envelope;
+//   * a fixed number of loads and stores per tile (pairs outside the row go to a dump slot), first tile of a run peeled.
+struct GenInv2Args {
+  const float2* X;         // (rows, n_x, M + 1)
+  const float* window;
+  const float2* tw;        // (N): (cos, -sin)(2 pi k / N)
+  const float* inv_env;    // ((n_frames - 1) hop + N): 1 / sum_f w^2
+  float* dump;             // INV2_DUMP_FLOATS
+  const float2* zeros;     // M + 1 zero bins
+  float* out;              // (rows, length)
+  int64_t rows, length, total_units;
+  int n_x, lead, n_frames, n_seg, run, runs_per_row;
+};
+constexpr int INV2_DUMP_FLOATS = 8 * 256 * 2;      // one pair slot per (emitted pair of a tile, thread)
+constexpr int INV2_RUN = 96;                       // segments per run (a multiple of 2); 4 lead-in frames each
+
+__global__ __launch_bounds__(256) void istft_env_generic_kernel(const float* __restrict__ window, float* __restrict__ inv_env,
+                                                                int n_frames, int N, int hop, int64_t total, int64_t tail_zero) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = gid; i < tail_zero; i += gsz) inv_env[total + i] = 0.f;      // dump slots + zero page behind the table
+  for (int64_t pp = gid; pp < total; pp += gsz) {
+    int64_t f_hi = pp / hop;
+    if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+    int64_t f_lo = (pp - N + hop) / hop;
+    if (pp - N + 1 <= 0 || f_lo < 0) f_lo = 0;
+    float env = 0.f;
+    for (int64_t f = f_lo; f <= f_hi; ++f) {
+      const int64_t n = pp - f * hop;
+      if (n >= 0 && n < N) { const float w = window[n]; env = fmaf(w, w, env); }
+    }
+    inv_env[pp] = env > 1e-11f ? 1.0f / env : 0.f;
+  }
+}
+
+template <int PLAN>
+__global__ __launch_bounds__(256, 2) void istft_tiled_pow2_kernel(const GenInv2Args A) {
+  extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
+  constexpr int M = PLAN == 1 ? 2048 : 4096, FB = PLAN == 1 ? 2 : 1, N = 2 * M, HOP = N / 4;
+  constexpr int R3 = PLAN == 1 ? 8 : 16;
+  constexpr int NPI = M / 512;                    // pair iterations per frame: k = t + 256 i < M / 2
+  constexpr int NWR = M / 256;                    // window pairs (= points of a frame) per thread = R3
+  constexpr int NSG = HOP / 512;                  // emitted pairs per thread and segment
+  constexpr int FS = M + M / 256;
+  constexpr int NLD = FB * (2 * NPI + 1);         // bins per thread and tile
+  static_assert(NWR == R3, "the third pass leaves a frame's points in the registers of its window pairs");
+  using at::gfft::dft_r;
+  float2* buf = gbuf;                             // [4096 + 16]
+  float2* tw = gbuf + 4096 + 16;                  // [240 + 257 (R3 - 1)] (<= M)
+  float2* ring = tw + M;                          // [M] overlap-add window, slot = sample pair mod M
+  for (int idx = threadIdx.x; idx < 240; idx += 256) {
+    const int q1 = idx >> 4, k = idx & 15;
+    tw[idx] = A.tw[2 * (k * (q1 + 1) * (M / 256))];
+  }
+  for (int idx = threadIdx.x; idx < 256 * (R3 - 1); idx += 256) {
+    const int q1 = idx >> 8, k = idx & 255;
+    tw[240 + 257 * q1 + k] = A.tw[2 * (k * (q1 + 1))];
+  }
+  float2 wreg[NWR], swr[NPI];
+  const float inv_n = 1.0f / (float)N;
+#pragma unroll
+  for (int i = 0; i < NWR; ++i) {
+    const float2 w = reinterpret_cast<const float2*>(A.window)[threadIdx.x + 256 * i];
+    wreg[i] = make_float2(w.x * inv_n, w.y * inv_n);
+  }
+#pragma unroll
+  for (int i = 0; i < NPI; ++i) swr[i] = A.tw[threadIdx.x + 256 * i];
+  const float2 wmid = A.tw[M / 2];
+  __syncthreads();
+  const int len = (int)A.length;
+
+  float2 xr_[NLD];                                // the tile's bins: per frame k ascending x NPI, M - k descending x NPI, M / 2
+  auto fetch = [&](int64_t row, int f0, int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int fi = 0; fi < FB; ++fi) {
+      const int f = f0 + fi, fx = f - A.lead;
+      const bool live = f >= 0 && f < A.n_frames && fx >= 0 && fx < A.n_x;
+      const float2* __restrict__ Xf = live ? A.X + (row * A.n_x + fx) * (int64_t)(M + 1) : A.zeros;
+#pragma unroll
+      for (int i = 0; i < NPI; ++i) {
+        xr_[fi * (2 * NPI + 1) + i] = Xf[t + 256 * i];
+        xr_[fi * (2 * NPI + 1) + NPI + i] = Xf[(M - 256 * i - 255) + (255 - t)];      // bin M - (t + 256 i)
+      }
+      xr_[fi * (2 * NPI + 1) + 2 * NPI] = Xf[M / 2];
+    }
+  };
+
+  for (int64_t unit = blockIdx.x; unit < A.total_units; unit += gridDim.x) {
+    const int64_t row = unit / A.runs_per_row;
+    const int h0 = (int)(unit - row * A.runs_per_row) * A.run;       // first segment of the run (a multiple of FB)
+    const int h1 = min(h0 + A.run, A.n_seg);
+    float* __restrict__ orow = A.out + row * A.length;
+    for (int i = threadIdx.x; i < M; i += 256) ring[i] = make_float2(0.f, 0.f);   // (slot i belongs to thread i mod 256)
+    const int f_first = h0 - 4;                   // lead-in: the three frames before the run reach into its first segment
+    fetch(row, f_first, (int)threadIdx.x);
+
+    auto tile = [&](int f0) __attribute__((always_inline)) {
+      int t = (int)threadIdx.x;
+      asm volatile("" : "+v"(t));
+      const int st = t ^ ((t >> 4) & 15);
+      const int tm = (256 - t) & 255;
+      const int sm = (tm ^ ((tm >> 4) & 15)) + (t == 0 ? 257 : 0);
+      // ---- fold the half spectra into the transform buffer: slot of point k := conj(Z[k])
+#pragma unroll
+      for (int fi = 0; fi < FB; ++fi) {
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+          float2 xk = xr_[fi * (2 * NPI + 1) + i], xm = xr_[fi * (2 * NPI + 1) + NPI + i];
+          if (i == 0) { if (t == 0) { xk.y = 0.f; xm.y = 0.f; } }      // c2r ignores the imaginary part of DC and Nyquist
+          const float2 w = swr[i];
+          const float c = w.x, s = -w.y;
+          const float sr = xk.x + xm.x, si = xk.y - xm.y;
+          const float dr = xk.x - xm.x, di = xk.y + xm.y;
+          const float P = fmaf(s, dr, c * di), Q = fmaf(c, dr, -s * di);
+          buf[fi * FS + st + 257 * i] = make_float2(sr - P, -(si + Q));
+          // point M - k; for k = 0 there is no point M (its pair slot would be the next frame's first): skipped
+          const int am = fi * FS + sm + 257 * (2 * NPI - 1 - i);
+          if (!(i == 0 && t == 0)) buf[am] = make_float2(sr + P, si - Q);
+        }
+        {
+          const float2 x = xr_[fi * (2 * NPI + 1) + 2 * NPI];           // k = M / 2 pairs with itself
+          const float c = wmid.x, s = -wmid.y;
+          const float sr = 2.f * x.x, di = 2.f * x.y;
+          const float P = c * di, Q = -s * di;
+          if (t == 0) buf[fi * FS + M / 2 + M / 512] = make_float2(sr - P, -Q);
+        }
+      }
+      __syncthreads();
+      // reciprocal envelope of the FB segments this tile finishes, THEN the next tile's bins (vmcnt retires in order:
+      // the stores below need the envelope, not the prefetch)
+      float2 env[FB * NSG];
+#pragma unroll
+      for (int fi = 0; fi < FB; ++fi) {
+        const int f = f0 + fi;
+        const int fe = f < 0 ? 0 : (f >= A.n_seg ? A.n_seg - 1 : f);
+        const float2* __restrict__ e2 = reinterpret_cast<const float2*>(A.inv_env) + (int64_t)fe * (HOP / 2);
+#pragma unroll
+        for (int jj = 0; jj < NSG; ++jj) env[fi * NSG + jj] = e2[t + 256 * jj];
+      }
+      fetch(row, f0 + FB, t);
+      // ---- the forward tile's passes
+      const int fj = PLAN == 1 ? (t >> 7) : 0, j = PLAN == 1 ? (t & 127) : t;
+      const int jl = j & 15;
+      const int rb0 = fj * FS + (j ^ ((j >> 4) & 15));
+      const int rb1 = PLAN == 1 ? fj * FS + (j ^ ((j >> 4) | 8)) : rb0;
+      const int wb1 = fj * FS + 16 * j + (j >> 4);
+      const int wb2 = fj * FS + 257 * (j >> 4);
+      auto rq = [](int q) constexpr { return PLAN == 1 ? 128 * q + (q >> 1) : 257 * q; };
+      float2 v[at::gfft::MAX_RADIX];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = buf[((q & 1) ? rb1 : rb0) + rq(q)];
+      dft_r<16>(v);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) buf[wb1 + (q ^ jl)] = v[q];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = buf[((q & 1) ? rb1 : rb0) + rq(q)];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) v[q] = cmulf(v[q], tw[(q - 1) * 16 + jl]);
+      dft_r<16>(v);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) buf[wb2 + 16 * q + (jl ^ q)] = v[q];
+      __syncthreads();
+      // ---- third pass per frame, then window, overlap-add and the finished segment
+#pragma unroll
+      for (int b = 0; b < FB; ++b) {
+#pragma unroll
+        for (int q = 0; q < R3; ++q) v[q] = buf[st + FS * b + 257 * q];
+#pragma unroll
+        for (int q = 1; q < R3; ++q) v[q] = cmulf(v[q], tw[240 + (q - 1) * 257 + t]);
+        dft_r<R3>(v);
+        const int f = f0 + b;
+        const int base = ((f & 3) * (HOP / 2) + t) & (M - 1);            // ring slot of pair n = t; pair t + 256 q: + 256 q
+#pragma unroll
+        for (int q = 0; q < R3; ++q) {
+          const int slot = (base + 256 * q) & (M - 1);
+          float2 a = ring[slot];
+          a.x = fmaf(v[q].x, wreg[q].x, a.x);
+          a.y = fmaf(-v[q].y, wreg[q].y, a.y);
+          ring[slot] = a;
+        }
+        // segment f = samples [f HOP, (f + 1) HOP) of the padded row: pairs t + 256 jj, ring slots base + 256 jj
+        const bool emit = f >= h0 && f < h1;
+        bool cut = false;
+#pragma unroll
+        for (int jj = 0; jj < NSG; ++jj) {
+          const int slot = (base + 256 * jj) & (M - 1);
+          const float2 a = ring[slot];
+          ring[slot] = make_float2(0.f, 0.f);
+          const float2 e = env[b * NSG + jj];
+          const int p = f * HOP + 2 * (t + 256 * jj) - N / 2;            // output sample of the pair (centre padding removed)
+          const bool full = emit && p >= 0 && p + 1 < len;
+          cut |= emit && !full && p + 1 >= 0 && p < len;
+          float* dst = full ? orow + p : A.dump + ((b * NSG + jj) * 256 + t) * 2;
+          at::stg2_a4<false>(dst, a.x * e.x, a.y * e.y);
+          if (!full) { v[jj].x = a.x * e.x; v[jj].y = a.y * e.y; }       // kept for the element stores below
+        }
+        if (__any(cut)) {            // a pair cut by the end of an odd-length row (or by its start): element stores
+#pragma unroll
+          for (int jj = 0; jj < NSG; ++jj) {
+            const int p = f * HOP + 2 * (t + 256 * jj) - N / 2;
+            if (!emit || (p >= 0 && p + 1 < len)) continue;
+            if (p >= 0 && p < len) orow[p] = v[jj].x;
+            if (p + 1 >= 0 && p + 1 < len) orow[p + 1] = v[jj].y;
+          }
+        }
+      }
+      __syncthreads();               // every read of the transform buffer is done: the next fold may overwrite it
+    };
+
+    tile(f_first);                   // peeled: both edges of the loop below carry "loads, then stores"
+    for (int f0 = f_first + FB; f0 < h1; f0 += FB) tile(f0);
+  }
+}
+
 __global__ __launch_bounds__(256) void istft_frames_generic_kernel(const GenInvArgs A) {
   extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
   const int M = A.M, N = 2 * M;
@@ -828,6 +1057,47 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
   int e = allow_big_lds(reinterpret_cast<const void*>(stft_generic_kernel));
   if (e != AT_OK) return e;
   hipLaunchKernelGGL(stft_generic_kernel, dim3((unsigned)grid_for(rows * n_frames_out)), dim3(256), lds, st, A);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+bool istft_tiled_supported(int n_fft, int hop) { return (n_fft == 4096 || n_fft == 8192) && hop * 4 == n_fft; }
+
+int64_t istft_tiled_workspace_floats(int64_t n_frames, int n_fft, int hop) {
+  return (n_frames - 1) * hop + n_fft + INV2_DUMP_FLOATS + 2 * (int64_t)(n_fft / 2 + 1) + 2;
+}
+
+int istft_tiled(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft, int hop,
+                int lead, int64_t n_frames, int64_t length, float* out, float* workspace, hipStream_t st) {
+  if (!istft_tiled_supported(n_fft, hop)) return AT_ERR_UNSUPPORTED;
+  const int M = n_fft / 2, plan = M == 2048 ? 1 : 2, FB = plan == 1 ? 2 : 1;
+  const int64_t env_n = (n_frames - 1) * hop + n_fft;           // even
+  {
+    int64_t eb = (env_n + 255) / 256;
+    if (eb > 4096) eb = 4096;
+    hipLaunchKernelGGL(istft_env_generic_kernel, dim3((unsigned)eb), dim3(256), 0, st, window, workspace, (int)n_frames, n_fft,
+                       hop, env_n, (int64_t)INV2_DUMP_FLOATS + 2 * (M + 1) + 2);
+    AT_LAUNCH_CHECK();
+  }
+  GenInv2Args G;
+  G.X = reinterpret_cast<const float2*>(X); G.window = window; G.tw = reinterpret_cast<const float2*>(twiddles);
+  G.inv_env = workspace; G.dump = workspace + env_n; G.zeros = reinterpret_cast<const float2*>(workspace + env_n + INV2_DUMP_FLOATS);
+  G.out = out; G.rows = rows; G.length = length; G.n_x = (int)n_x; G.lead = lead; G.n_frames = (int)n_frames;
+  G.n_seg = (int)n_frames - 1 + 4;
+  G.run = INV2_RUN;
+  G.runs_per_row = (G.n_seg + G.run - 1) / G.run;
+  G.total_units = rows * G.runs_per_row;
+  (void)FB;
+  const size_t lds = ((size_t)4096 + 16 + 2 * (size_t)M) * sizeof(float2) + 64;
+  const void* kfn = plan == 1 ? reinterpret_cast<const void*>(istft_tiled_pow2_kernel<1>) : reinterpret_cast<const void*>(istft_tiled_pow2_kernel<2>);
+  int e = allow_big_lds(kfn);
+  if (e != AT_OK) return e;
+  int per_cu = (int)((160 * 1024) / lds);
+  per_cu = per_cu > 2 ? 2 : (per_cu < 1 ? 1 : per_cu);
+  int64_t blocks = (int64_t)device_cu_count() * per_cu;
+  if (blocks > G.total_units) blocks = G.total_units;
+  if (plan == 1) hipLaunchKernelGGL(istft_tiled_pow2_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+  else hipLaunchKernelGGL(istft_tiled_pow2_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, G);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }

@@ -139,6 +139,12 @@ def istft_fused_supported(n_fft: int, hop: int) -> bool:
     return stft_fused_supported(n_fft) and any(hop * r == n_fft for r in (2, 4, 8, 16))
 
 
+def istft_tiled_supported(n_fft: int, hop: int) -> bool:
+    """True when at_istft_f32 takes the tiled single-pass path of the 96 / 192 kHz default sizes (n_fft 4096 / 8192 with
+    hop = n_fft / 4; csrc/stft_generic.hip); like the fused path it takes virtual lead / trail frames without a copy."""
+    return n_fft in (4096, 8192) and hop * 4 == n_fft and os.environ.get("AT_ISTFT_TILED_OFF", "0") in ("", "0")
+
+
 def istft_edit_supported(n_fft: int, hop: int) -> bool:
     """The fused inverse kernel can apply a pending STFT-domain edit while it reads the spectrum."""
     return istft_fused_supported(n_fft, hop) and hop * 4 == n_fft and 64 <= n_fft <= 2048
@@ -154,7 +160,7 @@ def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, l
     _require_native_ok(stft_bcfn)
     B, C, F, N = stft_bcfn.shape
     assert F == n_fft // 2 + 1
-    if (lead or trail) and not istft_fused_supported(n_fft, hop):
+    if (lead or trail) and not (istft_fused_supported(n_fft, hop) or istft_tiled_supported(n_fft, hop)):
         stft_bcfn = torch.nn.functional.pad(stft_bcfn, (lead, trail))
         N, lead, trail = N + lead + trail, 0, 0
     # physical (B, C, N, F) bin-contiguous layout; a no-op for tensors produced by stft_mel()

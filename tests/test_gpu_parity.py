@@ -16,7 +16,7 @@ import pytest
 import torch
 
 import audiotools_amd as A
-from audiotools_amd import _native, kernels
+from audiotools_amd import _native, kernels, tables
 from oracle import restate
 from tests import synth
 
@@ -1127,6 +1127,28 @@ def test_stft_generic_sizes_vs_oracle(n_fft, hop, wt):
         y = s.istft(n_fft, hop, wt).audio_data
         yr = restate.istft(ref, n_fft, hop, wt, False, T)
         assert rel_err(y, yr) < REL and float((y.cpu() - x).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("n_fft,T,B", [(4096, 96000 + 1, 3), (4096, 3 * 1024, 2), (4096, 200000, 5), (8192, 9 * 8192 + 5, 2),
+                                       (8192, 6000, 1)])
+def test_istft_tiled_sizes(n_fft, T, B):
+    """The tiled inverse of the 96 / 192 kHz default sizes (csrc/stft_generic.hip, overlap-add in an LDS ring): odd and
+    even lengths, rows shorter than a run / than one frame, several runs per row (200 000 samples = 196 frames > 96
+    segments), against torch.istft on the same spectrum and against the frame-buffer + gather path."""
+    hop = n_fft // 4
+    x = synth.audio_batch(B, 2, T, seed=n_fft + T, gaps=False)
+    s = A.AudioSignal(x.clone(), 96000).to("cuda")
+    X = s.stft(n_fft, hop, "hann").clone()
+    win = tables.window("hann", n_fft, "cuda")
+    y = kernels.istft(X, win, n_fft, hop, T)
+    ref = torch.istft(X.reshape(-1, X.shape[-2], X.shape[-1]).cpu(), n_fft, hop, window=win.cpu(), center=True, length=T)
+    assert rel_err(y.reshape(ref.shape), ref) < REL and float((y.cpu() - x).abs().max()) < 1e-4
+    # a modified spectrum (no longer the transform of any signal) exercises every frame's own contribution
+    g = torch.Generator(device="cuda").manual_seed(1)
+    X2 = X * (0.5 + torch.rand(X.shape, device="cuda", generator=g))
+    y2 = kernels.istft(X2, win, n_fft, hop, T)
+    ref2 = torch.istft(X2.reshape(-1, X.shape[-2], X.shape[-1]).cpu(), n_fft, hop, window=win.cpu(), center=True, length=T)
+    assert rel_err(y2.reshape(ref2.shape), ref2) < REL
 
 
 def test_stft_generic_match_stride_and_mel():
