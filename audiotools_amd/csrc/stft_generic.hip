@@ -717,6 +717,7 @@ struct GenInv2Args {
   int n_x, lead, n_frames, n_seg, run, runs_per_row;
 };
 constexpr int INV2_DUMP_FLOATS = 8 * 256 * 2;      // one pair slot per (emitted pair of a tile, thread)
+#define INV2_TW_SLOTS(PLAN) ((PLAN) == 1 ? 2048 : 240 + 4 * 257 + 12)
 constexpr int INV2_RUN = 96;                       // segments per run (a multiple of 2); 4 lead-in frames each
 
 __global__ __launch_bounds__(256) void istft_env_generic_kernel(const float* __restrict__ window, float* __restrict__ inv_env,
@@ -748,17 +749,21 @@ __global__ __launch_bounds__(256, 2) void istft_tiled_pow2_kernel(const GenInv2A
   constexpr int FS = M + M / 256;
   constexpr int NLD = FB * (2 * NPI + 1);         // bins per thread and tile
   static_assert(NWR == R3, "the third pass leaves a frame's points in the registers of its window pairs");
+  // M = 4096 keeps w^k, w^2k, w^4k, w^8k of the third pass's fifteen twiddle rows (the others are one product each):
+  // 23 KB less LDS, which is what lets two workgroups share a CU next to the 32 KB ring
+  constexpr bool TW3S = PLAN == 2;
+  constexpr int TWSLOTS = INV2_TW_SLOTS(PLAN);
   using at::gfft::dft_r;
   float2* buf = gbuf;                             // [4096 + 16]
-  float2* tw = gbuf + 4096 + 16;                  // [240 + 257 (R3 - 1)] (<= M)
-  float2* ring = tw + M;                          // [M] overlap-add window, slot = sample pair mod M
+  float2* tw = gbuf + 4096 + 16;                  // [240 + 257 rows]
+  float2* ring = tw + TWSLOTS;                    // [M] overlap-add window, slot = sample pair mod M
   for (int idx = threadIdx.x; idx < 240; idx += 256) {
     const int q1 = idx >> 4, k = idx & 15;
     tw[idx] = A.tw[2 * (k * (q1 + 1) * (M / 256))];
   }
-  for (int idx = threadIdx.x; idx < 256 * (R3 - 1); idx += 256) {
+  for (int idx = threadIdx.x; idx < 256 * (TW3S ? 4 : R3 - 1); idx += 256) {
     const int q1 = idx >> 8, k = idx & 255;
-    tw[240 + 257 * q1 + k] = A.tw[2 * (k * (q1 + 1))];
+    tw[240 + 257 * q1 + k] = A.tw[2 * (k * (TW3S ? (1 << q1) : q1 + 1))];
   }
   float2 wreg[NWR], swr[NPI];
   const float inv_n = 1.0f / (float)N;
@@ -868,12 +873,23 @@ __global__ __launch_bounds__(256, 2) void istft_tiled_pow2_kernel(const GenInv2A
       for (int q = 0; q < 16; ++q) buf[wb2 + 16 * q + (jl ^ q)] = v[q];
       __syncthreads();
       // ---- third pass per frame, then window, overlap-add and the finished segment
+      float2 w3[R3];
+      if constexpr (TW3S) {
+        const float2 w1 = tw[240 + t], w2 = tw[240 + 257 + t], w4 = tw[240 + 2 * 257 + t], w8 = tw[240 + 3 * 257 + t];
+        w3[1] = w1; w3[2] = w2; w3[4] = w4; w3[8] = w8;
+        w3[3] = cmulf(w1, w2); w3[5] = cmulf(w1, w4); w3[6] = cmulf(w2, w4); w3[7] = cmulf(w3[3], w4);
+#pragma unroll
+        for (int q = 9; q < 16; ++q) w3[q] = cmulf(w3[q - 8], w8);
+      } else {
+#pragma unroll
+        for (int q = 1; q < R3; ++q) w3[q] = tw[240 + (q - 1) * 257 + t];
+      }
 #pragma unroll
       for (int b = 0; b < FB; ++b) {
 #pragma unroll
         for (int q = 0; q < R3; ++q) v[q] = buf[st + FS * b + 257 * q];
 #pragma unroll
-        for (int q = 1; q < R3; ++q) v[q] = cmulf(v[q], tw[240 + (q - 1) * 257 + t]);
+        for (int q = 1; q < R3; ++q) v[q] = cmulf(v[q], w3[q]);
         dft_r<R3>(v);
         const int f = f0 + b;
         const int base = ((f & 3) * (HOP / 2) + t) & (M - 1);            // ring slot of pair n = t; pair t + 256 q: + 256 q
@@ -1088,7 +1104,7 @@ int istft_tiled(const float* X, int64_t rows, int64_t n_x, const float* window, 
   G.runs_per_row = (G.n_seg + G.run - 1) / G.run;
   G.total_units = rows * G.runs_per_row;
   (void)FB;
-  const size_t lds = ((size_t)4096 + 16 + 2 * (size_t)M) * sizeof(float2) + 64;
+  const size_t lds = ((size_t)4096 + 16 + (plan == 1 ? INV2_TW_SLOTS(1) : INV2_TW_SLOTS(2)) + (size_t)M) * sizeof(float2) + 64;
   const void* kfn = plan == 1 ? reinterpret_cast<const void*>(istft_tiled_pow2_kernel<1>) : reinterpret_cast<const void*>(istft_tiled_pow2_kernel<2>);
   int e = allow_big_lds(kfn);
   if (e != AT_OK) return e;
