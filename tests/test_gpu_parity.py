@@ -1426,3 +1426,18 @@ def test_spectral_gate_kernel_vs_torch_formulation(nz_batch, amount):
     sm = torch.nn.functional.conv2d(g.reshape(2, 1, 65, 37), torch.outer(tf, tt)[None, None].cuda(), padding=(3, 5)).reshape(2, 1, 65, 37)
     want = Xl * (1 - sm * torch.tensor([1.0, 0.5]).cuda()[:, None, None, None])
     assert rel_err(torch.view_as_real(Y), torch.view_as_real(want)) < 1e-5
+
+
+def test_lufs_does_not_depend_on_workspace_contents():
+    """at_lufs_f32 no longer zero-fills its hop-energy table (every hop that holds samples is written by exactly one
+    wave; only signals shorter than a gating block keep the memset): the result must be bit-stable when the recycled
+    workspace is full of NaNs -- whole rows, a tail that is not a multiple of the hop, exactly one block, less than one."""
+    for T in (441000, 44100 * 3 + 28, 17640, 8000, 4410 * 5, 100000):
+        x = synth.audio_batch(6, 2, T, seed=T, gaps=False).cuda() * 0.3
+        ref = kernels.integrated_loudness(x, 44100).clone()
+        for _ in range(3):
+            junk = torch.full((32 * 1024 * 1024,), float("nan"), device="cuda")
+            del junk
+            assert torch.equal(kernels.integrated_loudness(x, 44100), ref), T
+        want = restate.loudness(x.cpu(), 44100)
+        assert float((ref.cpu() - want).abs().max()) < 0.1
