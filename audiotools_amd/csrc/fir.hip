@@ -319,7 +319,10 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResMfmaArgs A
 // the barrier, ~28 DMA pieces plus an HBM round trip before the next barrier can fall.  Tried: 2 - 4 loader waves
 // (AT_RESAMPLE_LOADERS: 1.19 / 1.41 / 1.40 ms against 1.21), and one workgroup per CU with a 170-register budget
 // and all 48 operands of a tile read before the first MFMA (1.48 ms against 1.27-1.32: the second workgroup hides
-// more than the deeper pipeline gains).  A ring of three tile buffers does not fit twice into 160 KB.
+// more than the deeper pipeline gains).  A ring of three tile buffers does not fit twice into 160 KB; as ONE workgroup
+// per CU -- three buffers, two loader waves alternating so that two tile loads are in flight with two tile periods
+// each, operands in registers -- it measured 1.45-1.49 ms against 1.28-1.32 (profiles/r03_s72_resample_ws3.txt): the
+// load latency is not what holds the kernel either; ten matrix waves per CU keep the pipe ~47 % busy, twenty 57 %.
 constexpr int WS_NC = 6;          // 32-tap chunks a wave keeps in registers (441 -> 160 needs 6)
 
 template <int NC>
