@@ -118,6 +118,8 @@ SIGNATURES = {
     "at_stft_adjoint_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
     "at_stft_mel_adjoint_f32": (_i32, [_p, _p, _p, _p, _i32, _i64, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
     "at_fir_per_item_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "at_sinc_taps_f32": (_i32, [_p, _i64, _f32, _i32, _i32, _p, _p]),
+    "at_eq_taps_f32": (_i32, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "at_fir_fft_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "at_spec_mask_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _f32, _f32, _p]),
     "at_spec_phase_shift_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _p, _p]),

@@ -421,6 +421,78 @@ __global__ __launch_bounds__(1024, 6) void resample_mfma_ws_kernel(const ResMfma
   }
 }
 
+
+// ---- per-item filter design on the device -------------------------------------------------------------------------
+// low_pass / high_pass (dsp.py:177-179 -> julius.LowPassFilter: Hann-windowed sinc of half size int(zeros / c / 2),
+// unit DC gain) and equalizer (effects.py:399-432 -> julius.SplitBands bank, weighted band sum) designed ONE launch per
+// call, straight into the zero-padded (B, L_padded) tap table the FIR kernels read.  The torch formulation they replace
+// is ~25 (sinc) / ~8 (equalizer) whole-table elementwise launches of 3-5 us each per call -- with a (B, bands, L)
+// intermediate for the equalizer -- i.e. as long on the GPU as the filtering itself at cfg4 (1.03 ms for a 0.51 ms
+// kernel).  Arithmetic: float32, the operation order of the torch formulation (kernels.sinc_taps_batched, fx.equalizer_taps).
+constexpr int DESIGN_THREADS = 256;
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  const float tot = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return tot;
+}
+
+// cutoffs (B) normalised (cycles / sample); row b: taps of length 2 H + 1 centred at column H (its own filter has
+// half size h_b <= H, zero outside), columns [2 H + 1, Lp) zero.
+__global__ __launch_bounds__(DESIGN_THREADS) void sinc_taps_kernel(const float* __restrict__ cutoffs, float zeros, int H, int Lp,
+                                                                   float* __restrict__ taps) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const float c = cutoffs[b];
+  const bool pos = c > 0.f;
+  const int half = pos ? (int)((zeros / c) / 2.0f) : 0;
+  const float hf = (float)half;
+  const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
+  const float den = fmaxf(2.0f * hf, 1.0f);
+  float* __restrict__ row = taps + (int64_t)b * Lp;
+  const int L = 2 * H + 1;
+  float part = 0.f;
+  for (int i = threadIdx.x; i < L; i += DESIGN_THREADS) {
+    const int n = i - H;
+    const float nf = (float)n;
+    const bool inside = (n < 0 ? -n : n) <= half;
+    float win = 0.5f - 0.5f * cosf(two_pi * (nf + hf) / den);
+    if (half == 0) win = 1.0f;
+    const float arg = ((2.0f * c) * pi) * nf;
+    const float sinc = arg == 0.f ? 1.0f : sinf(arg) / arg;
+    const float h = inside ? ((2.0f * c) * win) * sinc : 0.f;
+    row[i] = h;
+    part += h;
+  }
+  const float tot = block_sum_256(part, sh);
+  for (int i = threadIdx.x; i < Lp; i += DESIGN_THREADS) {
+    float h = i < L ? row[i] / tot : 0.f;                    // (a thread re-reads only what it wrote)
+    if (!pos) h = 0.f;
+    row[i] = h;
+  }
+}
+
+// weights (B, n_bands); bank (n_bands - 1, L) low-pass bank of the band split; taps[b] = sum_k (w[b,k] - w[b,k+1]) bank[k]
+// + w[b, last] delta(half), zero-padded to Lp.
+__global__ __launch_bounds__(DESIGN_THREADS) void eq_taps_kernel(const float* __restrict__ weights, const float* __restrict__ bank,
+                                                                 int n_bands, int L, int half, int Lp, float* __restrict__ taps) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * DESIGN_THREADS + threadIdx.x;
+  if (i >= Lp) return;
+  const float* __restrict__ w = weights + (int64_t)b * n_bands;
+  float acc = 0.f;
+  if (i < L) {
+    for (int k = 0; k + 1 < n_bands; ++k) acc += (w[k] - w[k + 1]) * bank[(int64_t)k * L + i];
+    if (i == half) acc += w[n_bands - 1];
+  }
+  taps[(int64_t)b * Lp + i] = acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -558,6 +630,36 @@ int at_resample_mfma_f32(const float* x, int64_t rows, int64_t T, const float* W
   // at least 4 waves so that staging a tile is not a one-wave job
   if (threads < 256) threads = 256;
   hipLaunchKernelGGL(resample_mfma_kernel, dim3((unsigned)blocks), dim3(threads), lds, reinterpret_cast<hipStream_t>(stream), A);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+
+// Device-side design of the per-item windowed-sinc low-pass taps of low_pass / high_pass (dsp.py:177-179, 209-211 ->
+// julius.LowPassFilter).  cutoffs (B) f32 normalised cutoffs in (0, 0.5] (0 = the all-zero filter; range checks are the
+// caller's), zeros = julius' `zeros`, H = max_b int(zeros / c_b / 2) (the common half size, computed by the caller from
+// its host copy of the cutoffs), taps (B, L_padded) with L_padded >= 2 H + 1: row b = the filter of item b centred at
+// column H, zero elsewhere -- the table at_fir_fft_f32 / at_fir_per_item_f32 take with half = H.
+int at_sinc_taps_f32(const float* cutoffs, int64_t B, float zeros, int H, int L_padded, float* taps, void* stream) {
+  if (B == 0) return AT_OK;
+  if (!cutoffs || !taps || B < 0 || B > 0x7fffffffLL || H < 0 || L_padded < 2 * H + 1 || !(zeros > 0.f)) return AT_ERR_INVALID;
+  hipLaunchKernelGGL(sinc_taps_kernel, dim3((unsigned)B), dim3(DESIGN_THREADS), 0, reinterpret_cast<hipStream_t>(stream), cutoffs,
+                     zeros, H, L_padded, taps);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+// Composite equalizer FIR per item (effects.py:399-403, 429-432: julius.SplitBands + weighted band sum collapsed to one
+// filter): weights (B, n_bands) linear band gains, bank (n_bands - 1, L) the low-pass bank of the band split (all rows
+// of the common odd length L, centre `half`), taps (B, L_padded >= L).
+int at_eq_taps_f32(const float* weights, const float* bank, int64_t B, int n_bands, int L, int half, int L_padded, float* taps,
+                   void* stream) {
+  if (B == 0) return AT_OK;
+  if (!weights || !bank || !taps || B < 0 || B > 65535 || n_bands < 2 || L <= 0 || half < 0 || half >= L || L_padded < L)
+    return AT_ERR_INVALID;
+  const dim3 grid((unsigned)((L_padded + DESIGN_THREADS - 1) / DESIGN_THREADS), (unsigned)B);
+  hipLaunchKernelGGL(eq_taps_kernel, grid, dim3(DESIGN_THREADS), 0, reinterpret_cast<hipStream_t>(stream), weights, bank, n_bands,
+                     L, half, L_padded, taps);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }

@@ -379,8 +379,17 @@ class EffectMixin:
         weights = (10 ** db).float()
         audio = self.audio_data
         if kernels.is_native(audio):
-            taps, half = equalizer_taps(self.sample_rate, weights.expand(self.batch_size, n_bands), audio.device)
-            self.audio_data = kernels.fir_per_item(audio, taps, replicate=True)
+            bank, half = tables.band_split_bank(int(self.sample_rate), int(n_bands))
+            if bank is None or self.batch_size > 65535:
+                taps, half = equalizer_taps(self.sample_rate, weights.expand(self.batch_size, n_bands), audio.device)
+                self.audio_data = kernels.fir_per_item(audio, taps, replicate=True)
+            else:
+                # the composite filter of every item in one launch, straight into the FIR kernels' padded tap table
+                bank_d = tables.device_table(("band_split_bank", int(self.sample_rate), int(n_bands)), audio.device,
+                                             lambda: (bank.numpy(),))[0]
+                w = weights.to(audio.device).expand(self.batch_size, n_bands)
+                tp, L = kernels.eq_taps_native(w, bank_d, half)
+                self.audio_data = kernels.fir_per_item(audio, tp, replicate=True, L=L)
         else:
             fbank = self.mel_filterbank(n_bands)
             self.audio_data = (fbank * weights.to(self.device)[:, None, None, :]).sum(-1)

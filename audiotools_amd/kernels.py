@@ -363,20 +363,27 @@ FIR_FFT_MIN_TAPS = 96   # below this the direct register-window kernel is cheape
 
 
 def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False, replicate: bool = True,
-                 method: str = "auto", out: torch.Tensor = None):
+                 method: str = "auto", out: torch.Tensor = None, L: int = None):
     """Per-item FIR with replicate padding.  ``taps`` (B or 1, L) odd-length, centred.
     ``method``: "direct" (at_fir_per_item_f32), "fft" (overlap-save, at_fir_fft_f32) or "auto".
-    ``out``: optional contiguous float32 result buffer of ``audio``'s shape (e.g. one slab of a band stack)."""
+    ``out``: optional contiguous float32 result buffer of ``audio``'s shape (e.g. one slab of a band stack).
+    ``L``: ``taps`` is already the zero-padded (rows, pad8(L)) float32 device table of filters of length L
+    (:func:`sinc_taps_native` / :func:`eq_taps_native`): no padding copy."""
     _require_native_ok(audio)
     assert replicate
     B, C, T = audio.shape
     audio = audio.contiguous()
-    rows, L = taps.shape
-    assert L % 2 == 1 and rows in (1, B)
+    if L is None:
+        rows, L = taps.shape
+        assert L % 2 == 1 and rows in (1, B)
+        Lp = _pad8(L)
+        tp = torch.zeros((rows, Lp), dtype=torch.float32, device=audio.device)
+        tp[:, :L] = taps.to(audio.device, torch.float32)
+    else:
+        rows, Lp = taps.shape
+        assert L % 2 == 1 and rows in (1, B) and Lp == _pad8(L) and taps.is_contiguous() and taps.dtype == torch.float32
+        tp = taps
     half = (L - 1) // 2
-    Lp = _pad8(L)
-    tp = torch.zeros((rows, Lp), dtype=torch.float32, device=audio.device)
-    tp[:, :L] = taps.to(audio.device, torch.float32)
     if out is None:
         out = torch.empty_like(audio)
     assert out.shape == audio.shape and out.is_contiguous() and out.dtype == torch.float32 and out.device == audio.device
@@ -595,11 +602,65 @@ def sinc_taps_batched(cutoffs: torch.Tensor, zeros: float, host_cutoffs: torch.T
     return h
 
 
+def _sinc_limits(c: torch.Tensor, zeros: float, host_cutoffs: torch.Tensor = None) -> int:
+    """Range checks of the cutoffs (julius raises ValueError) and the common half size max_b int(zeros / c_b / 2), from
+    the host twin of the cutoffs when there is one (no device-to-host synchronisation), else with one round trip."""
+    def halves(v):
+        pos = v > 0
+        return torch.where(pos, (zeros / torch.where(pos, v, torch.ones_like(v)) / 2).to(torch.int64),
+                           torch.zeros_like(v, dtype=torch.int64))
+    if host_cutoffs is not None:
+        # the same float32 arithmetic as on the device (IEEE division on both sides), in numpy: a handful of torch CPU
+        # ops on a 1024-element tensor cost more than the kernel they size on a 256-core host (thread-pool wake-ups)
+        import numpy as np
+        ch = host_cutoffs.detach().reshape(-1).to(torch.float32).numpy()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            hv = np.where(ch > 0, (np.float32(zeros) / np.where(ch > 0, ch, np.float32(1)) / np.float32(2)).astype(np.int64), 0)
+        cmin, cmax, hmax = float(ch.min()), float(ch.max()), float(hv.max())
+    else:
+        cmin, cmax, hmax = torch.stack([c.min().double(), c.max().double(), halves(c).max().double()]).tolist()
+    if cmin < 0:
+        raise ValueError("Minimum cutoff must be larger than zero.")
+    if cmax > 0.5:
+        raise ValueError("A cutoff above 0.5 does not make sense.")
+    return int(hmax)
+
+
+def sinc_taps_native(cutoffs: torch.Tensor, zeros: float, host_cutoffs: torch.Tensor = None):
+    """``sinc_taps_batched`` as ONE launch (``at_sinc_taps_f32``): returns ``(table (B, pad8(L)) float32, L)`` -- the
+    zero-padded tap table the FIR kernels read, row b centred at column (L - 1) / 2."""
+    c = cutoffs.reshape(-1).to(torch.float32).contiguous()
+    _require_native_ok(c)
+    H = _sinc_limits(c, zeros, host_cutoffs)
+    L = 2 * H + 1
+    Lp = _pad8(L)
+    tp = torch.empty((c.shape[0], Lp), dtype=torch.float32, device=c.device)
+    code = _native.lib().at_sinc_taps_f32(_native.ptr(c), c.shape[0], float(zeros), H, Lp, _native.ptr(tp),
+                                          _native.current_stream(c.device))
+    _native.check(code, "at_sinc_taps_f32")
+    return tp, L
+
+
+def eq_taps_native(weights: torch.Tensor, bank: torch.Tensor, half: int):
+    """Composite equalizer FIR per item as ONE launch (``at_eq_taps_f32``): weights (B, n_bands) linear gains, bank
+    (n_bands - 1, L) device copy of the band-split low-pass bank.  Returns ``(table (B, pad8(L)), L)``."""
+    w = weights.to(torch.float32).contiguous()
+    _require_native_ok(w)
+    B, n_bands = w.shape
+    L = int(bank.shape[1])
+    Lp = _pad8(L)
+    tp = torch.empty((B, Lp), dtype=torch.float32, device=w.device)
+    code = _native.lib().at_eq_taps_f32(_native.ptr(w), _native.ptr(bank), B, n_bands, L, int(half), Lp, _native.ptr(tp),
+                                        _native.current_stream(w.device))
+    _native.check(code, "at_eq_taps_f32")
+    return tp, L
+
+
 def sinc_filter(audio: torch.Tensor, cutoffs_norm: torch.Tensor, zeros: float, highpass: bool, host_cutoffs=None):
     B = audio.shape[0]
-    taps = sinc_taps_batched(cutoffs_norm.to(audio.device).reshape(B), zeros,
+    tp, L = sinc_taps_native(cutoffs_norm.to(audio.device).reshape(B), zeros,
                              None if host_cutoffs is None else host_cutoffs.reshape(B))
-    return fir_per_item(audio, taps, highpass=highpass)
+    return fir_per_item(audio, tp, highpass=highpass, L=L)
 
 
 RESAMPLE_LDS_LIMIT = 160 * 1024

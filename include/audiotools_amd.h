@@ -186,6 +186,21 @@ int at_fir_per_item_f32(const float* x, int64_t B, int64_t C, int64_t T, const f
 int at_fir_fft_f32(const float* x, int64_t B, int64_t C, int64_t T, const float* taps, int taps_rows, int L_padded,
                    int half, int highpass, const float* twiddles2048, float* out, void* stream);
 
+/* ---- per-item filter design on the device ------------------------------------------------
+ * Replaces the per-item julius.LowPassFilter construction of  audiotools/core/dsp.py:177-179, 209-211  and the
+ * julius.SplitBands + weighted band sum of  audiotools/core/effects.py:399-403, 429-432  (host loops over the batch in the
+ * reference; ~25 / ~8 whole-table torch launches per call in this package before round 3): ONE launch writes the
+ * zero-padded (B, L_padded) tap table at_fir_fft_f32 / at_fir_per_item_f32 read.
+ *   at_sinc_taps_f32: cutoffs (B) f32 normalised cutoffs in [0, 0.5] (0 = all-zero filter; the range checks and
+ *     H = max_b int(zeros / c_b / 2) are the caller's, from its host copy); row b = Hann-windowed sinc of half size
+ *     int(zeros / c_b / 2), unit DC gain, centred at column H; L_padded >= 2 H + 1.
+ *   at_eq_taps_f32: weights (B, n_bands) linear gains, bank (n_bands - 1, L) low-pass bank of the band split (centre
+ *     `half`); taps[b] = sum_k (w[b,k] - w[b,k+1]) bank[k] + w[b,last] delta(half); B <= 65535.
+ */
+int at_sinc_taps_f32(const float* cutoffs, int64_t B, float zeros, int H, int L_padded, float* taps, void* stream);
+int at_eq_taps_f32(const float* weights, const float* bank, int64_t B, int n_bands, int L, int half, int L_padded, float* taps,
+                   void* stream);
+
 /* ---- in-place edits of stft_data ---------------------------------------------------------
  * Replaces the polar round trips (abs, angle, masked_fill, exp, multiply: 8-10 whole-tensor passes)
  * of  audiotools/core/dsp.py:217-306 (mask_frequencies / mask_timesteps),  :308-334

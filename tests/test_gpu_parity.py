@@ -1441,3 +1441,28 @@ def test_lufs_does_not_depend_on_workspace_contents():
             assert torch.equal(kernels.integrated_loudness(x, 44100), ref), T
         want = restate.loudness(x.cpu(), 44100)
         assert float((ref.cpu() - want).abs().max()) < 0.1
+
+
+def test_tap_design_kernels_match_torch_formulation():
+    """at_sinc_taps_f32 / at_eq_taps_f32 (one launch per call) against the whole-table torch formulations they replace
+    (kernels.sinc_taps_batched, fx.equalizer_taps): per-item lengths, a zero cutoff (all-zero filter), the zero padding
+    of the table, gains over several decades."""
+    from audiotools_amd import fx
+    cut = torch.tensor([4000.0, 8000.0, 16000.0, 0.0, 24000.0, 123.4, 1000.0]) / 48000
+    ref = kernels.sinc_taps_batched(cut.cuda(), 51, host_cutoffs=cut)
+    tp, L = kernels.sinc_taps_native(cut.cuda(), 51, host_cutoffs=cut)
+    assert L == ref.shape[1] and tp.shape == (7, (L + 7) // 8 * 8)
+    assert float((tp[:, :L] - ref).abs().max()) < 2e-7 and not tp[:, L:].any() and not tp[3].any()
+    assert float((tp[:, :L].sum(-1)[[0, 1, 2, 4, 5, 6]] - 1).abs().max()) < 1e-5          # unit DC gain
+    tp2, L2 = kernels.sinc_taps_native(cut.cuda(), 51)                                       # without the host twin: one sync
+    assert L2 == L and torch.equal(tp2, tp)
+    with pytest.raises(ValueError):
+        kernels.sinc_taps_native(torch.tensor([0.6]).cuda(), 51)
+    for sr, nb in ((48000, 6), (44100, 10), (16000, 3)):
+        g = torch.Generator().manual_seed(nb)
+        w = (10 ** (torch.rand(5, nb, generator=g) * 2 - 1.5)).cuda()
+        ref_t, half = fx.equalizer_taps(sr, w)
+        bank, half2 = tables.band_split_bank(sr, nb)
+        tq, Lq = kernels.eq_taps_native(w, bank.cuda(), half2)
+        assert half == half2 and Lq == ref_t.shape[1]
+        assert rel_err(tq[:, :Lq], ref_t) < 1e-6 and not tq[:, Lq:].any()
