@@ -268,3 +268,29 @@ int main() {
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", str(exe), str(cpp)])
     errs = [float(v) for v in subprocess.check_output([str(exe)]).split()]
     assert len(errs) == 9 and max(errs) < 5e-6, errs
+
+
+def test_sinc_limits_host_arithmetic_matches_device_arithmetic():
+    """The common filter half size of low_pass / high_pass is computed on the HOST twin of the cutoffs (numpy float32) and
+    must equal what the float32 torch formulation -- the device's arithmetic -- gives: a mismatch would size the tap
+    table differently from the filters the design kernel writes into it."""
+    from audiotools_amd import kernels
+
+    def torch_half_max(c, zeros):
+        pos = c > 0
+        return int(torch.where(pos, (zeros / torch.where(pos, c, torch.ones_like(c)) / 2).to(torch.int64),
+                               torch.zeros_like(c, dtype=torch.int64)).max())
+
+    g = torch.Generator().manual_seed(0)
+    for zeros in (51, 8, 24.5, 3):
+        for _ in range(300):
+            c = torch.rand(17, generator=g) * 0.5
+            c[int(torch.randint(0, 17, (1,), generator=g))] = 0.0
+            assert kernels._sinc_limits(c, zeros, c) == torch_half_max(c, zeros)
+    # values at the rounding edges of zeros / c / 2
+    c = torch.tensor([51 / (2 * k) for k in range(52, 450)], dtype=torch.float32)
+    assert kernels._sinc_limits(c, 51, c) == torch_half_max(c, 51)
+    with pytest.raises(ValueError):
+        kernels._sinc_limits(torch.tensor([0.3, 0.51]), 51, torch.tensor([0.3, 0.51]))
+    with pytest.raises(ValueError):
+        kernels._sinc_limits(torch.tensor([-0.1]), 51, torch.tensor([-0.1]))
