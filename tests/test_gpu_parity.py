@@ -1439,7 +1439,7 @@ def test_lufs_does_not_depend_on_workspace_contents():
             junk = torch.full((32 * 1024 * 1024,), float("nan"), device="cuda")
             del junk
             assert torch.equal(kernels.integrated_loudness(x, 44100), ref), T
-        want = restate.loudness(x.cpu(), 44100)
+        want = restate.integrated_loudness(x.cpu(), 44100)          # the meter itself (no padding to 0.5 s, no -70 clamp)
         assert float((ref.cpu() - want).abs().max()) < 0.1
 
 
