@@ -132,6 +132,7 @@ SIGNATURES = {
     "at_absmax_f32": (_i32, [_p, _i64, _i64, _p, _p, _p]),
     "at_roll_pad_f32": (_i32, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "at_alter_drr_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p, _p]),
+    "at_alter_drr_peak_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
     "at_resample_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "at_resample_mfma_supported": (_i32, [_i32, _i32]),
     "at_resample_mfma_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),

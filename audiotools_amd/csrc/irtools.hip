@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void roll_pad_kernel(const float* __restrict__
 // sweeps two and three hit L2 / Infinity Cache.
 __global__ __launch_bounds__(RT) void alter_drr_kernel(const float* __restrict__ x, int64_t B, int C, int64_t T, int t0,
                                                        const float* __restrict__ drr /* (B) */,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, float* __restrict__ vmax, int64_t* __restrict__ imax) {
   __shared__ MaxIdx shm[RT / 64];
   __shared__ float shf[RT / 64];
   for (int64_t row = blockIdx.x; row < B * C; row += gridDim.x) {
@@ -250,11 +250,17 @@ __global__ __launch_bounds__(RT) void alter_drr_kernel(const float* __restrict__
     const float gain = (alpha == alpha && peak > 1.0f) ? 1.0f / peak : 1.0f;  // NaN peak: no rescale
     // sweep 3: literal alpha*w*early + (1-w)*early + late (a non-finite alpha poisons the row as in torch)
     float* __restrict__ orow = out + row * T;
+    // max |output| and its first position (absmax_kernel's rule), for the convolution that follows in apply_ir: the
+    // fourth pass over the impulse responses (0.11 ms at cfg4) rides on this one
+    MaxIdx am{-1.0f, 0};
     auto out_one = [&](float v, int64_t i) {
       const bool early = i >= e_lo && i <= e_hi;
       const bool win = i >= w_lo && i <= w_hi;
       const float e = early ? v : 0.f, l = early ? 0.f : v, w = win ? 1.f : 0.f;
-      return (alpha * w * e + (1.f - w) * e + l) * gain;
+      const float o = (alpha * w * e + (1.f - w) * e + l) * gain;
+      const float a = fabsf(o);
+      if (takes_over(a, am.v)) { am.v = a; am.i = i; }
+      return o;
     };
     if (vec) {
       const float4* __restrict__ p4 = reinterpret_cast<const float4*>(xr);
@@ -273,6 +279,13 @@ __global__ __launch_bounds__(RT) void alter_drr_kernel(const float* __restrict__
       }
     } else {
       for (int64_t i = threadIdx.x; i < T; i += RT) orow[i] = out_one(xr[i], i);
+    }
+    if (vmax) {
+      am = block_argmax(am, shm);
+      if (threadIdx.x == 0) {
+        vmax[row] = am.v;
+        if (imax) imax[row] = am.i;
+      }
     }
   }
 }
@@ -311,18 +324,23 @@ int at_roll_pad_f32(const float* x, int64_t rows, int64_t L, const int64_t* shif
 // x (B, C, T) impulse responses, drr (B) target direct-to-reverberant ratios in dB, t0 = early
 // half-span in samples (int(sample_rate * 0.0025)).  out (B, C, T) = alter_drr(x) followed by
 // ensure_max_of_audio(1.0).  out may alias x.
-int at_alter_drr_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, const float* drr, float* out,
-                     void* stream) {
+// vmax (B*C) / imax (B*C), both optional: max |out| per row and its first position, as at_absmax_f32(out) would report.
+int at_alter_drr_peak_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, const float* drr, float* out,
+                          float* vmax, int64_t* imax, void* stream) {
   if (B == 0) return AT_OK;  // empty batch: nothing to do (torch hands out null data pointers)
-  if (!x || !drr || !out || B < 0 || C <= 0 || T <= 0 || t0 < 0) return AT_ERR_INVALID;
-  if (B == 0) return AT_OK;
+  if (!x || !drr || !out || B < 0 || C <= 0 || T <= 0 || t0 < 0 || (imax && !vmax)) return AT_ERR_INVALID;
   if (C > 1 && x == out) return AT_ERR_INVALID;  // channel 0 is re-read by the other channels
   const int64_t rows = B * C;
   const int64_t blocks = rows < 65536 ? rows : 65536;
   hipLaunchKernelGGL(alter_drr_kernel, dim3((unsigned)blocks), dim3(RT), 0, reinterpret_cast<hipStream_t>(stream), x, B,
-                     (int)C, T, t0, drr, out);
+                     (int)C, T, t0, drr, out, vmax, imax);
   AT_LAUNCH_CHECK();
   return AT_OK;
+}
+
+int at_alter_drr_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, const float* drr, float* out,
+                     void* stream) {
+  return at_alter_drr_peak_f32(x, B, C, T, t0, drr, out, nullptr, nullptr, stream);
 }
 
 }  // extern "C"

@@ -199,7 +199,11 @@ class EffectMixin:
             # value / position come from the un-padded samples (padding zeros never win the max).
             L = min(ir0.shape[-1], T)
             raw = ir0[..., :L].contiguous()
-            peak, idx = kernels.absmax(raw, want_index=True)
+            known = getattr(other, "_peak_of", None)
+            if known is not None and known[0] is ir0 and known[1] == ir0._version and L == ir0.shape[-1]:
+                peak, idx = known[2], known[3]          # found by alter_drr's output pass on these very samples
+            else:
+                peak, idx = kernels.absmax(raw, want_index=True)
             if start_at_max and raw.shape[1] != 1:
                 raise RuntimeError("start_at_max requires a single-channel impulse response")
         pad_len = T - other.signal_length
@@ -465,8 +469,11 @@ class ImpulseResponseMixin:
         drr = util.ensure_tensor(drr, 2, self.batch_size).to(self.device)
         x = self.audio_data
         if kernels.is_native(x) and drr.shape[-1] == 1:
-            # decompose + solve_alpha + recombination + ensure_max_of_audio in one kernel
-            self.audio_data = kernels.alter_drr(x, int(self.sample_rate * 0.0025), drr[:, 0])
+            # decompose + solve_alpha + recombination + ensure_max_of_audio in one kernel; its output pass also finds the
+            # peak and its position, which the convolution of apply_ir asks for next (kept until the samples change)
+            y, vmax, imax = kernels.alter_drr(x, int(self.sample_rate * 0.0025), drr[:, 0], want_peak=True)
+            self.audio_data = y
+            self._peak_of = (y, y._version, vmax, imax)
             return self
         early, late, window = self.decompose_ir()
         alpha = self.solve_alpha(early, late, window, drr)

@@ -546,18 +546,22 @@ def roll_pad(x: torch.Tensor, shift: torch.Tensor, T: int) -> torch.Tensor:
     return out
 
 
-def alter_drr(x: torch.Tensor, t0: int, drr: torch.Tensor) -> torch.Tensor:
-    """alter_drr + ensure_max_of_audio of a batch of impulse responses (B, C, T); ``drr`` (B,)."""
+def alter_drr(x: torch.Tensor, t0: int, drr: torch.Tensor, want_peak: bool = False):
+    """alter_drr + ensure_max_of_audio of a batch of impulse responses (B, C, T); ``drr`` (B,).  ``want_peak``: also
+    returns what ``absmax(out, want_index=True)`` would (max |out| and its first position per row), found in the kernel's
+    output pass."""
     _require_native_ok(x)
     x = x.contiguous()
     B, C, T = x.shape
     d = drr.reshape(-1).to(x.device, torch.float32).contiguous()
     assert d.numel() == B
     out = torch.empty_like(x)
-    code = _native.lib().at_alter_drr_f32(_native.ptr(x), B, C, T, int(t0), _native.ptr(d), _native.ptr(out),
-                                          _native.current_stream(x.device))
-    _native.check(code, "at_alter_drr_f32")
-    return out
+    vmax = torch.empty((B, C), dtype=torch.float32, device=x.device) if want_peak else None
+    imax = torch.empty((B, C), dtype=torch.int64, device=x.device) if want_peak else None
+    code = _native.lib().at_alter_drr_peak_f32(_native.ptr(x), B, C, T, int(t0), _native.ptr(d), _native.ptr(out),
+                                               _native.ptr(vmax), _native.ptr(imax), _native.current_stream(x.device))
+    _native.check(code, "at_alter_drr_peak_f32")
+    return (out, vmax, imax) if want_peak else out
 
 
 def sinc_taps_batched(cutoffs: torch.Tensor, zeros: float, host_cutoffs: torch.Tensor = None):

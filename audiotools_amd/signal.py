@@ -383,6 +383,7 @@ class AudioSignal(SpectralMixin, EffectMixin, LoudnessMixin, ImpulseResponseMixi
             assert data.ndim == 3, "audio_data should be 3-dim (B, C, T)"
         self._audio_data = data
         self._loudness = None  # stale once the samples change
+        self._peak_of = None   # (samples, max |.|, position) left by alter_drr for the convolution that follows
 
     samples = audio_data
 

@@ -264,6 +264,10 @@ int at_absmax_f32(const float* x, int64_t rows, int64_t T, float* vmax, int64_t*
 int at_roll_pad_f32(const float* x, int64_t rows, int64_t L, const int64_t* shift, int64_t T, float* out, void* stream);
 int at_alter_drr_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, const float* drr, float* out,
                      void* stream);
+/* the same, and in its output pass what at_absmax_f32(out) would report: vmax (B*C) and imax (B*C, may be NULL) -- the
+ * peak and roll position effects.py:94-100, 118 take from the altered impulse response before the convolution */
+int at_alter_drr_peak_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, const float* drr, float* out,
+                          float* vmax, int64_t* imax, void* stream);
 
 /* ---- polyphase resampling ---------------------------------------------------------------
  * Replaces  audiotools/core/audio_signal.py:732  julius.resample_frac(x, old, new) (zeros 24,

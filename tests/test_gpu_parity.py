@@ -1466,3 +1466,24 @@ def test_tap_design_kernels_match_torch_formulation():
         tq, Lq = kernels.eq_taps_native(w, bank.cuda(), half2)
         assert half == half2 and Lq == ref_t.shape[1]
         assert rel_err(tq[:, :Lq], ref_t) < 1e-6 and not tq[:, Lq:].any()
+
+
+def test_alter_drr_reports_the_peak_absmax_would():
+    """at_alter_drr_peak_f32: the output pass of alter_drr also yields max |out| and its first position per row -- what
+    apply_ir's convolution asks at_absmax_f32 for next -- for mono and multi-channel impulse responses, a row whose DRR
+    solve fails (NaN propagates like torch), and the cache on the signal object is dropped when the samples change."""
+    sr = 48000
+    g = torch.Generator().manual_seed(3)
+    for B, C, T in ((7, 1, 96000), (3, 2, 24000), (2, 1, 9999)):
+        ir = (torch.randn(B, C, T, generator=g) * torch.exp(-torch.arange(T) / (0.05 * sr))).cuda()
+        drr = (torch.rand(B, generator=g) * 30).cuda()
+        same = lambda a, b: bool(((a == b) | (a.isnan() & b.isnan())).all())     # (a failed DRR solve is a NaN row)
+        out, vmax, imax = kernels.alter_drr(ir, int(sr * 0.0025), drr, want_peak=True)
+        assert same(out, kernels.alter_drr(ir, int(sr * 0.0025), drr))
+        pv, pi = kernels.absmax(out, want_index=True)
+        assert same(vmax, pv) and torch.equal(imax, pi)
+    s = A.AudioSignal(ir.clone(), sr)
+    s.alter_drr(drr)
+    assert s._peak_of is not None and s._peak_of[0] is s.audio_data
+    s.audio_data = s.audio_data * 2
+    assert s._peak_of is None
