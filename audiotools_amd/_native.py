@@ -33,7 +33,11 @@ HEADERS = ["at_common.h", "fft_wave.h", "generic_fft.h"]
 _NO_SLP = ["-fno-slp-vectorize"]
 # loudness.hip (round 3): the scalar build of kweight_hop_energy_dma needs 86 VGPRs instead of 113 and its loop has
 # fewer issue slots (803 scalar FP + 74 moves vs 605 scalar + 126 half-rate packed + 121 moves).
-FILE_FLAGS = {"stft.hip": _NO_SLP, "istft.hip": _NO_SLP, "firfft.hip": _NO_SLP, "longconv.hip": _NO_SLP, "loudness.hip": _NO_SLP,
+# istft.hip: the inverse kernels are one long dependent chain per wave at two waves per SIMD; LLVM's "max-ilp" strategy
+# orders it for latency instead of register pressure (no spills, 237 -> 254 registers: the occupancy is the same) and
+# measures 2-3 % faster; every other source measured slower or equal with it (profiles/r03_notes.md, s81).
+_MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+FILE_FLAGS = {"stft.hip": _NO_SLP, "istft.hip": _NO_SLP + _MAX_ILP, "firfft.hip": _NO_SLP, "longconv.hip": _NO_SLP, "loudness.hip": _NO_SLP,
               "stft_generic.hip": _NO_SLP}
 LINK_FLAGS = ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
 
