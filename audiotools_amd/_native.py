@@ -53,6 +53,8 @@ def compile_command(src, obj):
         per_file = []
     if os.environ.get("AT_NOSLP_ALL") == "1":          # A/B builds: every source without SLP packing
         per_file = ["-fno-slp-vectorize"]
+    if os.path.basename(src) in os.environ.get("AT_MAXILP_FILES", "").split(","):   # A/B builds of the scheduler strategy
+        per_file = [f for f in per_file if f not in _MAX_ILP] + _MAX_ILP
     return [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + per_file + extra + ["-o", obj, src]
 
 
@@ -76,7 +78,7 @@ def build(force: bool = False, verbose: bool = False, out: str = None) -> str:
     hdrs = [os.path.join(CSRC_DIR, h) for h in HEADERS]
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
     flag_stamp = os.path.join(obj_dir, "flags.txt")
-    flags_now = repr((os.environ.get("AT_HIPCC_FLAGS", ""), os.environ.get("AT_STFT_SLP", ""), os.environ.get("AT_NOSLP_ALL", ""), FILE_FLAGS))
+    flags_now = repr((os.environ.get("AT_HIPCC_FLAGS", ""), os.environ.get("AT_STFT_SLP", ""), os.environ.get("AT_NOSLP_ALL", ""), os.environ.get("AT_MAXILP_FILES", ""), FILE_FLAGS))
     flags_same = os.path.exists(flag_stamp) and open(flag_stamp).read() == flags_now
     jobs, objs = [], []
     for s in SOURCES:
