@@ -244,10 +244,19 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   // before the next could be issued.  Without the zeroing the fold is one block: 32 + 16 LDS operations in flight
   // (1.963 -> 1.954 ms at B = 512, same box interleaved, profiles/r03_notes.md).
   constexpr bool ZERO_PAGE = !ADJ && !MELB && !EDIT;
+  // PAIRED (M = 1024): the transform runs as 4 . 16 . 16 instead of 16 . 16 . 4, and a lane owns the four radix-4 groups
+  //   j = t, t + 64, 192 - t, 256 - t   (lane 0: 0, 64, 192, 128),   points j + 256 r in register b + 4 r,
+  // a set closed under k -> M - k: the Hermitian partner of register q is register 15 - q of the SAME lane (lane 0:
+  // groups 0 and 128 pair with themselves, bin 0 with the Nyquist bin).  The fold needs no lane exchange -- the 32
+  // ds_bpermute per frame of the t + 64 q layout are gone --, the pairs of the two middle groups come out of one
+  // evaluation each, and all four groups are still 512-byte runs of a frame's bins (two ascending, two descending).
+  // The first pass writes every group where the Stockham order wants it, so nothing behind it changes but the radices.
+  constexpr bool PAIRED = M == 1024 && !ADJ && !MELB;
   __shared__ float2 lds[4 * WAVE_LDS_SLOTS];
   __shared__ float2 s_win2[M];
   __shared__ float2 s_twf[M];                                     // fold twiddles (cos, -sin)(2 pi k / N), k < M
-  __shared__ __attribute__((aligned(16))) float s_tw2[16 * 36];   // pass-2 twiddles, row = j mod 16
+  __shared__ __attribute__((aligned(16))) float s_tw2[16 * 36];   // pass-2 twiddles, row = j mod 16 (PAIRED: j mod 4)
+  __shared__ __attribute__((aligned(16))) float s_tw3[PAIRED ? 64 * 36 : 4];   // PAIRED: last-pass twiddles w_M^(r t), row = t
   __shared__ int s_bb[MELB ? M + 1 : 1];
   __shared__ float2 s_bw[MELB ? M + 1 : 1];
   if constexpr (MELB) {
@@ -260,7 +269,16 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     s_win2[i] = make_float2(w.x * inv_n, w.y * inv_n);
     s_twf[i] = A.tw[i];
   }
-  if constexpr (P::R2 > 1) {
+  if constexpr (PAIRED) {
+    for (int i = threadIdx.x; i < 4 * 16; i += 256) {             // second pass: radix 16 behind NS = 4
+      const int jj = i / 16, r = i % 16;
+      reinterpret_cast<float2*>(s_tw2 + jj * 36)[r] = A.tw[r * jj * (N / 64)];
+    }
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {            // last pass: radix 16 behind NS = 64
+      const int tt = i / 16, r = i % 16;
+      reinterpret_cast<float2*>(s_tw3 + tt * 36)[r] = A.tw[r * tt * (N / M)];
+    }
+  } else if constexpr (P::R2 > 1) {
     for (int i = threadIdx.x; i < 16 * P::R2; i += 256) {
       const int jj = i / P::R2, r = i % P::R2;
       reinterpret_cast<float2*>(s_tw2 + jj * 36)[r] = A.tw[r * jj * (N / (16 * P::R2))];
@@ -316,6 +334,13 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   // select) and issued one frame AHEAD, right after the fold consumed the registers, so their
   // latency hides behind the FFT of the current frame.
   const int src_lane = (lane - t) + ((L - t) & (L - 1));
+  // bin held by register q: t + L q, or (PAIRED) group b = q & 3, r = q >> 2
+  const int pj2 = 192 - t, pj3 = t == 0 ? 128 : 256 - t;
+  auto kq = [&](int q) __attribute__((always_inline)) -> int {
+    if constexpr (!PAIRED) return t + L * q;
+    const int b = q & 3, r = q >> 2;
+    return (b == 0 ? t : b == 1 ? t + 64 : b == 2 ? pj2 : pj3) + 256 * r;
+  };
   float2 xa[16], xN;
   constexpr int GP = 8;            // mel values per lane: n_mels <= GP * L
   float gpre[MELB ? GP : 1];
@@ -324,7 +349,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     const bool live = fx >= 0 && fx < A.n_x && f < h1;
     const float2* __restrict__ Xf = (ZERO_PAGE && !live) ? A.zeros : Xrow + (int64_t)(live ? fx : 0) * (M + 1);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) xa[q] = at::ldg2<AT_NT_ISTFT_LD != 0>(Xf + t + L * q);
+    for (int q = 0; q < 16; ++q) xa[q] = at::ldg2<AT_NT_ISTFT_LD != 0>(Xf + kq(q));
     xN = at::ldg2<AT_NT_ISTFT_LD != 0>(Xf + M);
     if constexpr (MELB) {
       const float* __restrict__ gr = A.gmel + (row * (int64_t)A.n_x + (live ? fx : 0)) * A.n_mels;
@@ -389,12 +414,52 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
         return x;
       };
 #pragma unroll
-      for (int q = 0; q < 16; ++q) xa[q] = edit(xa[q], t + L * q);
+      for (int q = 0; q < 16; ++q) xa[q] = edit(xa[q], kq(q));
       xN = edit(xN, M);
     }
     float2 a[16];
+    if constexpr (PAIRED) {
+      if constexpr (!ZERO_PAGE) {
+        if (!live) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+          for (int q = 0; q < 16; ++q) xa[q] = make_float2(0.f, 0.f);
+          xN = make_float2(0.f, 0.f);
+        }
+      }
+      // the two middle groups: registers q = 1 + 4 r and 15 - q hold X[k] and X[M - k]; with (c, s) = (cos, sin)(2 pi k / N)
+      // and P = s dr + c di, Q = c dr - s di:   a[k] = (sr - P, -(si + Q)),   a[M - k] = (sr + P, si - Q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = 1 + 4 * r, qp = 15 - q;
+        const float2 xk = xa[q], xm = xa[qp];
+        const float2 w = s_twf[t + 64 + 256 * r];
+        const float c = w.x, sn = -w.y;
+        const float sr = xk.x + xm.x, si = xk.y - xm.y;
+        const float dr = xk.x - xm.x, di = xk.y + xm.y;
+        const float pp = fmaf(sn, dr, c * di), qq = fmaf(c, dr, -sn * di);
+        a[q] = make_float2(sr - pp, -(si + qq));
+        a[qp] = make_float2(sr + pp, si - qq);
+      }
+      // the outer groups pair across each other (q <-> 15 - q) -- except in lane 0, where group 0 pairs with itself
+      // (bin 0 with the Nyquist bin) and so does group 128: one evaluation per register, partner by select
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = (i & 1) ? 4 * (i >> 1) + 3 : 4 * (i >> 1);
+        float2 xk = xa[q];
+        const float2 own = (q & 3) == 0 ? (q == 0 ? xN : xa[q == 0 ? 0 : 16 - q]) : xa[18 - q];
+        float2 xm = t == 0 ? own : xa[15 - q];
+        if (q == 0) {
+          if (t == 0) { xk.y = 0.f; xm.y = 0.f; }   // c2r ignores the imaginary part of DC and Nyquist
+        }
+        const float2 w = s_twf[kq(q)];
+        const float c = w.x, sn = -w.y;
+        const float sr = xk.x + xm.x, si = xk.y - xm.y;
+        const float dr = xk.x - xm.x, di = xk.y + xm.y;
+        a[q] = make_float2(sr - sn * dr - c * di, -(si + c * dr - sn * di));
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < (PAIRED ? 0 : 16); ++q) {
       const int k = t + L * q;
       float2 xk = xa[q];
       const float2 sv = make_float2(__shfl(xa[15 - q].x, src_lane, 64), __shfl(xa[15 - q].y, src_lane, 64));
@@ -426,7 +491,36 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     // The last pass of the transform runs in place on registers (pass_compute_regs): its outputs
     // are the points t + L q of this thread, the layout the register window needs -- no slab
     // round trip behind it.
-    if constexpr (P::R2 == 1) {
+    if constexpr (PAIRED) {
+      // pass 1: the four radix-4 butterflies of this lane's groups, each written to points 4 j .. 4 j + 3
+      const int jb[4] = {t, t + 64, pj2, pj3};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        float2 v[4] = {a[b], a[b + 4], a[b + 8], a[b + 12]};
+        Dft<4>::run(v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fbuf[phys<L>(4 * jb[b] + r)] = v[r];
+      }
+      wave_sync();
+      load_points<L>(a, fbuf, t);
+      wave_sync();
+      float2 tw2[16], tw3[16];
+      {
+        const float2* rowp = reinterpret_cast<const float2*>(s_tw2 + (t & 3) * 36);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tw2[r] = rowp[r];
+      }
+      pass_compute_store<16, 4, L>(a, fbuf, t, tw2);
+      wave_sync();
+      load_points<L>(a, fbuf, t);
+      wave_sync();
+      {
+        const float2* rowp = reinterpret_cast<const float2*>(s_tw3 + t * 36);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tw3[r] = rowp[r];
+      }
+      pass_compute_regs<16, 64, L>(a, tw3);
+    } else if constexpr (P::R2 == 1) {
       pass_compute_regs<16, 1, L>(a, nullptr);
     } else {
       pass_compute_store<16, 1, L>(a, fbuf, t, nullptr);
