@@ -294,3 +294,19 @@ def test_sinc_limits_host_arithmetic_matches_device_arithmetic():
         kernels._sinc_limits(torch.tensor([0.3, 0.51]), 51, torch.tensor([0.3, 0.51]))
     with pytest.raises(ValueError):
         kernels._sinc_limits(torch.tensor([-0.1]), 51, torch.tensor([-0.1]))
+
+
+def test_paired_inverse_index_plan_replays_irfft():
+    """csrc/istft.hip PAIRED: groups j = t, t + L, 3L - t, 4L - t per lane are closed under k -> M - k, the fold needs
+    in-lane partners only, and the Stockham passes 4 . 16 . (M / 64) behind the permuted first pass give the transform
+    (tools/emulate_istft_paired.py replays the kernel's index arithmetic in numpy)."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "emulate_istft_paired.py")
+    spec = importlib.util.spec_from_file_location("emulate_istft_paired", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for M in (1024, 512, 256):
+        fft_err, irfft_err = mod.replay(M, seed=M)
+        assert fft_err < 1e-12 and irfft_err < 1e-13, (M, fft_err, irfft_err)
