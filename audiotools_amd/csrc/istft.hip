@@ -244,19 +244,23 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   // before the next could be issued.  Without the zeroing the fold is one block: 32 + 16 LDS operations in flight
   // (1.963 -> 1.954 ms at B = 512, same box interleaved, profiles/r03_notes.md).
   constexpr bool ZERO_PAGE = !ADJ && !MELB && !EDIT;
-  // PAIRED (M = 1024): the transform runs as 4 . 16 . 16 instead of 16 . 16 . 4, and a lane owns the four radix-4 groups
-  //   j = t, t + 64, 192 - t, 256 - t   (lane 0: 0, 64, 192, 128),   points j + 256 r in register b + 4 r,
+  // PAIRED (M = 16 L = 1024): the transform runs as 4 . 16 . (M / 64) instead of 16 . 16 . (M / 256), and a lane owns
+  // the four radix-4 groups
+  //   j = t, t + L, 3L - t, 4L - t   (lane 0: 0, L, 3L, 2L),   points j + 4L r in register b + 4 r,
   // a set closed under k -> M - k: the Hermitian partner of register q is register 15 - q of the SAME lane (lane 0:
-  // groups 0 and 128 pair with themselves, bin 0 with the Nyquist bin).  The fold needs no lane exchange -- the 32
+  // groups 0 and 2L pair with themselves, bin 0 with the Nyquist bin).  The fold needs no lane exchange -- the 32
   // ds_bpermute per frame of the t + 64 q layout are gone --, the pairs of the two middle groups come out of one
   // evaluation each, and all four groups are still 512-byte runs of a frame's bins (two ascending, two descending).
   // The first pass writes every group where the Stockham order wants it, so nothing behind it changes but the radices.
+  // (M = 512 is expressible the same way -- tools/emulate_istft_paired.py replays it -- but its hop = n_fft / 4 instantiation then
+  //  needs 258 registers: the two spilled ones are the row pointer, reloaded in front of every prefetch behind an s_waitcnt vmcnt(0))
   constexpr bool PAIRED = M == 1024 && !ADJ && !MELB;
+  constexpr int R3P = PAIRED ? M / 64 : 16;                       // PAIRED: the last radix
   __shared__ float2 lds[4 * WAVE_LDS_SLOTS];
   __shared__ float2 s_win2[M];
   __shared__ float2 s_twf[M];                                     // fold twiddles (cos, -sin)(2 pi k / N), k < M
   __shared__ __attribute__((aligned(16))) float s_tw2[16 * 36];   // pass-2 twiddles, row = j mod 16 (PAIRED: j mod 4)
-  __shared__ __attribute__((aligned(16))) float s_tw3[PAIRED ? 64 * 36 : 4];   // PAIRED: last-pass twiddles w_M^(r t), row = t
+  __shared__ __attribute__((aligned(16))) float s_tw3[PAIRED ? L * 36 : 4];    // PAIRED: last-pass twiddles, row = t
   __shared__ int s_bb[MELB ? M + 1 : 1];
   __shared__ float2 s_bw[MELB ? M + 1 : 1];
   if constexpr (MELB) {
@@ -274,9 +278,9 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
       const int jj = i / 16, r = i % 16;
       reinterpret_cast<float2*>(s_tw2 + jj * 36)[r] = A.tw[r * jj * (N / 64)];
     }
-    for (int i = threadIdx.x; i < 64 * 16; i += 256) {            // last pass: radix 16 behind NS = 64
-      const int tt = i / 16, r = i % 16;
-      reinterpret_cast<float2*>(s_tw3 + tt * 36)[r] = A.tw[r * tt * (N / M)];
+    for (int i = threadIdx.x; i < L * 16; i += 256) {             // last pass: radix M / 64 behind NS = 64, entry b R + r
+      const int tt = i / 16, b3 = (i % 16) / R3P, r = i % R3P;
+      reinterpret_cast<float2*>(s_tw3 + tt * 36)[i % 16] = A.tw[r * ((tt + b3 * L) % 64) * (N / (64 * R3P))];
     }
   } else if constexpr (P::R2 > 1) {
     for (int i = threadIdx.x; i < 16 * P::R2; i += 256) {
@@ -335,11 +339,11 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   // latency hides behind the FFT of the current frame.
   const int src_lane = (lane - t) + ((L - t) & (L - 1));
   // bin held by register q: t + L q, or (PAIRED) group b = q & 3, r = q >> 2
-  const int pj2 = 192 - t, pj3 = t == 0 ? 128 : 256 - t;
+  const int pj2 = 3 * L - t, pj3 = t == 0 ? 2 * L : 4 * L - t;
   auto kq = [&](int q) __attribute__((always_inline)) -> int {
     if constexpr (!PAIRED) return t + L * q;
     const int b = q & 3, r = q >> 2;
-    return (b == 0 ? t : b == 1 ? t + 64 : b == 2 ? pj2 : pj3) + 256 * r;
+    return (b == 0 ? t : b == 1 ? t + L : b == 2 ? pj2 : pj3) + 4 * L * r;
   };
   float2 xa[16], xN;
   constexpr int GP = 8;            // mel values per lane: n_mels <= GP * L
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
       for (int r = 0; r < 4; ++r) {
         const int q = 1 + 4 * r, qp = 15 - q;
         const float2 xk = xa[q], xm = xa[qp];
-        const float2 w = s_twf[t + 64 + 256 * r];
+        const float2 w = s_twf[t + L + 4 * L * r];
         const float c = w.x, sn = -w.y;
         const float sr = xk.x + xm.x, si = xk.y - xm.y;
         const float dr = xk.x - xm.x, di = xk.y + xm.y;
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
     // round trip behind it.
     if constexpr (PAIRED) {
       // pass 1: the four radix-4 butterflies of this lane's groups, each written to points 4 j .. 4 j + 3
-      const int jb[4] = {t, t + 64, pj2, pj3};
+      const int jb[4] = {t, t + L, pj2, pj3};
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         float2 v[4] = {a[b], a[b + 4], a[b + 8], a[b + 12]};
@@ -517,9 +521,9 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
       {
         const float2* rowp = reinterpret_cast<const float2*>(s_tw3 + t * 36);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) tw3[r] = rowp[r];
+        for (int r = 0; r < 16; ++r) tw3[r] = rowp[r];
       }
-      pass_compute_regs<16, 64, L>(a, tw3);
+      pass_compute_regs<R3P, 64, L>(a, tw3);
     } else if constexpr (P::R2 == 1) {
       pass_compute_regs<16, 1, L>(a, nullptr);
     } else {
