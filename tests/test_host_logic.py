@@ -328,3 +328,31 @@ def test_pow2_tile_index_plan_replays_rfft_and_is_conflict_free():
         mod.run(plan, seed=plan)          # asserts inside
     for sr, n_fft, n_mels, FB, NPC in [(96000, 4096, 80, 2, 4), (96000, 4096, 7, 2, 4), (192000, 8192, 128, 1, 8), (192000, 8192, 3, 1, 8)]:
         mod.mel_reduction(sr, n_fft, n_mels, FB, NPC)
+
+
+def _load_tool(name):
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", name + ".py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_kernel_index_plans_replayed_on_the_cpu():
+    """The numpy replays the kernels were designed against stay true: the four-step convolution's index plan
+    (csrc/longconv.hip) for plans of every shape, the hop-energy pieces of the loudness kernel (csrc/loudness.hip: every hop
+    written exactly once, nothing past the end counted), and the fused forward kernel's paired last pass (csrc/stft.hip)."""
+    import numpy as np
+
+    lc = _load_tool("emulate_longconv")
+    rng = np.random.default_rng(0)
+    for T in (16, 120, 2 * 7 * 9, 4096, 9600, 44100):
+        x, h = rng.standard_normal(T), rng.standard_normal(T)
+        ref = np.fft.irfft(np.fft.rfft(x) * np.fft.rfft(h), T) * 0.37
+        y, _ = lc.emulate(T, x, h, 0.37)
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-6, T
+    _load_tool("emulate_lufs_pieces").main(60)      # asserts inside
+    _load_tool("emulate_stft_v2")                   # a script: asserts its error against numpy's rfft on import

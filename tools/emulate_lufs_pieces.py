@@ -68,8 +68,9 @@ def kernel_model(y2, T, S, H_data, seg_hops, seg, warm):
     return out
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+def main(n=None):
+    if n is None:
+        n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     rng = np.random.default_rng(0)
     worst = 0.0
     for trial in range(n):
