@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   // before the next could be issued.  Without the zeroing the fold is one block: 32 + 16 LDS operations in flight
   // (1.963 -> 1.954 ms at B = 512, same box interleaved, profiles/r03_notes.md).
   constexpr bool ZERO_PAGE = !ADJ && !MELB && !EDIT;
-  // PAIRED (M = 16 L = 1024): the transform runs as 4 . 16 . (M / 64) instead of 16 . 16 . (M / 256), and a lane owns
+  // PAIRED (M = 16 L = 1024, 512): the transform runs as 4 . 16 . (M / 64) instead of 16 . 16 . (M / 256), and a lane owns
   // the four radix-4 groups
   //   j = t, t + L, 3L - t, 4L - t   (lane 0: 0, L, 3L, 2L),   points j + 4L r in register b + 4 r,
   // a set closed under k -> M - k: the Hermitian partner of register q is register 15 - q of the SAME lane (lane 0:
@@ -252,9 +252,11 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
   // ds_bpermute per frame of the t + 64 q layout are gone --, the pairs of the two middle groups come out of one
   // evaluation each, and all four groups are still 512-byte runs of a frame's bins (two ascending, two descending).
   // The first pass writes every group where the Stockham order wants it, so nothing behind it changes but the radices.
-  // (M = 512 is expressible the same way -- tools/emulate_istft_paired.py replays it -- but its hop = n_fft / 4 instantiation then
-  //  needs 258 registers: the two spilled ones are the row pointer, reloaded in front of every prefetch behind an s_waitcnt vmcnt(0))
-  constexpr bool PAIRED = M == 1024 && !ADJ && !MELB;
+  // (M = 512: radices 4 . 16 . 8; the last pass composes its twiddles from three table entries per butterfly -- with all 14
+  //  read up front the hop = n_fft / 4 instantiation needs 258 registers and spills the row pointer, reloaded in front of every
+  //  prefetch behind an s_waitcnt vmcnt(0).  Its EDIT instantiation keeps the exchange layout: no GPU test covers folded edits at
+  //  n_fft 1024.  M = 256 would be 4 . 16 . 4: tools/emulate_istft_paired.py replays all three.)
+  constexpr bool PAIRED = (M == 1024 || (M == 512 && !EDIT)) && !ADJ && !MELB;
   constexpr int R3P = PAIRED ? M / 64 : 16;                       // PAIRED: the last radix
   __shared__ float2 lds[4 * WAVE_LDS_SLOTS];
   __shared__ float2 s_win2[M];
@@ -518,12 +520,30 @@ __global__ __launch_bounds__(256, AT_ISTFT_WPS) void istft_fused_kernel(const Is
       wave_sync();
       load_points<L>(a, fbuf, t);
       wave_sync();
-      {
+      if constexpr (R3P == 16) {
         const float2* rowp = reinterpret_cast<const float2*>(s_tw3 + t * 36);
 #pragma unroll
         for (int r = 0; r < 16; ++r) tw3[r] = rowp[r];
+        pass_compute_regs<R3P, 64, L>(a, tw3);
+      } else {
+        // M = 512: two radix-8 butterflies; of each butterfly's seven twiddles w, w^2, w^4 come from the table and the rest
+        // are one or two products (all 14 entries read up front do not fit the register budget of the hop = n_fft / 4 kernel)
+        constexpr int NBP = 16 / R3P;
+        const float2* rowp = reinterpret_cast<const float2*>(s_tw3 + t * 36);
+#pragma unroll
+        for (int b = 0; b < NBP; ++b) {
+          float2 v[R3P];
+#pragma unroll
+          for (int r = 0; r < R3P; ++r) v[r] = a[b + r * NBP];
+          const float2 w1 = rowp[b * R3P + 1], w2 = rowp[b * R3P + 2], w4 = rowp[b * R3P + 4];
+          const float2 w6 = cmul(w4, w2);
+          v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], cmul(w2, w1)); v[4] = cmul(v[4], w4);
+          v[5] = cmul(v[5], cmul(w4, w1)); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], cmul(w6, w1));
+          Dft<R3P>::run(v);
+#pragma unroll
+          for (int r = 0; r < R3P; ++r) a[b + r * NBP] = v[r];
+        }
       }
-      pass_compute_regs<R3P, 64, L>(a, tw3);
     } else if constexpr (P::R2 == 1) {
       pass_compute_regs<16, 1, L>(a, nullptr);
     } else {

@@ -1271,7 +1271,7 @@ def test_stft_mel_structured_inputs(sr, n_fft, hop):
     _bounded_by_torch(mel.cpu(), mel32, mel64, f"mel {n_fft}/{hop}")
 
 
-@pytest.mark.parametrize("sr,n_fft,hop", [(44100, 2048, 512), (16000, 512, 128)])
+@pytest.mark.parametrize("sr,n_fft,hop", [(44100, 2048, 512), (16000, 512, 128), (22050, 1024, 256)])
 def test_istft_structured_inputs(sr, n_fft, hop):
     from audiotools_amd import tables
     x = synth.structured_batch(40000, sr)
