@@ -356,3 +356,23 @@ def test_kernel_index_plans_replayed_on_the_cpu():
         assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-6, T
     _load_tool("emulate_lufs_pieces").main(60)      # asserts inside
     _load_tool("emulate_stft_v2")                   # a script: asserts its error against numpy's rfft on import
+
+
+def test_build_flags_per_source(monkeypatch):
+    """_native.compile_command: no SLP packing for the FFT / filter sources, LLVM's max-ilp scheduler strategy for istft.hip only
+    (measured per source, profiles/r03_notes.md), and the A/B switches of the build leave the defaults alone when unset."""
+    from audiotools_amd import _native
+
+    for var in ("AT_HIPCC_FLAGS", "AT_STFT_SLP", "AT_NOSLP_ALL", "AT_MAXILP_FILES"):
+        monkeypatch.delenv(var, raising=False)
+    flags = {s: _native.compile_command("/x/" + s, "/x/o.o") for s in _native.SOURCES}
+    ilp = "-amdgpu-sched-strategy=max-ilp"
+    assert [s for s, f in flags.items() if ilp in f] == ["istft.hip"]
+    for s in ("stft.hip", "istft.hip", "firfft.hip", "longconv.hip", "loudness.hip", "stft_generic.hip"):
+        assert "-fno-slp-vectorize" in flags[s]
+    for s in ("fir.hip", "irtools.hip", "specedit.hip", "fftconv.hip", "vocoder.hip"):
+        assert "-fno-slp-vectorize" not in flags[s]
+    assert all("--offload-arch=gfx950" in f and "-O3" in f for f in flags.values())
+    monkeypatch.setenv("AT_MAXILP_FILES", "longconv.hip")
+    assert ilp in _native.compile_command("/x/longconv.hip", "/x/o.o") and ilp not in _native.compile_command("/x/fir.hip", "/x/o.o")
+    assert _native.compile_command("/x/istft.hip", "/x/o.o").count(ilp) == 1
