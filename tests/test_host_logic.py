@@ -376,3 +376,25 @@ def test_build_flags_per_source(monkeypatch):
     monkeypatch.setenv("AT_MAXILP_FILES", "longconv.hip")
     assert ilp in _native.compile_command("/x/longconv.hip", "/x/o.o") and ilp not in _native.compile_command("/x/fir.hip", "/x/o.o")
     assert _native.compile_command("/x/istft.hip", "/x/o.o").count(ilp) == 1
+
+
+def test_fp16_split_resampler_model_matches_the_oracle():
+    """tools/emulate_resample_f16.py models the resampler planned in DESIGN.md section 10 (fp16 high / low planes with a
+    per-tile power-of-two scale, operands through aligned dwords + v_alignbit, hh + hl + lh products in fp32): same framing and
+    length as julius.resample_frac, and closer to float64 than the fp32 formulation on loud, quiet and unclipped inputs."""
+    import numpy as np
+    import torch
+
+    mod = _load_tool("emulate_resample_f16")
+    pl = mod.plan(44100, 16000)
+    assert (pl["NPB"], pl["NS"]) == (10, 12)
+    rng = np.random.default_rng(3)
+    for T, amp in [(5000, 0.1), (4410 + 17, 1e-4), (7000, 2.0)]:
+        x = (amp * rng.standard_normal(T)).astype(np.float32)
+        want = julius_leaf.resample_frac(torch.from_numpy(x)[None, None].double(), 44100, 16000)[0, 0].numpy()
+        got = mod.resample(x, 44100, 16000, pl)
+        assert got.shape == want.shape == (16000 * T // 44100,)
+        m = np.abs(want).max()
+        f32 = mod.reference(x, 44100, 16000, np.float32)
+        assert np.abs(got - want).max() / m < 5e-7
+        assert np.abs(got - want).max() <= 1.5 * np.abs(f32 - want).max() + 1e-9 * m
