@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("AT_LIB_PATH") or os.path.join(LIB_DIR, "libaudiotools_amd.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "firfft.hip", "irtools.hip", "specedit.hip", "fftconv.hip", "vocoder.hip", "stft_generic.hip", "longconv.hip"]
+SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "firfft.hip", "irtools.hip", "specedit.hip", "fftconv.hip", "vocoder.hip", "stft_generic.hip", "longconv.hip", "resample_f16.hip"]
 
 _lib = None
 _lock = threading.Lock()
@@ -117,6 +117,8 @@ SIGNATURES = {
     "at_mel_bands_host": (_i32, [_p, _i32, _i32, _p, _p]),
     "at_stft_mel_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
+    "at_stft_mel_floor_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
+                                     _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
     "at_istft_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
     "at_istft_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i64, _i64, _p, _p, _i64, _p]),
     "at_istft_edit_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i64, _i64, _p, _p, _i64,
@@ -142,6 +144,8 @@ SIGNATURES = {
     "at_resample_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "at_resample_mfma_supported": (_i32, [_i32, _i32]),
     "at_resample_mfma_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "at_resample_f16s_supported": (_i32, [_i32, _i32]),
+    "at_resample_f16s_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "at_fftconv_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "at_fftconv_circ_f32": (_i32, [_p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _p]),
     "at_longconv_supported": (_i32, [_i64]),
@@ -184,13 +188,18 @@ def lib():
     return _lib
 
 
+class NativeUnsupported(NativeError):
+    """AT_ERR_UNSUPPORTED: a valid request this entry point has no kernel for (callers that own another native route to the
+    same result may catch it; everything else treats it as the NativeError it is)."""
+
+
 def check(code: int, what: str):
     if code == 0:
         return
     if code == -1:
         raise NativeError(f"{what}: invalid argument")
     if code == -2:
-        raise NativeError(f"{what}: unsupported configuration")
+        raise NativeUnsupported(f"{what}: unsupported configuration")
     raise NativeError(f"{what}: HIP error {-(code) - 1000}")
 
 

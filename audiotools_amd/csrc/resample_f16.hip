@@ -1,0 +1,341 @@
+// Polyphase resampler on the fp16 matrix cores with float32-class accuracy (round 4).
+//
+// Replaces julius.resample_frac (audiotools/core/audio_signal.py:732) for odd gcd-reduced source rates, like
+// resample_mfma_ws_kernel (fir.hip), which it supersedes on the hot ratio 441 -> 160: that kernel sits on the fp32
+// matrix-pipe floor (v_mfma_f32_16x16x4_f32 = the fp32 VECTOR rate; 0.60 ms of pipe time per cfg5 share, 57 % busy).
+// Here every sample and every tap is split into an fp16 high and low half,
+//     x s = xh + xl,   w sw = wh + wl      (s: a power of two per tile, sw: a power of two per bank)
+// and the banded GEMM  Y[frame, phase] = sum_tap X[frame, tap] W[tap, phase]  is evaluated as the three products
+// xh wh + (xh wl + xl wh) with v_mfma_f32_16x16x32_f16 (16x the fp32 MFMA rate; every fp16 x fp16 product is exact in
+// the fp32 accumulator, the dropped xl wl term is 2^-22 relative).  Matrix time falls 5.3x; what remains is the stream
+// of samples through HBM and LDS.
+//
+// Numbers (tools/emulate_resample_f16s.py is a lane-level numpy model of exactly this kernel, tests/test_host_logic.py
+// runs it against float64): 2-3e-7 of the row maximum on loud, quiet (1e-4), unclipped (|x| = 5) and 100 dB-dynamic
+// inputs, where the fp32 formulation has 4-7e-7.  The per-tile power-of-two scale brings max|x| of the tile into
+// [2^14, 2^15): without it a quiet passage loses its low halves to fp16 subnormals.
+//
+// Structure: persistent workgroups of NPB waves (one per block of 16 output phases, its weight window resident in
+// 8 NC registers), each walking a CONTIGUOUS run of 16-frame tiles (the ~8 % halo a tile shares with its
+// predecessor comes from this CU's L1 / the XCD's L2).  All waves are alike; two LDS buffers of one dword per sample:
+//     LDS-DMA of tile t+1 (raw float32, this lane's NLD float4 pieces, 16-byte aligned source) into the other buffer ->
+//     compute tile t from this buffer (per 32-tap chunk: 8 dwords per lane, 8 v_perm_b32, 3 MFMAs) ->
+//     wait for the own pieces, tile maximum (wave reduction, one LDS slot per wave), barrier, scale + split each own
+//     float4 IN PLACE into (hi | lo << 16) dwords, barrier -> store tile t.
+// The staged tile never occupies registers while another one is being computed (register staging pushed the kernel
+// past 96 registers, i.e. below the two workgroups per CU that overlap each other's phases).  The LDS image has the
+// footprint, traffic and bank mapping of the fp32 kernel (K-slot permutation {0, 16, 8, 24}: lane (frame i,
+// k-group g) reads dwords i old + off_g + 0..7, conflict-free for odd `old`) and needs no alignment handling (a dword
+// is both halves of one sample).
+#include "at_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f4a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+struct ResF16Args {
+  const float* x;        // (rows, T)
+  const u32x4* W;        // (NPB, NC, 2, 64) x 4 dwords: tables.resample_f16_bank  (h = 0: high halves, h = 1: low halves)
+  const int* lo;         // (NPB): first tap of the phase block's window
+  float* out;            // (rows, out_len)
+  int64_t T, out_len, rows, n_tiles;
+  int old_sr, new_sr, width, NPB;
+  int tiles_per_row, tiles_per_wg;
+  int need;              // samples a tile touches: 15 old + max_lo + 32 NC
+  float inv_wscale;      // 1 / sw
+};
+
+constexpr int F16S_MAXSLOTS = 16;     // one float per wave for the tile maximum (NPB <= 16)
+
+// (hi | lo << 16) of e = x s:  hi = RN16(e), lo = RN16(e - hi)  (the difference is exact in fp32)
+__device__ __forceinline__ unsigned split_pack(float e) {
+  const _Float16 h = (_Float16)e;
+  const float r = e - (float)h;
+  const _Float16 l = (_Float16)r;
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+
+// maximum of a wave's NON-NEGATIVE values, in an SGPR: DPP steps (lanes without a source see 0, the identity here) --
+// the xor-shuffle form costs six lane-index registers that stay live across the whole tile loop
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+#define AT_DPP_MAX(CTRL, ROWS, BOUND) \
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, BOUND)))
+  AT_DPP_MAX(0xB1, 0xf, true);     // quad_perm [1,0,3,2]
+  AT_DPP_MAX(0x4E, 0xf, true);     // quad_perm [2,3,0,1]
+  AT_DPP_MAX(0x141, 0xf, true);    // row_half_mirror
+  AT_DPP_MAX(0x140, 0xf, true);    // row_mirror
+  AT_DPP_MAX(0x142, 0xa, false);   // row_bcast15 -> rows 1, 3
+  AT_DPP_MAX(0x143, 0xc, false);   // row_bcast31 -> rows 2, 3
+#undef AT_DPP_MAX
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int NC, int NLD>
+__global__ __launch_bounds__(1024, 5) void resample_f16s_kernel(const ResF16Args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+  float* __restrict__ maxslot = reinterpret_cast<float*>(lds);
+  unsigned* __restrict__ pl = lds + F16S_MAXSLOTS;              // one dword per staged sample
+  const int t = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int koff = (g & 1) * 16 + (g >> 1) * 8;                 // {0, 16, 8, 24}
+  const int old = A.old_sr;
+
+  const int64_t tile_id = (int64_t)blockIdx.x * A.tiles_per_wg;
+  const int64_t tiles_left = A.n_tiles - tile_id;
+  const int n_mine = tiles_left < A.tiles_per_wg ? (int)tiles_left : A.tiles_per_wg;
+  if (n_mine <= 0) return;
+
+  // weights of this wave's phase block: registers for the whole launch
+  u32x4 wh[NC], wl[NC];
+  {
+    const u32x4* __restrict__ wp = A.W + (int64_t)wave * NC * 128 + lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { wh[c] = wp[c * 128]; wl[c] = wp[c * 128 + 64]; }
+  }
+  const int a_base = j * old + A.lo[wave] + koff;
+  if (t >= A.NPB && t < F16S_MAXSLOTS) maxslot[t] = 0.f;       // slots of absent waves stay 0
+
+  int64_t row = tile_id / A.tiles_per_row;
+  int tile = (int)(tile_id - row * A.tiles_per_row);
+
+  // ---- stage: HBM -> LDS (DMA, issued a tile ahead), then in place: float32 -> scaled fp16 pairs ----
+  // dword d of a buffer holds sample a0 + d of the row (replicate-padded), a0 = gx - shift with gx = 16 tile old - width
+  // the first sample the tile needs and shift in 0..3 making the source 16-byte aligned.  The prefetch is ONE
+  // unconditional sequence of NLD aligned 16-byte pieces per lane (float4 index clamped into the row): a tile that
+  // reaches over either end of its row (the first and the last one or two of a row) is re-read element by element
+  // with replicate padding when it is staged -- exposed latency on ~1 % of the tiles -- so the loop body has a static
+  // order of memory operations.
+  struct Geom { const float* xr; int64_t a0; int n4; int shift; bool edge; };
+  auto geom = [&](int64_t r, int tl) __attribute__((always_inline)) -> Geom {
+    Geom G;
+    G.xr = A.x + r * A.T;
+    const int64_t gx = (int64_t)tl * 16 * old - A.width;
+    const int64_t word = (int64_t)(reinterpret_cast<uintptr_t>(G.xr) >> 2) + gx;
+    G.shift = (int)(word & 3);
+    G.a0 = gx - G.shift;
+    G.n4 = (A.need + G.shift + 3) >> 2;
+    G.edge = !(G.a0 >= 0 && G.a0 + 4 * (int64_t)G.n4 <= A.T);
+    return G;
+  };
+  const int buf_dwords = 4 * NLD * nthreads;
+  auto issue_dma = [&](const Geom& G, unsigned* __restrict__ buf) __attribute__((always_inline)) {
+    // float4 indices fully inside the row: [q_lo, q_hi]  (T >= 16 guarantees one); 32-bit offsets from a uniform base
+    int64_t q_lo64 = G.a0 >= 0 ? 0 : (-G.a0 + 3) >> 2;
+    int64_t q_hi64 = ((A.T - G.a0) >> 2) - 1;
+    if (q_hi64 > G.n4 - 1) q_hi64 = G.n4 - 1;
+    if (q_lo64 > q_hi64) q_lo64 = q_hi64;
+    const int q_lo = (int)q_lo64, q_hi = (int)q_hi64;
+    const char* __restrict__ src = reinterpret_cast<const char*>(G.xr + G.a0);
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      int q = t + l * nthreads;
+      q = q < q_lo ? q_lo : (q > q_hi ? q_hi : q);
+      // LDS destination: wave-uniform base + 16 lane = float4 index t + l nthreads of the buffer
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)q << 4)),
+                                       (__attribute__((address_space(3))) void*)(buf + 4 * (64 * wave + l * nthreads)), 16, 0, 0);
+    }
+  };
+  // returns 1 / s of the staged tile.  Two sweeps over the lane's own pieces (maximum, then conversion) instead of
+  // holding them across the barrier: at most one float4 is live next to the 8 NC weight registers.
+  auto stage = [&](const Geom& G, unsigned* __restrict__ buf) __attribute__((always_inline)) -> float {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // LDS-DMA is ordered by the issuing wave's vmcnt only;
+    f32x4* __restrict__ raw = reinterpret_cast<f32x4*>(buf);    // a lane reads back exactly the pieces its wave requested
+    if (G.edge) {
+      // replicate padding: dword d of the image is sample clamp(a0 + d, 0, T - 1), as 32-bit offsets from xr + a0
+      const int64_t d_lo64 = G.a0 < 0 ? -G.a0 : 0, d_hi64 = A.T - 1 - G.a0;
+      const int d_lo = (int)d_lo64, d_hi = d_hi64 > 0x3fffffff ? 0x3fffffff : (int)d_hi64;
+      const char* __restrict__ src = reinterpret_cast<const char*>(G.xr + G.a0);
+#pragma unroll 1
+      for (int l = 0; l < NLD; ++l) {
+        int q = t + l * nthreads;
+        q = q < G.n4 ? q : G.n4 - 1;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int d = 4 * q + e;
+          d = d < d_lo ? d_lo : (d > d_hi ? d_hi : d);
+          v[e] = *reinterpret_cast<const float*>(src + ((unsigned)d << 2));
+        }
+        raw[t + l * nthreads] = v;
+      }
+    }
+    // maximum over the FINITE samples (as integers: |x| bits below the infinity pattern): an inf / NaN sample poisons the
+    // outputs whose window holds it, as in the float32 kernels, not the scale of the 16 frames around it
+    unsigned mi = 0u;
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      const u32x4 v = reinterpret_cast<const u32x4*>(raw)[t + l * nthreads];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned a = v[e] & 0x7fffffffu;
+        mi = a < 0x7f800000u ? (a > mi ? a : mi) : mi;
+      }
+    }
+    float m = __builtin_bit_cast(float, mi);
+    m = wave_max_nonneg(m);
+    if (lane == 0) maxslot[wave] = m;
+    __syncthreads();
+    const f32x4* __restrict__ ms = reinterpret_cast<const f32x4*>(maxslot);
+    f32x4 mm = ms[0];
+#pragma unroll
+    for (int q = 1; q < F16S_MAXSLOTS / 4; ++q) {
+      const f32x4 u = ms[q];
+      mm.x = fmaxf(mm.x, u.x); mm.y = fmaxf(mm.y, u.y); mm.z = fmaxf(mm.z, u.z); mm.w = fmaxf(mm.w, u.w);
+    }
+    const float tm = fmaxf(fmaxf(mm.x, mm.y), fmaxf(mm.z, mm.w));
+    // s = 2^(141 - E) brings the maximum into [2^14, 2^15); exponent fields clamped so that s and 1 / s are normal
+    int field = 268 - (int)(__builtin_bit_cast(unsigned, tm) >> 23);
+    field = field < 1 ? 1 : (field > 253 ? 253 : field);
+    const float s = __builtin_bit_cast(float, (unsigned)field << 23);
+    const float inv = __builtin_bit_cast(float, (unsigned)(254 - field) << 23);
+    u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(buf);
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      const f32x4 x = raw[t + l * nthreads];
+      u32x4 v;
+      v.x = split_pack(x.x * s); v.y = split_pack(x.y * s);
+      v.z = split_pack(x.z * s); v.w = split_pack(x.w * s);
+      dst[t + l * nthreads] = v;
+    }
+    __syncthreads();                                            // (also: the maxima have been read by everybody)
+    return inv;
+  };
+
+  int cur = 0;
+  Geom G = geom(row, tile);
+  issue_dma(G, pl);
+  float inv = stage(G, pl);
+  int shift = G.shift;
+
+  for (int k = 0; k < n_mine; ++k) {
+    const int64_t row_c = row;
+    const int tile_c = tile;
+    // the next tile of the run; the last iteration stages its own tile once more (nobody reads it)
+    if (k + 1 < n_mine && ++tile == A.tiles_per_row) { tile = 0; ++row; }
+    G = geom(row, tile);
+    unsigned* __restrict__ nbuf = pl + (cur ^ 1) * buf_dwords;
+    issue_dma(G, nbuf);           // every wave has left the previous tile's operands (second barrier of its stage)
+    // ---- compute: 16 frames x 16 phases, NC chunks of 32 taps ----
+    f32x4 acc_m = {0.f, 0.f, 0.f, 0.f}, acc_c = {0.f, 0.f, 0.f, 0.f};
+    const unsigned* __restrict__ ap = pl + cur * buf_dwords + shift + a_base;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      unsigned d[8];
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) d[s2] = ap[32 * c + s2];
+      u32x4 xh, xl;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xh[q] = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x05040100u);   // low halves:  (d0 & 0xffff) | (d1 << 16)
+        xl[q] = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x07060302u);   // high halves: (d0 >> 16) | (d1 & 0xffff0000)
+      }
+      const f16x8 ah = __builtin_bit_cast(f16x8, xh), al = __builtin_bit_cast(f16x8, xl);
+      const f16x8 bh = __builtin_bit_cast(f16x8, wh[c]), bl = __builtin_bit_cast(f16x8, wl[c]);
+      acc_m = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc_m, 0, 0, 0);
+      acc_c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_c, 0, 0, 0);
+      acc_c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc_c, 0, 0, 0);
+      // one chunk's operands at a time: with two in flight the allocator spills weight registers, and a scratch
+      // reload is a VMEM operation -- its wait would drain the tile prefetch in mid-tile
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float scale_out = inv * A.inv_wscale;
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = (acc_m[r] + acc_c[r]) * scale_out;
+    inv = stage(G, nbuf);
+    shift = G.shift;
+    cur ^= 1;
+    // ---- store: D lane (j, g) holds frames 4 g + r of phase 16 wave + j ----
+    // (32-bit offsets from the tile's first output: uniform base + per-lane offset)
+    const int64_t tile_o = (int64_t)tile_c * 16 * A.new_sr;
+    float* __restrict__ otile = A.out + row_c * A.out_len + tile_o;
+    const int64_t left64 = A.out_len - tile_o;
+    const int left = left64 > 0x40000000 ? 0x40000000 : (int)left64;      // outputs of this row from the tile's first on
+    const int ph = 16 * wave + j;
+    if (ph < A.new_sr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = (4 * g + r) * A.new_sr + ph;
+        if (o < left) otile[(unsigned)o] = y[r];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// The fp16-split kernel needs conflict-free operand reads (odd reduced source rate, as at_resample_mfma_f32) and is
+// built for ratios with enough output phases to fill whole waves: 64 <= new <= 256.
+int at_resample_f16s_supported(int old_sr, int new_sr) {
+  return (old_sr > 0 && new_sr >= 64 && new_sr <= 256 && (old_sr & 1)) ? 1 : 0;
+}
+
+// x (rows, T) -> out (rows, out_len), out_len = floor(new T / old) for the REDUCED ratio old : new.
+// W (NPB, NC, 2, 64, 4) uint32 and lo (NPB): tables.resample_f16_bank; max_lo = max(lo); w_scale_log2: the bank holds
+// w * 2^w_scale_log2 split into fp16 halves.  Same result as at_resample_mfma_f32 / at_resample_f32 up to float32
+// round-off (the arithmetic is fp16 x fp16 products accumulated in fp32: see the file header).
+int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W, const int* lo, int old_sr, int new_sr,
+                         int width, int NPB, int NC, int max_lo, int w_scale_log2, float* out, int64_t out_len, void* stream) {
+  if (rows == 0) return AT_OK;
+  if (!x || !W || !lo || !out || rows < 0 || T <= 0 || old_sr <= 0 || new_sr <= 0 || width <= 0 || NPB <= 0 || NC <= 0 ||
+      max_lo < 0 || out_len < 0 || 16 * NPB < new_sr || w_scale_log2 < -100 || w_scale_log2 > 100)
+    return AT_ERR_INVALID;
+  if (!at_resample_f16s_supported(old_sr, new_sr) || NPB > F16S_MAXSLOTS || NC > 6) return AT_ERR_UNSUPPORTED;
+  if (out_len == 0) return AT_OK;
+  ResF16Args A;
+  A.x = x; A.W = reinterpret_cast<const u32x4*>(W); A.lo = lo; A.out = out; A.T = T; A.out_len = out_len; A.rows = rows;
+  A.old_sr = old_sr; A.new_sr = new_sr; A.width = width; A.NPB = NPB;
+  const int64_t frames = (out_len + new_sr - 1) / new_sr;
+  A.tiles_per_row = (int)((frames + 15) / 16);
+  A.n_tiles = rows * A.tiles_per_row;
+  A.need = 15 * old_sr + max_lo + 32 * NC;
+  A.inv_wscale = ldexpf(1.0f, -w_scale_log2);
+  const int threads = NPB * 64;
+  const int n4 = (A.need + 3 + 3) / 4;                       // worst shift
+  const int NLD = (n4 + threads - 1) / threads;
+  if (NLD > 4) return AT_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)F16S_MAXSLOTS * 4 + 2 * (size_t)NLD * threads * 16;     // two tile buffers
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 2048 / threads) per_cu = 2048 / threads;
+  static const int per_cu_env = at::env_int_once("AT_RESAMPLE_F16_WGS", 2);
+  if (per_cu > per_cu_env) per_cu = per_cu_env;
+  if (per_cu < 1) per_cu = 1;
+  int64_t blocks = (int64_t)at::device_cu_count() * per_cu;
+  if (blocks > A.n_tiles) blocks = A.n_tiles;
+  A.tiles_per_wg = (int)((A.n_tiles + blocks - 1) / blocks);
+  blocks = (A.n_tiles + A.tiles_per_wg - 1) / A.tiles_per_wg;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define AT_F16S_LAUNCH(NCV, NLDV)                                                                              \
+  {                                                                                                            \
+    int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_f16s_kernel<NCV, NLDV>));                 \
+    if (e != AT_OK) return e;                                                                                  \
+    hipLaunchKernelGGL((resample_f16s_kernel<NCV, NLDV>), dim3((unsigned)blocks), dim3(threads), lds, st, A);  \
+  }
+#define AT_F16S_NLD(NCV)                                                                                       \
+  case NCV:                                                                                                    \
+    switch (NLD) {                                                                                             \
+      case 1: AT_F16S_LAUNCH(NCV, 1) break;                                                                    \
+      case 2: AT_F16S_LAUNCH(NCV, 2) break;                                                                    \
+      case 3: AT_F16S_LAUNCH(NCV, 3) break;                                                                    \
+      default: AT_F16S_LAUNCH(NCV, 4) break;                                                                   \
+    }                                                                                                          \
+    break;
+  switch (NC) {
+    AT_F16S_NLD(1) AT_F16S_NLD(2) AT_F16S_NLD(3) AT_F16S_NLD(4) AT_F16S_NLD(5) AT_F16S_NLD(6)
+    default: return AT_ERR_UNSUPPORTED;
+  }
+#undef AT_F16S_NLD
+#undef AT_F16S_LAUNCH
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+}  // extern "C"

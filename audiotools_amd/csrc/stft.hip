@@ -505,10 +505,15 @@ __device__ __forceinline__ float2 ld2(const float2* p) {
 //   loop head, profiles/r03_notes.md).  With VAR & 1 the Nyquist bin is stored by all lanes (same
 //   address, lane 0's value) and the band sums are gathered in the wave's LDS slab and stored by two
 //   unconditional, coalesced instructions: every store is counted, the loop head waits for the loads only.
+// VAR bit 1: FLOOR.  The measurement twin of the kernel (at_stft_mel_floor_f32, round 4): the same persistent grid, runs,
+//   XCD spans, row pitch, load / store instructions, counts, order and cache policy -- and no transform: a frame's stores
+//   carry its sample registers.  Its duration on a box is what this traffic pattern costs there with zero compute;
+//   bench.py prints it next to the kernel's (roofline.floor_ms).  Output contents are meaningless.
 template <int NR /* mel rounds of 64 units; 0 = no mel */, int POL = 0, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   constexpr bool MEL = NR > 0;
   constexpr bool STATIC_STORES = (VAR & 1) != 0;
+  constexpr bool FLOOR = (VAR & 2) != 0;
   constexpr int MELOUT_OFF = 1312;   // floats: band sums of the frame, behind the 65 x 20 magnitude rows of the slab
   constexpr bool PRIO = (POL & 8) != 0;
   constexpr int M = 1024, L = 64, N = 2048, NW = 4, SH = 4;
@@ -627,6 +632,32 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
 #pragma unroll
       for (int i = 0; i < SH; ++i) raw[(12 + i + 4 * P) & 15] = nxt[i];
     }
+    if constexpr (FLOOR) {
+      const int64_t s0n = s0 + A.hop;
+      const bool have_nxt = want_next && fo + 1 < gpr && s0n >= 0 && s0n + N <= Ti;
+      {
+        const float2* __restrict__ p2 = reinterpret_cast<const float2*>(xr + (have_nxt ? s0n : 0)) + t + L * (16 - SH);
+#pragma unroll
+        for (int i = 0; i < SH; ++i) nxt[i] = ld2<POL>(p2 + L * i);
+      }
+      float2* __restrict__ orow = A.out + ((int64_t)row * n_out + fo) * (M + 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int k0 = 256 * m + t;
+        st2<POL>(orow + k0, raw[(m + 4 * P) & 15]);
+        st2<POL>(orow + k0 + 64, raw[(4 + m + 4 * P) & 15]);
+        st2<POL>(orow + k0 + 128, raw[(8 + m + 4 * P) & 15]);
+        st2<POL>(orow + k0 + 192, raw[(12 + m + 4 * P) & 15]);
+      }
+      const float nyq0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, raw[(4 * P) & 15].x), 0));
+      st2<POL>(orow + M, make_float2(nyq0, 0.f));
+      if constexpr (MEL) {
+        float* mrow = A.mel + ((int64_t)row * n_out + fo) * A.n_mels;
+        at::stg<(POL & 2) != 0>(mrow + gb0, raw[(1 + 4 * P) & 15].x);
+        at::stg<(POL & 2) != 0>(mrow + gb1, raw[(2 + 4 * P) & 15].y);
+      }
+      return have_nxt;
+    } else {
     float2 a[16];
     {
       const float4* wr = reinterpret_cast<const float4*>(s_winr + t * WROW);
@@ -816,6 +847,7 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       }
     }
     return have_nxt;
+    }   // !FLOOR
   };
 
   for (int64_t gbase = w0; gbase < g_hi; gbase += Wtot * RUN) {
@@ -1177,6 +1209,41 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
     case 1024: return launch_m<1024>(A, vec2, n_cu, s);
   }
   return AT_ERR_UNSUPPORTED;
+}
+
+
+// Measurement twin of at_stft_mel_f32 for the n_fft 2048 / hop 512 kernel (same arguments): launches
+// stft_mel_kernel_v2<..., FLOOR> -- identical grid, schedule, addresses, load / store instruction sequence and cache
+// policy, no transform, no mel arithmetic -- so that its duration is the zero-compute cost of the kernel's traffic on
+// THIS device (bench.py: roofline.floor_ms).  The outputs are overwritten with meaningless values.
+// AT_ERR_UNSUPPORTED for every shape the v2 kernel does not take (then there is no floor to print).
+int at_stft_mel_floor_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
+                          int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,
+                          float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,
+                          float* mel_out, void* stream) {
+  if (rows == 0) return AT_OK;
+  if (!x || !window || !twiddles || !stft_out || rows < 0 || T <= 0 || frame_lo != 0 || n_frames_out <= 0) return AT_ERR_INVALID;
+  const bool mel = mel_out != nullptr;
+  if (n_fft != 2048 || hop != 512 || pad != 0 || right_pad != 0 || T < 2 * 2048 || (T & 1) ||
+      (reinterpret_cast<uintptr_t>(x) % 8) != 0 || n_frames_out != 1 + T / hop ||
+      (mel && (n_units != 256 || n_mels <= 0 || n_mels > 128 || !mel_unit_info || !mel_unit_w)))
+    return AT_ERR_UNSUPPORTED;
+  if (T >= (1LL << 31) || n_frames_out >= (1LL << 31) / 1025) return AT_ERR_UNSUPPORTED;
+  StftArgs A;
+  A.x = x; A.window = window; A.tw = reinterpret_cast<const float2*>(twiddles);
+  A.out = reinterpret_cast<float2*>(stft_out); A.mel = mel_out;
+  A.unit_info = mel_unit_info; A.unit_w = mel_unit_w;
+  A.T = T; A.rows = rows; A.n_out = n_frames_out; A.frame_lo = 0; A.hop = hop; A.pad = 0;
+  A.T2 = T; A.pad_mode = pad_mode; A.n_units = mel ? n_units : 0; A.n_mels = n_mels;
+  A.groups_per_row = (int)n_frames_out;
+  A.total_groups = rows * A.groups_per_row;
+  A.flags = mel ? 1 : 0;
+  A.run_max = AT_STFT_RUN_V2;
+  int auto_x = device_cu_count() / 32;
+  A.n_xcd = auto_x < 1 ? 1 : (auto_x > 8 ? 8 : auto_x);
+  A.stagger = 0; A.debug = 0; A.reuse_shift = 4; A.run = 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return mel ? launch_v2<4, 1, 3>(A, device_cu_count(), s) : launch_v2<0, 0, 2>(A, device_cu_count(), s);
 }
 
 }  // extern "C"

@@ -131,10 +131,17 @@ def broadcast_cfg5_tables(old_sr, new_sr, n_fft, n_mels, device, window_type="ha
         W, lo = tables.resample_mfma_bank(int(old_sr), int(new_sr))[:2]
         return (W, lo)
 
+    def f16_bank():
+        import numpy as np
+        W, lo = tables.resample_f16_bank(int(old_sr), int(new_sr))[:2]
+        return (W.view(np.int32), lo)
+
     if old != new:
         # the bank of whichever kernel kernels.resample() dispatches to (odd reduced source rate:
-        # the MFMA form; otherwise the VALU form)
-        if old & 1:
+        # the matrix-core forms -- fp16-split for 64..256 output phases --; otherwise the VALU form)
+        if (old & 1) and 64 <= new <= 256:
+            broadcast_table(("resample_f16", old, new), f16_bank, device)
+        elif old & 1:
             broadcast_table(("resample_mfma", old, new), mfma_bank, device)
         else:
             broadcast_table(("resample_grouped", old, new), bank, device)

@@ -8,6 +8,8 @@ function here computes anything on the host beyond shapes.
 import math
 import os
 
+import numpy as np
+
 import torch
 
 from . import _native, tables
@@ -92,6 +94,29 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
     stft = stft_buf.transpose(2, 3) if stft_buf is not None else None
     mel_spec = mel_buf.transpose(2, 3) if mel_buf is not None else None
     return stft, mel_spec
+
+
+def stft_mel_floor(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, stft_buf: torch.Tensor, mel=None,
+                   mel_buf: torch.Tensor = None) -> bool:
+    """MEASUREMENT: one launch of the zero-compute twin of the n_fft 2048 / hop 512 kernel (at_stft_mel_floor_f32) into
+    caller-provided buffers of the shapes ``stft_mel`` allocates; False when that kernel does not take the shape."""
+    _require_native_ok(audio)
+    B, C, T = audio.shape
+    dev = audio.device
+    tw = tables.stft_twiddles(n_fft, dev)
+    info = w = None
+    n_units = n_mels = 0
+    if mel is not None:
+        info, w, n_mels = mel
+        n_units = int(info.shape[0])
+    code = _native.lib().at_stft_mel_floor_f32(
+        _native.ptr(audio), B * C, T, _native.ptr(window), _native.ptr(tw), n_fft, hop, 0, 0, PAD_MODES["reflect"], 0,
+        1 + T // hop, _native.ptr(stft_buf), _native.ptr(info), _native.ptr(w), n_units, n_mels, _native.ptr(mel_buf),
+        _native.current_stream(dev))
+    if code == -2:
+        return False
+    _native.check(code, "at_stft_mel_floor_f32")
+    return True
 
 
 _nola_cache = {}
@@ -687,6 +712,7 @@ def resample_supported(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float
 
 
 _RESAMPLE_MFMA = os.environ.get("AT_RESAMPLE_MFMA", "1") != "0"     # development A/B switch, read once
+_RESAMPLE_F16 = os.environ.get("AT_RESAMPLE_F16", "1") != "0"       # the fp16-split matrix-core form (round 4)
 
 
 def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
@@ -701,6 +727,14 @@ def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
     out_len = int(math.floor(new * T / old))
     out = torch.empty((B, C, out_len), dtype=torch.float32, device=dev)
     lib = _native.lib()
+    if _RESAMPLE_F16 and T >= 16 and lib.at_resample_f16s_supported(old, new):
+        W_np, lo_np, old, new, width, NPB, NC, wk = tables.resample_f16_bank(old, new)
+        W, lo = tables.device_table(("resample_f16", old, new), dev, lambda: (W_np.view(np.int32), lo_np))
+        code = lib.at_resample_f16s_f32(_native.ptr(audio), B * C, T, _native.ptr(W), _native.ptr(lo), old, new, width,
+                                        NPB, NC, int(lo_np.max()), wk, _native.ptr(out), out_len, _native.current_stream(dev))
+        if code != -2:            # AT_ERR_UNSUPPORTED (a tile that does not fit): the f32 kernels below
+            _native.check(code, "at_resample_f16s_f32")
+            return out
     if _RESAMPLE_MFMA and lib.at_resample_mfma_supported(old, new):
         W_np, lo_np, old, new, width, NPB, NC = tables.resample_mfma_bank(old, new)
         need = (32 * old + int(lo_np.max()) + 32 * NC + 32 + 4) * 4       # one 32-frame tile of LDS

@@ -13,7 +13,7 @@ import math
 import numpy as np
 import torch
 
-from . import kernels, tables
+from . import _native, kernels, tables
 
 STFTParams = collections.namedtuple(
     "STFTParams", ["window_length", "hop_length", "window_type", "match_stride", "padding_type"])
@@ -242,21 +242,32 @@ class SpectralMixin:
         units = None
         if kernels.stft_fused_supported(n_fft) and audio.is_cuda:
             units = tables.mel_units_or_none(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, audio.device)
+        banded = False
         if (units is None and kernels.is_native(audio) and not kernels.stft_fused_supported(n_fft)
                 and kernels.stft_native_supported(n_fft) and n_fft <= 8192):
             # generic sizes (4096 @ 96 kHz, 8192 @ 192 kHz, 400 / 1200 / 1920 ...): banded mel fused into the
             # mixed-radix kernel -- no second pass over stft_data, no dense matmul
             units = tables.mel_bands(self.sample_rate, n_fft, n_mels, mel_fmin, mel_fmax, audio.device)
+            banded = True
         if kernels.is_native(audio) and units is not None:
             dev = audio.device
             info, w = units
             window = self.get_window(wtype, n_fft, str(dev))
             right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
-            X, mel = kernels.stft_mel(audio, window, n_fft, hop, pad=pad, right_pad=right_pad,
-                                      padding_type=padding_type, match_stride=match_stride,
-                                      mel=(info, w, n_mels))
-            self.stft_data = X
-            return mel
+            try:
+                X, mel = kernels.stft_mel(audio, window, n_fft, hop, pad=pad, right_pad=right_pad,
+                                          padding_type=padding_type, match_stride=match_stride,
+                                          mel=(info, w, n_mels))
+                self.stft_data = X
+                return mel
+            except _native.NativeUnsupported:
+                # the TILED generic kernel is the only one with a fused mel stage; inputs it does not take (a clip
+                # shorter than its tile: T < n_fft + (frames per tile - 1) hop, fewer frames than a tile holds, chunk
+                # tables past 160 KB of LDS for very many bands at 8192) keep the route they had before the fusion:
+                # native stft() + the dense basis on the native spectrum, below
+                if not banded:
+                    raise
+                units = None
         if units is not None and _native_autograd_ok(audio, n_fft, hop, match_stride) and not kwargs.get("padding_type"):
             dev = audio.device
             units = tuple(units) + (n_mels,)

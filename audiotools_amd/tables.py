@@ -203,7 +203,7 @@ def device_table(key, device, builder):
     return hit
 
 
-_EVICTABLE = ("resample_mfma", "resample_grouped")
+_EVICTABLE = ("resample_mfma", "resample_grouped", "resample_f16")
 _EVICT_KEEP = 16
 
 
@@ -526,3 +526,31 @@ def resample_mfma_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float
                     vals = np.where(np.abs(vals) > thr, vals, 0.0)
                     W[P, c, h, :, e] = vals
     return W, lo, old, new, width, NPB, NC
+
+
+@functools.lru_cache(32)
+def resample_f16_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
+    """Bank layout of ``at_resample_f16s_f32`` (csrc/resample_f16.hip: the polyphase sum on
+    v_mfma_f32_16x16x32_f16 with every tap split into an fp16 high and low half).  Phase blocks and windows
+    as :func:`resample_mfma_bank`; the taps are scaled by ``2 ** wscale_log2`` (max |w| lands in [2^13, 2^14):
+    the low halves of the significant taps stay normal fp16 numbers) and stored as the B operands the kernel
+    consumes, eight fp16 per lane and chunk:
+        half s of W[P, c, h, lane, :]  =  (hi if h == 0 else lo)(2^k bank[16 P + lane % 16, lo[P] + 32 c + s + MFMA_KOFF[lane // 16]])
+    with hi = RN16(v), lo = RN16(v - hi) and half s in bits 16 (s % 2) .. of dword s // 2.
+    Returns ``(W uint32 (NPB, NC, 2, 64, 4), lo int32 (NPB,), old, new, width, NPB, NC, wscale_log2)`` or None."""
+    plan = resample_mfma_bank(old_sr, new_sr, zeros, rolloff)
+    if plan is None:
+        return None
+    W32, lo, old, new, width, NPB, NC = plan
+    # resample_mfma_bank holds slot s of a chunk at [h = s // 4, e = s % 4]: (NPB, NC, 2, 64, 4) -> (NPB, NC, 64, 8)
+    taps = np.ascontiguousarray(np.transpose(W32, (0, 1, 3, 2, 4))).reshape(NPB, NC, 64, 8)
+    wmax = float(np.abs(taps).max())
+    k = 13 - int(math.floor(math.log2(wmax)))
+    v = (taps * np.float32(2.0 ** k)).astype(np.float32)
+    hi = v.astype(np.float16)
+    lw = (v - hi.astype(np.float32)).astype(np.float16)
+    out = np.zeros((NPB, NC, 2, 64, 4), dtype=np.uint32)
+    for h, plane in enumerate((hi, lw)):
+        u = plane.view(np.uint16).astype(np.uint32)          # (NPB, NC, 64, 8)
+        out[:, :, h] = u[..., 0::2] | (u[..., 1::2] << 16)
+    return out, lo, old, new, width, NPB, NC, k

@@ -21,6 +21,7 @@ the ``AudioLoader.__call__`` signature; :class:`TensorLoader` serves items from 
 (device-resident, broadcastable) bank.
 """
 import copy
+import threading
 from contextlib import contextmanager
 from inspect import signature
 from typing import List
@@ -66,8 +67,9 @@ def _assemble(values: list):
         return torch.stack(values)
     if isinstance(v0, dict):
         return {k: _assemble([v[k] for v in values]) for k in v0}
-    if isinstance(v0, (list, tuple)):
+    if isinstance(v0, (list, tuple)) and len(v0) and isinstance(v0[0], (AudioSignal, dict)):
         return [_assemble(list(col)) for col in zip(*values)]
+    # (a list / tuple of plain values is ONE parameter: instantiate() makes it torch.tensor(list) -> (n,), collated (B, n))
     probe = torch.tensor(v0)
     try:
         arr = np.ascontiguousarray(np.asarray(values))
@@ -77,25 +79,43 @@ def _assemble(values: list):
     return out.to(probe.dtype).reshape((len(values),) + tuple(probe.shape))
 
 
-_STATE_POOL = []
+_POOL = threading.local()
 
 
-def _pooled_states(states):
-    """One ``RandomState`` per item.  Integer seeds re-seed POOLED generator objects: ``RandomState(seed)`` costs
-    ~220 us of object construction, ``pooled.seed(seed)`` 2 us for the identical stream.  The pooled objects never
-    leave ``batch_instantiate`` (states handed in by the caller are used as they are)."""
-    out, used = [], 0
-    for s in states:
-        if isinstance(s, (int, np.integer)) and not isinstance(s, bool):
-            if used == len(_STATE_POOL):
-                _STATE_POOL.append(np.random.RandomState(0))
-            st = _STATE_POOL[used]
-            used += 1
-            st.seed(int(s))
-            out.append(st)
-        else:
-            out.append(util.random_state(s))
-    return out
+class _pooled_states:
+    """``with _pooled_states(states) as rs``: one ``RandomState`` per item.  Integer seeds re-seed POOLED generator objects:
+    ``RandomState(seed)`` costs ~220 us of object construction, ``pooled.seed(seed)`` 2 us for the identical stream.  The
+    pool is per thread and handed out by depth: a ``batch_instantiate`` entered while another one is still drawing (a
+    custom ``_instantiate`` or loader that batches something itself) takes the objects BEHIND the ones in use instead of
+    re-seeding them.  The pooled objects never leave ``batch_instantiate`` (states handed in by the caller are used as
+    they are)."""
+
+    def __init__(self, states):
+        self.states = states
+
+    def __enter__(self):
+        pool = getattr(_POOL, "pool", None)
+        if pool is None:
+            pool, _POOL.used = [], 0
+            _POOL.pool = pool
+        self.base = used = _POOL.used
+        out = []
+        for s in self.states:
+            if isinstance(s, (int, np.integer)) and not isinstance(s, bool):
+                if used == len(pool):
+                    pool.append(np.random.RandomState(0))
+                st = pool[used]
+                used += 1
+                st.seed(int(s))
+                out.append(st)
+            else:
+                out.append(util.random_state(s))
+        _POOL.used = used
+        return out
+
+    def __exit__(self, *exc):
+        _POOL.used = self.base
+        return False
 
 
 def _draw(dist: tuple, state):
@@ -209,11 +229,42 @@ class BaseTransform:
         item's ``RandomState`` sees the same draws in the same order -- but built parameter-major: the scalar draws
         stay per item (numpy), every parameter becomes ONE tensor (:func:`_assemble`), and transforms that own a
         loader fetch their B excerpts with one ``loader.batch`` call (no per-item tensor, no per-item launch)."""
-        rs = _pooled_states(states)
-        if len({id(st) for st in rs}) < len(rs):
-            # items sharing one RandomState (or the global one): only the item-major order reproduces the draws
-            return util.collate([self.instantiate(st, signal) for st in rs])
-        return {self.name: self._batch_params(rs, signal)}
+        with _pooled_states(states) as rs:
+            if len({id(st) for st in rs}) < len(rs):
+                # items sharing one RandomState (or the global one): only the item-major order reproduces the draws
+                return util.collate([self.instantiate(st, signal) for st in rs])
+            return {self.name: self._params_for(rs, signal)}
+
+    def _route(self) -> str:
+        """Which construction describes THIS object.  A specialised ``_draw_items`` / ``_batch_params`` restates the
+        ``_instantiate`` of the class that defines it, so it is stale as soon as a subclass overrides ``_instantiate``
+        below it: "generic" then (BaseTransform's own parameter-major path, which calls ``self._instantiate``).  An
+        overridden public ``instantiate`` can do anything: "collate" (B ``instantiate`` calls, the reference's own
+        batch_instantiate, transforms.py:228-265)."""
+        cls = type(self)
+        if cls.instantiate is not BaseTransform.instantiate:
+            return "collate"
+        mro = cls.__mro__
+        first = lambda name: next(i for i, c in enumerate(mro) if name in c.__dict__)
+        i_inst = first("_instantiate")
+        for name in ("_draw_items", "_batch_params"):
+            i_fast = first(name)
+            if mro[i_fast] is not BaseTransform and i_fast > i_inst:
+                return "generic"
+        return "fast"
+
+    def _params_for(self, states: list, signal: AudioSignal = None):
+        """This transform's parameter dict for B distinct states (also what Compose / Choose ask their children for:
+        child-major order gives every item's state the same draws as the item-major loop)."""
+        route = self._route()
+        if route == "fast":
+            return self._batch_params(states, signal)
+        if route == "generic":
+            items = BaseTransform._draw_items(self, states, signal)
+            params = {k: _assemble([d[k] for d in items]) for k in items[0]}
+            params["mask"] = _assemble([st.rand() <= self.prob for st in states])
+            return params
+        return util.collate([self.instantiate(st, signal) for st in states])[self.name]
 
     def _draw_items(self, states: list, signal: AudioSignal = None):
         """B raw parameter dicts (python / numpy values, tensors, AudioSignals), one ``_instantiate`` per state."""
@@ -290,7 +341,7 @@ class Compose(BaseTransform):
 
     def _batch_params(self, states: list, signal: AudioSignal = None):
         # child-major: every item's state still sees child 0, child 1, ... in order
-        params = {t.name: t._batch_params(states, signal) for t in self.transforms}
+        params = {t.name: t._params_for(states, signal) for t in self.transforms}
         params["mask"] = _assemble([st.rand() <= self.prob for st in states])
         return params
 
@@ -324,7 +375,7 @@ class Choose(Compose):
         return kwargs
 
     def _batch_params(self, states: list, signal: AudioSignal = None):
-        params = {t.name: t._batch_params(states, signal) for t in self.transforms}
+        params = {t.name: t._params_for(states, signal) for t in self.transforms}
         n = len(self.transforms)
         picks = np.asarray([st.choice(list(range(n)), p=self.weights) for st in states])
         one_hot = []
@@ -505,8 +556,6 @@ class Equalizer(BaseTransform):
         return {"eq": -util.sample_from_dist(self.eq_amount, state) * state.rand(self.n_bands)}
 
     def _draw_items(self, states, signal=None):
-        if type(self)._instantiate is not Equalizer._instantiate:
-            return super()._draw_items(states, signal)
         return [{"eq": -_draw(self.eq_amount, st) * st.rand(self.n_bands)} for st in states]
 
     def _transform(self, signal, eq):

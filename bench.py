@@ -138,27 +138,68 @@ def cpu_baseline_cfg(config, kw_cpu, n_items):
             "host_cpus": ncpu, "sample": f"{n_items} items of {config}, median of 3 passes ({med:.2f} s), oracle/restate.py"}
 
 
-def committed_traffic(config, n_local):
+def committed_traffic(config, n_local, kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS
-    configuration (profiles/r02_*_pmc_summary.json; FETCH_SIZE and WRITE_SIZE in separate passes,
+    configuration and shape (profiles/r0N_<tag>_pmc_summary.json; FETCH_SIZE and WRITE_SIZE in separate passes,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this
-    exact shape is committed -- it is a recorded measurement, not one made by this run."""
-    if config != "north_star" or n_local != 512:
-        return None, None
-    for name in ("r03_bench_pmc_summary.json", "r02_bench_pmc_summary.json"):
+    exact shape is committed -- it is a recorded measurement, not one made by this run.  Also returns the per-kernel
+    table {kernel: bytes per launch} of the same passes (every kernel of the configuration, not only the dominant one)."""
+    tag = {"north_star": "bench", "cfg4": "cfg4", "cfg5": "cfg5"}[config]
+    want_items = CONFIGS[config]["batch"]
+    if n_local != want_items:
+        return None, None, None
+    for rnd in ("r04", "r03", "r02"):
+        name = f"{rnd}_{tag}_pmc_summary.json"
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
         try:
             d = json.load(open(path))
-            f = [v["FETCH_SIZE"] for k, v in d["pmc_fetch"].items() if "stft_mel_kernel" in k][0]
-            w = [v["WRITE_SIZE"] for k, v in d["pmc_write"].items() if "stft_mel_kernel" in k][0]
+            per_kernel = {}
+            for k, v in d["pmc_fetch"].items():
+                w = d["pmc_write"].get(k, {}).get("WRITE_SIZE")
+                if w is not None and "FETCH_SIZE" in v:
+                    per_kernel[k] = (2.0 * v["FETCH_SIZE"] + w) * 1024.0
+            dom = [v for k, v in per_kernel.items() if kernel_substr in k]
+            if not dom:
+                continue
             box = d.get("box", "another MI355X of the pool (not this run's box)")
-            return (2.0 * f + w) * 1024.0, (f"profiles/{name}: rocprofv3 --pmc of the same command, recorded on {box}; "
-                                            f"a committed measurement replayed here, NOT taken by this run")
+            return dom[0], (f"profiles/{name}: rocprofv3 --pmc of the same command, recorded on {box}; "
+                            f"a committed measurement replayed here, NOT taken by this run"), per_kernel
         except Exception:
             continue
-    return None, None
+    return None, None, None
+
+
+# ----------------------------------------------------------------------------- parity of the benchmarked outputs
+def rel_rows(got, ref):
+    """max over (item, channel) rows of max|got - ref| / max|ref| (the per-row measure of tests/test_gpu_parity.py)."""
+    got, ref = got.double().reshape(-1, got.shape[-2] * got.shape[-1] if got.dim() > 3 else got.shape[-1]), \
+        ref.double().reshape(-1, ref.shape[-2] * ref.shape[-1] if ref.dim() > 3 else ref.shape[-1])
+    den = ref.abs().amax(-1).clamp_min(1e-30)
+    return float(((got - ref).abs().amax(-1) / den).max())
+
+
+def parity_items(n_local):
+    return sorted({0, n_local // 2 + (1 if n_local > 2 else 0), n_local - 1})[:3]
+
+
+def parity_north_star(x, sr, mel, stft, lufs):
+    """The benchmarked launch itself (all n_local items in one launch) against the oracle on three of its items:
+    north_star tolerance 1e-4 relative (per row) for stft / mel, 0.1 LU for loudness."""
+    from oracle import restate
+    idx = parity_items(x.shape[0])
+    xc = x[idx].cpu()
+    X = restate.stft(xc, 2048, 512, "hann")
+    ref_mel = restate.mel_spectrogram(X, sr, N_MELS)
+    ref_lufs = restate.loudness(xc, sr)
+    got_stft = torch.view_as_real(stft[idx].cpu())
+    out = {"items": idx, "stft_rel": rel_rows(got_stft.flatten(-2), torch.view_as_real(X).flatten(-2)),
+           "mel_rel": rel_rows(mel[idx].cpu(), ref_mel),
+           "lufs_abs": float((lufs[idx].cpu().double() - ref_lufs.double()).abs().max()),
+           "tol": {"stft_rel": 1e-4, "mel_rel": 1e-4, "lufs_abs": 0.1}, "oracle": "oracle/restate.py on the host"}
+    out["ok"] = bool(out["stft_rel"] < 1e-4 and out["mel_rel"] < 1e-4 and out["lufs_abs"] < 0.1)
+    return out
 
 
 # ----------------------------------------------------------------------------- launching
@@ -357,7 +398,31 @@ def main():
                      "note": "one rank's share of an 8-way batch shard, timed on this device; the data path has no "
                              "collective, so 8 ranks are predicted to finish in this time (+ barrier skew)"}
         achieved = stft_bytes / (stft_ms * 1e-3) / 1e9
-        traffic, traffic_src = committed_traffic(args.config, n_local)
+        traffic, traffic_src, _ = committed_traffic(args.config, n_local, "stft_mel_kernel")
+        parity = parity_north_star(x, sr, mel, sig.stft_data, lufs)
+        # the zero-compute floor of the dominant kernel's traffic on THIS box: its measurement twin (same grid, schedule,
+        # addresses, load / store instructions and cache policy, no transform: at_stft_mel_floor_f32), timed the same way
+        floor_ms = None
+        try:
+            from audiotools_amd import kernels as K, tables as TB
+            win = TB.window("hann", n_fft, device)
+            units = TB.mel_units(sr, n_fft, N_MELS, 0.0, None, device)
+            fl_stft = torch.empty((n_local, ch, n_frames, F), dtype=torch.complex64, device=device)
+            fl_mel = torch.empty((n_local, ch, n_frames, N_MELS), dtype=torch.float32, device=device)
+            if K.stft_mel_floor(x, win, n_fft, hop, fl_stft, (units[0], units[1], N_MELS), fl_mel):
+                for _ in range(3):
+                    K.stft_mel_floor(x, win, n_fft, hop, fl_stft, (units[0], units[1], N_MELS), fl_mel)
+                fe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                fe[0].record()
+                for _ in range(args.steps):
+                    K.stft_mel_floor(x, win, n_fft, hop, fl_stft, (units[0], units[1], N_MELS), fl_mel)
+                fe[1].record()
+                torch.cuda.synchronize()
+                floor_ms = fe[0].elapsed_time(fe[1]) / args.steps
+            del fl_stft, fl_mel
+        except Exception as e:  # pragma: no cover - the floor is evidence, never a reason to lose the line
+            floor_ms = None
+            out["floor_error"] = f"{type(e).__name__}: {e}"
         # what a plain device copy reaches on THIS box (torch.Tensor.copy_, read + write counted),
         # measured the same way: the practical ceiling next to the 8 TB/s spec
         cp_src, cp_dst = x.view(-1), torch.empty_like(x).view(-1)
@@ -378,7 +443,13 @@ def main():
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": stft_bytes, "avg_launch_ms": stft_ms,
-                           "device_copy_GBps": copy_gbs, "frac_of_device_copy": achieved / copy_gbs}
+                           "device_copy_GBps": copy_gbs, "frac_of_device_copy": achieved / copy_gbs,
+                           "floor_ms": floor_ms, "frac_of_floor": (floor_ms / stft_ms) if floor_ms else None,
+                           "floor_frac_of_peak": (stft_bytes / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if floor_ms else None,
+                           "floor_note": "floor_ms = the same launch with the transform removed (stft_mel_kernel_v2<.., FLOOR>: "
+                                         "identical grid, runs, addresses, load/store instructions, nt policy), K launches, HIP events: "
+                                         "what this read:write mix costs on this box with zero compute"}
+        out["parity_check"] = parity
         out["kernels_ms"] = {"stft_mel": stft_ms, "lufs_total": lufs_ms, "lufs_GBps": lufs_bytes / (lufs_ms * 1e-3) / 1e9,
                              "timing": timing_note}
         if share is not None:
@@ -423,6 +494,19 @@ def main():
         assert torch.isfinite(res["y"]).all()
         chain_bytes = 3 * 2 * rows * T * 4 + rows * 2 * sr * 4
         achieved = chain_bytes / (elapsed / args.steps) / 1e9
+        # parity of the benchmarked launch: the oracle's chain on three of its items (those whose impulse responses
+        # were kept on the host), per-row relative error, tolerance 1e-4
+        from oracle import restate
+        idx = [i for i in (0, 3, n_cpu - 1) if i < n_local]
+        k4 = kw_cpu["Compose"]
+        r4 = k4["2.RoomImpulseResponse"]
+        yo = restate.low_pass(x[idx].cpu(), k4["0.LowPass"]["cutoff"][idx], sr)
+        yo = restate.equalizer(yo, sr, k4["1.Equalizer"]["eq"][idx])
+        yo = restate.apply_ir(yo, r4["ir_signal"].audio_data[idx], sr, r4["drr"][idx], r4["eq"][idx])
+        c4 = rel_rows(res["y"][idx].cpu(), yo)
+        out["parity_check"] = {"items": idx, "chain_rel": c4, "tol": {"chain_rel": 1e-4}, "ok": bool(c4 < 1e-4),
+                               "oracle": "oracle/restate.py low_pass -> equalizer -> apply_ir on the host"}
+        traffic, traffic_src, per_kernel = committed_traffic(args.config, n_local, "rowconv_kernel")
         out["config"] = {"workload": f"cfg4: batch={batch} mono 5s@48kHz Compose(LowPass, Equalizer(6), "
                                      f"RoomImpulseResponse(2 s RIR, DRR, EQ))", "global_batch": batch,
                          "items_per_gpu": n_local, "parallelism": f"batch-shard x{world} + RCCL broadcast of the IR bank / tables",
@@ -431,7 +515,10 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "whole chain (fir_fft x3, alter_drr, absmax, roll_pad, four-step FFT convolution: colfft x3 + rowconv)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": None, "algorithmic_bytes_per_launch": chain_bytes,
-                           "avg_launch_ms": 1e3 * elapsed / args.steps}
+                           "avg_launch_ms": 1e3 * elapsed / args.steps,
+                           "traffic_per_kernel_launch": per_kernel, "traffic_source": traffic_src,
+                           "traffic_note": "roofline.traffic stays null for the CHAIN (17 launches of 9 kernels per step); "
+                                           "traffic_per_kernel_launch holds the committed FETCH x 2 + WRITE bytes of every kernel of it"}
 
     else:  # cfg5
         adist.broadcast_cfg5_tables(sr, 16000, 2048, N_MELS, device)
@@ -442,6 +529,7 @@ def main():
             if ev is not None:
                 ev[0].record()
             s.resample(16000)
+            res["y"] = s.audio_data
             if ev is not None:
                 ev[1].record()
             res["mel"] = s.mel_spectrogram(N_MELS)
@@ -458,15 +546,27 @@ def main():
         rs_bytes = rows * T * 4 + rows * T2 * 4
         mel_bytes = rows * T2 * 4 + rows * n_frames * 1025 * 8 + rows * n_frames * N_MELS * 4
         achieved = rs_bytes / (rs_ms * 1e-3) / 1e9
+        from oracle import restate
+        idx = sorted({0, n_local - 1})
+        yo = restate.resample(x[idx].cpu(), sr, 16000)
+        mo = restate.mel_spectrogram(restate.stft(yo, 2048, 512), 16000, N_MELS)
+        e_rs, e_mel = rel_rows(res["y"][idx].cpu(), yo), rel_rows(res["mel"][idx].cpu(), mo)
+        out["parity_check"] = {"items": idx, "resample_rel": e_rs, "mel_rel": e_mel, "tol": {"resample_rel": 1e-4, "mel_rel": 1e-4},
+                               "ok": bool(e_rs < 1e-4 and e_mel < 1e-4), "oracle": "oracle/restate.py resample -> stft -> mel on the host"}
         out["config"] = {"workload": f"cfg5: batch={batch} 2ch 30s@44.1kHz resample(16000) + mel_spectrogram(80) "
                                      f"[STFT 2048/512 as the signal keeps its stft_params]", "global_batch": batch,
                          "items_per_gpu": n_local, "parallelism": f"batch-shard x{world} + RCCL broadcast of the resample bank / tables",
                          "inputs": "device-resident (H2D excluded)"}
-        rs_kernel = ("resample_mfma_ws_kernel (banded-GEMM polyphase 441->160 on v_mfma_f32_16x16x4_f32)"
-                     if _native.lib().at_resample_mfma_supported(441, 160) and os.environ.get("AT_RESAMPLE_MFMA", "1") != "0"
-                     else "resample_kernel (sparse polyphase 441->160)")
+        if os.environ.get("AT_RESAMPLE_F16", "1") != "0" and _native.lib().at_resample_f16s_supported(441, 160):
+            rs_kernel, rs_sub = "resample_f16s_kernel (banded-GEMM polyphase 441->160, fp16-split products on v_mfma_f32_16x16x32_f16)", "resample_f16s_kernel"
+        elif _native.lib().at_resample_mfma_supported(441, 160) and os.environ.get("AT_RESAMPLE_MFMA", "1") != "0":
+            rs_kernel, rs_sub = "resample_mfma_ws_kernel (banded-GEMM polyphase 441->160 on v_mfma_f32_16x16x4_f32)", "resample_mfma_ws_kernel"
+        else:
+            rs_kernel, rs_sub = "resample_kernel (sparse polyphase 441->160)", "resample_kernel"
+        traffic, traffic_src, per_kernel = committed_traffic(args.config, n_local, rs_sub)
         out["roofline"] = {"bound": "hbm", "kernel": rs_kernel, "achieved": achieved,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": traffic_src, "traffic_per_kernel_launch": per_kernel,
                            "algorithmic_bytes_per_launch": rs_bytes, "avg_launch_ms": rs_ms}
         out["kernels_ms"] = {"resample": rs_ms, "stft_mel": mel_ms, "stft_mel_GBps": mel_bytes / (mel_ms * 1e-3) / 1e9}
 
@@ -486,6 +586,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+    if rank == 0 and not out.get("parity_check", {"ok": True})["ok"]:
+        sys.exit("bench.py: the benchmarked outputs differ from the oracle beyond the tolerance (parity_check above)")
 
 
 if __name__ == "__main__":

@@ -84,6 +84,19 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
                     float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,
                     float* mel_out, void* stream);
 
+/* MEASUREMENT entry, not a replacement of a reference call: the zero-compute twin of at_stft_mel_f32 for the n_fft 2048 /
+ * hop 512 kernel (the default transform of audio_signal.py:1066-1070 at 44.1 / 48 kHz) -- the same persistent grid, runs,
+ * XCD spans, 8200-byte row pitch, load / store instruction sequence and cache policy, no transform and no mel arithmetic.
+ * Its duration is what the kernel's HBM traffic costs on THIS device with nothing to compute; bench.py prints it as
+ * roofline.floor_ms next to the kernel's own duration.  Same arguments; the outputs are overwritten with meaningless
+ * values.  AT_ERR_UNSUPPORTED for shapes that kernel does not take (pad / right_pad / frame_lo != 0, other sizes, odd T,
+ * n_units != 256).
+ */
+int at_stft_mel_floor_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
+                          int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,
+                          float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,
+                          float* mel_out, void* stream);
+
 /* ---- inverse STFT --------------------------------------------------------------------------
  * Replaces  audiotools/core/audio_signal.py:1278-1290  (F.pad of the two edge frames when
  *           match_stride) + torch.istft(X, n_fft, hop, window, length, center=True).
@@ -288,6 +301,18 @@ int at_resample_f32(const float* x, int64_t rows, int64_t T, const float* wg, co
 int at_resample_mfma_supported(int old_sr, int new_sr);
 int at_resample_mfma_f32(const float* x, int64_t rows, int64_t T, const float* W, const int* lo, int old_sr, int new_sr,
                          int width, int NPB, int NC, int max_lo, float* out, int64_t out_len, void* stream);
+
+/* The same sum on the fp16 matrix cores with float32-class accuracy (csrc/resample_f16.hip, round 4): samples (scaled
+ * per 16-frame tile by a power of two) and taps (scaled per bank by 2^w_scale_log2) are split into fp16 high + low
+ * halves and the three products hh + (hl + lh) are accumulated in fp32 by v_mfma_f32_16x16x32_f16 -- 16x the rate of
+ * the f32 MFMA the entry point above is bound by.  2-4e-7 of the row maximum against float64 (the f32 kernels: 4-7e-7).
+ * Odd reduced `old_sr`, 64 <= new_sr <= 256, T >= 16: at_resample_f16s_supported() tells; callers fall back to
+ * at_resample_mfma_f32 / at_resample_f32 otherwise (AT_ERR_UNSUPPORTED).
+ * W (NPB, NC, 2, 64, 4) uint32, lo (NPB), w_scale_log2: tables.resample_f16_bank; max_lo = max(lo).
+ */
+int at_resample_f16s_supported(int old_sr, int new_sr);
+int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W, const int* lo, int old_sr, int new_sr,
+                         int width, int NPB, int NC, int max_lo, int w_scale_log2, float* out, int64_t out_len, void* stream);
 
 /* ---- circular FFT convolution -----------------------------------------------------------
  * Replaces  audiotools/core/effects.py:102-121  (rfft x 3, irfft x 2 at length T, rescale).

@@ -3,6 +3,7 @@
 
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden            # the round-1 fixtures
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden --round3   # edits_r03.npz, ir_mix_loader_r03.npz only
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden --round4   # transforms_r04.npz only
 
 Inputs are stored next to the outputs (float16-exact values are not assumed), so the
 fixtures do not depend on torch's RNG staying stable.  Every array is produced by calling
@@ -171,8 +172,38 @@ def round3():
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 
+R4_TRANSFORMS = ["ClippingDistortion", "Equalizer", "Quantization", "MuLawQuantization", "NoiseFloor", "VolumeChange", "VolumeNorm",
+                 "Silence", "LowPass", "HighPass", "RescaleAudio", "ShiftPhase", "InvertPhase", "FrequencyMask", "TimeMask",
+                 "MaskLowMagnitudes", "Smoothing", "Identity", "SpectralDenoising"]
+R4_STATES = [3, 4, 5, 6]
+
+
+def round4():
+    """Fixtures added in round 4 (the transform GPU tests compared the HIP path with the package's
+    own CPU path, two hops from the reference): every loader-free transform of data/transforms.py, instantiated by the
+    UNMODIFIED reference for states 3..6 with prob = 0.5 and applied by it on CPU.  tests/test_golden_r04.py replays the
+    same states through the package (CPU path here, HIP path under -m gpu) and compares with these outputs."""
+    at = import_reference()
+    AudioSignal = at.AudioSignal
+    T = at.data.transforms
+    sr = 44100
+    x = synth.audio_batch(len(R4_STATES), 1, 9000, seed=401, gaps=False, sample_rate=sr)
+    out = {"x": x.numpy(), "states": np.asarray(R4_STATES), "sample_rate": np.asarray(sr)}
+    for name in R4_TRANSFORMS:
+        t = getattr(T, name)(prob=0.5) if name != "Identity" else T.Identity()
+        sig = AudioSignal(x.clone(), sr)
+        kw = t.batch_instantiate(R4_STATES, sig)
+        torch.manual_seed(7)         # (transforms that draw from torch's global generator inside transform())
+        y = t(sig.clone(), **kw)
+        out[name] = y.audio_data.numpy()
+    np.savez_compressed(os.path.join(OUT, "transforms_r04.npz"), **out)
+    print("transforms_r04.npz", os.path.getsize(os.path.join(OUT, "transforms_r04.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    if "--round3" in sys.argv:
+    if "--round4" in sys.argv:
+        round4()
+    elif "--round3" in sys.argv:
         round3()
     else:
         main()

@@ -131,7 +131,7 @@ def test_mel_vs_oracle(sr, n_fft, n_mels):
     assert mel.shape == ref.shape
     assert rel_err(mel, ref) < REL
     assert rel_err(s.stft_data, X) < REL      # mel_spectrogram() also refreshes stft_data
-    assert rel_err(s.mfcc(n_mels=n_mels), restate.mfcc(ref)) < 1e-3
+    assert rel_err(s.mfcc(n_mels=n_mels), restate.mfcc(ref)) < REL
 
 
 @pytest.mark.parametrize("win,n_mels", [(32, 5), (64, 10), (128, 20), (256, 40), (512, 80), (1024, 160), (2048, 320), (2048, 5), (512, 5)])
@@ -148,12 +148,26 @@ def test_mel_loss_grid(win, n_mels):
     assert rel_err(torch.view_as_real(s.stft_data), torch.view_as_real(X_ref)) < REL
 
 
+def test_mel_generic_size_short_clip_falls_back_to_dense_basis():
+    """mel_spectrogram on generic transform sizes (4096 @ 96 kHz ...) goes to the banded mel stage of the TILED
+    kernel; a clip that kernel does not take (shorter than its two-frame tile: T < n_fft + hop) must keep working through
+    native stft() + the dense basis, not raise."""
+    sr, n_fft, hop = 96000, 4096, 1024
+    for T in (3000, 4096 + 512, 4096 + 1024 + 8, 20000):
+        x = synth.audio_batch(2, 1, T, seed=T, gaps=False, sample_rate=sr)
+        s = A.AudioSignal(x.clone(), sr).to("cuda")
+        mel = s.mel_spectrogram(80)
+        X = restate.stft(x, n_fft, hop)
+        assert rel_err(mel, restate.mel_spectrogram(X, sr, 80)) < REL, T
+        assert rel_err(s.stft_data, X) < REL, T
+
+
 def test_mel_golden_cfg2():
     d = np.load(os.path.join(G, "mel_cfg2.npz"))
     s = A.AudioSignal(torch.from_numpy(d["x"]), 44100).to("cuda")
     assert rel_err(s.mel_spectrogram(80), torch.from_numpy(d["mel"])) < REL
     assert rel_err(s.stft_data, torch.from_numpy(d["stft"])) < REL
-    assert rel_err(A.AudioSignal(torch.from_numpy(d["x"]), 44100).to("cuda").mfcc(), torch.from_numpy(d["mfcc"])) < 1e-3
+    assert rel_err(A.AudioSignal(torch.from_numpy(d["x"]), 44100).to("cuda").mfcc(), torch.from_numpy(d["mfcc"])) < REL
 
 
 def test_mel_options():
@@ -805,6 +819,33 @@ def test_cfg2_full_size_stft_mel():
     assert torch.equal(mel3, mel)
 
 
+def test_north_star_full_size():
+    """BASELINE.json `metric` at its own size, as ONE launch each: batch 512 x 2ch x 10 s @44.1 kHz mel_spectrogram(80)
+    [fused STFT 2048/512 + mel] + loudness() -- the persistent grid's schedule (runs per wave, XCD spans) depends on the row
+    count, so the B = 256 test above does not cover the benchmarked launch.  Oracle on items {0, 37, 255, 511}, per row."""
+    B, C, T = 512, 2, 441000
+    x = _device_batch(B, C, T, 41)
+    for i in range(0, B, 20):
+        x[i, :, 3 * 44100: 5 * 44100] = 0          # bench.py's 5 % of items with 2 s of digital silence
+    s = A.AudioSignal(x, 44100)
+    mel = s.mel_spectrogram(80)
+    l = s.loudness()
+    assert mel.shape == (B, C, 80, 862) and s.stft_data.shape == (B, C, 1025, 862) and l.shape == (B,)
+    assert torch.isfinite(mel).all() and torch.isfinite(l).all()
+    idx = [0, 37, 255, 511]
+    xs = x[idx].cpu()
+    Xr = restate.stft(xs, 2048, 512)
+    assert rel_err(s.stft_data[idx], Xr) < REL
+    assert rel_err(mel[idx], restate.mel_spectrogram(Xr, 44100, 80)) < REL
+    assert float((l[idx].cpu() - restate.loudness(xs, 44100)).abs().max()) < LU
+    # every frame of every row: the same launch twice is bit-equal, and the 256-item launch agrees on its items
+    mel2 = A.AudioSignal(x, 44100).mel_spectrogram(80)
+    assert torch.equal(mel2, mel)
+    half = A.AudioSignal(x[:256], 44100)
+    assert rel_err(half.mel_spectrogram(80), mel[:256].cpu()) < 1e-6          # (another schedule of the same frames)
+    assert float((half.loudness() - l[:256]).abs().max()) < 1e-4
+
+
 def test_cfg3_full_size_loudness():
     """configs[2]: batch 512 x 2ch x 10s @44.1k LUFS.  Oracle on a subset, gain property on all,
     permutation invariance (items are independent), silence clamp."""
@@ -1046,9 +1087,11 @@ def _permute_kwargs(kw, perm):
     return out
 
 
-@pytest.mark.parametrize("B", [256])
+@pytest.mark.parametrize("B", [256, 2048])
 def test_cfg5_full_size_resample_mel(B):
-    """configs[4], one GPU's share: 256 x 2ch x 30 s @44.1 kHz -> resample(16000) ->
+    """configs[4]: one GPU's share of an 8-way shard (256 items) and the WHOLE configuration on one GPU (2048 items: what
+    `bench.py --config cfg5` runs; 21.7 GB of input, the resampler's runs of tiles then span several rows per workgroup):
+    B x 2ch x 30 s @44.1 kHz -> resample(16000) ->
     mel_spectrogram(80) with the literal (2048, 512) parameters the signal keeps after resample.
     Oracle on a subset of rows, linearity / determinism / finiteness on all of them."""
     C, T = 2, 1323000
@@ -1059,7 +1102,7 @@ def test_cfg5_full_size_resample_mel(B):
     assert y.shape == (B, C, 480000) and s.sample_rate == 16000 and s.stft_params.window_length == 2048
     mel = s.mel_spectrogram(80)
     assert mel.shape == (B, C, 80, 938) and torch.isfinite(mel).all() and torch.isfinite(y).all()
-    idx = [0, 100, 255]
+    idx = [0, 100, B - 1]
     yr = restate.resample(x[idx].cpu(), 44100, 16000)
     assert rel_err(y[idx], yr) < REL
     Xr = restate.stft(yr, 2048, 512)
@@ -1105,6 +1148,71 @@ def test_resample_mfma_and_valu_kernels_agree(old, new, T):
     assert rc == 0 and rel_err(y2, ref) < REL
     assert rel_err(y1, y2.cpu()) < 1e-5
     assert lib.at_resample_mfma_supported(160, 147) == 0      # even reduced source rate: VALU kernel only
+
+
+@pytest.mark.parametrize("old,new,T,off", [(441, 160, 50000, 0), (441, 160, 50001, 1), (147, 160, 20011, 2), (441, 160, 300, 3),
+                                            (441, 160, 16, 0), (147, 80, 30000, 1), (441, 160, 7056 * 3 + 70, 0)])
+def test_resample_f16_split_kernel_raw_abi(old, new, T, off):
+    """at_resample_f16s_f32 (fp16-split matrix-core form, csrc/resample_f16.hip) through the raw C ABI against the oracle and
+    against the float32 matrix-core kernel: several tiles per row and per workgroup, a partial last frame, rows shorter than
+    one tile, T = 16, rows whose base address is 4 / 8 / 12 bytes off a 16-byte boundary (the DMA alignment shift), an output
+    buffer pre-filled with NaN (every sample written), and a float64 yardstick: no worse than the float32 kernel."""
+    import math
+    from audiotools_amd import tables
+    lib = _native.lib()
+    assert lib.at_resample_f16s_supported(old, new) == 1
+    x = synth.audio_batch(3, 2, T, seed=old + new + T, gaps=False, sample_rate=old)
+    big = torch.zeros(6 * T + 8, device="cuda")
+    xd = big[off: off + 6 * T].view(3, 2, T)
+    xd.copy_(x)
+    assert xd.data_ptr() % 16 == 4 * off
+    out_len = int(math.floor(new * T / old))
+    st = _native.current_stream(xd.device)
+    ref = restate.resample(x, old, new)
+    ref64 = restate.resample(x.double(), old, new)
+    W, lo, o_, n_, width, NPB, NC, wk = tables.resample_f16_bank(old, new)
+    Wd, lod = torch.from_numpy(W.view(np.int32)).cuda(), torch.from_numpy(lo).cuda()
+    y1 = torch.full((3, 2, out_len), float("nan"), device="cuda")
+    rc = lib.at_resample_f16s_f32(_native.ptr(xd), 6, T, _native.ptr(Wd), _native.ptr(lod), old, new, width, NPB, NC,
+                                  int(lo.max()), wk, _native.ptr(y1), out_len, st)
+    assert rc == 0 and torch.isfinite(y1).all() and rel_err(y1, ref) < REL
+    W2, lo2, o_, n_, width, NPB2, NC2 = tables.resample_mfma_bank(old, new)
+    W2d, lo2d = torch.from_numpy(W2).cuda(), torch.from_numpy(lo2).cuda()
+    y2 = torch.full((3, 2, out_len), float("nan"), device="cuda")
+    rc = lib.at_resample_mfma_f32(_native.ptr(xd), 6, T, _native.ptr(W2d), _native.ptr(lo2d), old, new, width, NPB2, NC2,
+                                  int(lo2.max()), _native.ptr(y2), out_len, st)
+    assert rc == 0 and rel_err(y1, y2.cpu()) < 1e-5
+    e16 = (y1.cpu().double() - ref64).abs().amax(-1) / ref64.abs().amax(-1)
+    e32 = (y2.cpu().double() - ref64).abs().amax(-1) / ref64.abs().amax(-1)
+    print(f"resample {old}->{new} T={T}: fp16-split {e16.max():.2e}, f32 MFMA {e32.max():.2e}")
+    assert (e16 <= 1.5 * e32 + 3e-7).all()
+    # unsupported shapes are refused, not mis-computed
+    assert lib.at_resample_f16s_supported(160, 147) == 0 and lib.at_resample_f16s_supported(3, 1) == 0
+    assert lib.at_resample_f16s_f32(_native.ptr(xd), 6, T, _native.ptr(Wd), _native.ptr(lod), 160, 147, width, NPB, NC,
+                                    int(lo.max()), wk, _native.ptr(y1), out_len, st) == -2
+
+
+def test_resample_f16_split_nonfinite_and_extreme_rows():
+    """Rows the per-tile scale has to cope with: all zeros, 1e-30 and 1e+30 amplitudes, one inf sample (poisons its own
+    windows, nothing else of its tile), through AudioSignal.resample (the dispatch picks the fp16-split kernel for 441:160)."""
+    T = 60000
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(5, 1, T, generator=g)
+    x[0] = 0
+    x[1] *= 1e-30
+    x[2] *= 1e30
+    x[3, 0, 20000] = float("inf")
+    x[4, 0, :30000] *= 1e-5
+    got = A.AudioSignal(x.clone(), 44100).to("cuda").resample(16000).audio_data.cpu()
+    ref = restate.resample(x.double(), 44100, 16000)
+    assert torch.equal(got[0], torch.zeros_like(got[0]))
+    for r in (1, 2, 4):
+        assert ((got[r].double() - ref[r]).abs().max() / ref[r].abs().max()) < 1e-6
+    quiet = slice(0, 16000 * 29000 // 44100)
+    assert ((got[4, 0, quiet].double() - ref[4, 0, quiet]).abs().max() / ref[4, 0, quiet].abs().max()) < 2e-6
+    clean = torch.isfinite(ref[3, 0])
+    assert torch.isfinite(got[3, 0][clean]).all() and not torch.isfinite(got[3, 0][16000 * 20000 // 44100])
+    assert ((got[3, 0][clean].double() - ref[3, 0][clean]).abs().max() / ref[3, 0][clean].abs().max()) < 1e-6
 
 
 @pytest.mark.parametrize("n_fft,hop,wt", [(4096, 1024, "hann"), (8192, 2048, "sqrt_hann"), (16384, 4096, "hann"), (400, 160, "hann"),

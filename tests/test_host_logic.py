@@ -379,22 +379,44 @@ def test_build_flags_per_source(monkeypatch):
 
 
 def test_fp16_split_resampler_model_matches_the_oracle():
-    """tools/emulate_resample_f16.py models the resampler planned in DESIGN.md section 10 (fp16 high / low planes with a
-    per-tile power-of-two scale, operands through aligned dwords + v_alignbit, hh + hl + lh products in fp32): same framing and
-    length as julius.resample_frac, and closer to float64 than the fp32 formulation on loud, quiet and unclipped inputs."""
+    """tools/emulate_resample_f16s.py is a lane-level model of resample_f16s_kernel (csrc/resample_f16.hip: tile geometry and
+    the 16-byte source alignment shift, clamped prefetch + element-wise re-read of the tiles that reach over an end of the row,
+    per-tile power-of-two scale from the exponent field, in-place (hi | lo << 16) split, operand dwords with the K-slot
+    permutation, B operands decoded from tables.resample_f16_bank, hh + (hl + lh) in fp32, the store mask).  It asserts its own
+    index algebra (every DMA inside the row and aligned, the LDS image equal to the replicate-padded row, every output written
+    once); here: same framing and length as julius.resample_frac for several ratios / lengths / row alignments, and closer to
+    float64 than the fp32 formulation on loud, quiet, unclipped and 100 dB-dynamic inputs."""
     import numpy as np
     import torch
 
-    mod = _load_tool("emulate_resample_f16")
-    pl = mod.plan(44100, 16000)
-    assert (pl["NPB"], pl["NS"]) == (10, 12)
+    mod = _load_tool("emulate_resample_f16s")
     rng = np.random.default_rng(3)
-    for T, amp in [(5000, 0.1), (4410 + 17, 1e-4), (7000, 2.0)]:
-        x = (amp * rng.standard_normal(T)).astype(np.float32)
-        want = julius_leaf.resample_frac(torch.from_numpy(x)[None, None].double(), 44100, 16000)[0, 0].numpy()
-        got = mod.resample(x, 44100, 16000, pl)
-        assert got.shape == want.shape == (16000 * T // 44100,)
+    cases = [(44100, 16000, 5000, 0.1, 0, 2), (44100, 16000, 4410 + 17, 1e-4, 1, 1), (44100, 16000, 7000, 2.0, 3, 3),
+             (44100, 16000, 16, 0.5, 2, 1), (44100, 16000, 300, 0.5, 0, 2), (44100, 48000, 2000, 0.3, 1, 2),
+             (44100, 24000, 9000, 0.3, 2, 1)]
+    for old, new, T, amp, base_word, rows in cases:
+        x = (amp * rng.standard_normal((rows, T))).astype(np.float32)
+        want = julius_leaf.resample_frac(torch.from_numpy(x)[None].double(), old, new)[0].numpy()
+        got = mod.resample(x, old, new, base_word=base_word, n_wg=3)
+        assert got.shape == want.shape
         m = np.abs(want).max()
-        f32 = mod.reference(x, 44100, 16000, np.float32)
-        assert np.abs(got - want).max() / m < 5e-7
-        assert np.abs(got - want).max() <= 1.5 * np.abs(f32 - want).max() + 1e-9 * m
+        f32 = mod.reference(x, old, new, np.float32)
+        assert np.abs(got - want).max() / m < 5e-7, (old, new, T)
+        assert np.abs(got - want).max() <= 1.5 * np.abs(f32 - want).max() + 1e-9 * m, (old, new, T)
+    # a quiet passage next to a loud one inside ONE tile: the error of the quiet half is judged against the quiet level
+    T = 6000
+    x = np.concatenate([1e-4 * rng.standard_normal(T // 2), rng.standard_normal(T - T // 2)]).astype(np.float32)[None]
+    want = julius_leaf.resample_frac(torch.from_numpy(x)[None].double(), 44100, 16000)[0].numpy()
+    got = mod.resample(x, 44100, 16000)
+    quiet = slice(0, 16000 * (T // 2 - 200) // 44100)
+    assert np.abs(got[0, quiet] - want[0, quiet]).max() / np.abs(want[0, quiet]).max() < 2e-6
+    # a non-finite sample poisons the outputs whose window holds it -- not the scale of the 16 frames around it
+    x = (0.1 * rng.standard_normal((1, 9000))).astype(np.float32)
+    x[0, 3000] = np.inf
+    got = mod.resample(x, 44100, 16000)
+    want = julius_leaf.resample_frac(torch.from_numpy(x)[None].double(), 44100, 16000)[0].numpy()
+    clean = np.isfinite(want[0])          # (the reference multiplies the inf with all 581 taps of a frame: a superset)
+    assert (~clean).any() and np.isfinite(got[0][clean]).all() and (~np.isfinite(got[0])).any()
+    assert np.abs(got[0][clean] - want[0][clean]).max() < 5e-7 * np.abs(want[0][clean]).max()
+    centre = 16000 * 3000 // 44100
+    assert not np.isfinite(got[0][centre - 5: centre + 5]).any()

@@ -161,3 +161,87 @@ def test_batch_instantiate_equals_collated_instantiate():
     out_a = t(sig.clone(), **got).audio_data
     out_b = t(sig.clone(), **want).audio_data
     assert torch.equal(out_a, out_b)
+
+
+# ------------------------------------------------------------------ round 4: user overrides and the parameter-major path
+def _same_tree(a, b):
+    assert type(a) is type(b) or (torch.is_tensor(a) and torch.is_tensor(b)), (type(a), type(b))
+    if isinstance(a, dict):
+        assert a.keys() == b.keys()
+        for k in a:
+            _same_tree(a[k], b[k])
+    elif torch.is_tensor(a):
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), (a, b)
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            _same_tree(x, y)
+    else:
+        assert a == b
+
+
+def test_batch_instantiate_honours_user_overrides():
+    """batch_instantiate == collate(instantiate) also for subclasses that override _instantiate or the public instantiate
+    (the parameter-major fast paths restate the STOCK draws and must step aside), alone and as children of Compose /
+    Choose; list-valued parameters become one (B, n) tensor as tt(list) collates."""
+    from audiotools_amd import transforms as tfm
+
+    class Fixed(tfm.VolumeChange):
+        def _instantiate(self, state):
+            return {"db": -3.0}
+
+    class Public(tfm.VolumeChange):
+        def instantiate(self, state=None, signal=None):
+            out = super().instantiate(state, signal)
+            out[self.name]["db"] = out[self.name]["db"] * 0 - 7.0
+            return out
+
+    class Listy(tfm.BaseTransform):
+        def _instantiate(self, state):
+            return {"x": [state.rand(), 2.0 * state.rand()], "n": [1, 2, 3]}
+
+        def _transform(self, signal, x, n):
+            return signal
+
+    class NoisyEq(tfm.Equalizer):
+        def _instantiate(self, state):
+            return {"eq": -0.5 * state.rand(self.n_bands)}
+
+    sig = A.AudioSignal(torch.zeros(4, 1, 100), 16000)
+    seeds = [5, 6, 7, 8]
+    for make in (Fixed, Public, Listy, NoisyEq,
+                 lambda: tfm.Compose(Fixed(), tfm.LowPass(), Public(prob=0.5)),
+                 lambda: tfm.Choose(Listy(), Fixed(), NoisyEq()),
+                 lambda: tfm.Repeat(Fixed(), 2)):
+        t = make()
+        want = A.util.collate([t.instantiate(s, sig) for s in seeds])
+        got = t.batch_instantiate(seeds, sig)
+        _same_tree(got, want)
+    got = Fixed().batch_instantiate(seeds, sig)["Fixed"]["db"]
+    assert torch.equal(got, torch.full((4,), -3.0))
+    got = Listy().batch_instantiate(seeds, sig)["Listy"]
+    assert got["x"].shape == (4, 2) and got["x"].dtype == torch.float32 and got["n"].shape == (4, 3) and got["n"].dtype == torch.int64
+
+
+def test_nested_batch_instantiate_does_not_reseed_states_in_use():
+    """A batch_instantiate entered while another one is still drawing from its pooled RandomStates (here: from inside a
+    custom _instantiate) takes fresh generator objects -- the outer draws continue their own streams."""
+    from audiotools_amd import transforms as tfm
+
+    inner = tfm.VolumeChange()
+    sig = A.AudioSignal(torch.zeros(3, 1, 100), 16000)
+
+    class Outer(tfm.BaseTransform):
+        def _instantiate(self, state):
+            a = state.rand()
+            nested = inner.batch_instantiate([100, 101], sig)["VolumeChange"]["db"]
+            return {"a": a, "b": state.rand(), "nested": nested}
+
+        def _transform(self, signal, a, b, nested):
+            return signal
+
+    seeds = [1, 2, 3]
+    t = Outer()
+    want = A.util.collate([t.instantiate(s, sig) for s in seeds])
+    got = t.batch_instantiate(seeds, sig)
+    _same_tree(got, want)
