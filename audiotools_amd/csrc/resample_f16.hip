@@ -28,6 +28,7 @@
 // k-group g) reads dwords i old + off_g + 0..7, conflict-free for odd `old`) and needs no alignment handling (a dword
 // is both halves of one sample).
 #include "at_common.h"
+#include <utility>
 
 namespace {
 
@@ -47,6 +48,22 @@ struct ResF16Args {
   int need;              // samples a tile touches: 15 old + max_lo + 32 NC
   float inv_wscale;      // 1 / sw
 };
+
+// three consecutive floats through the scalar data cache (read-only data of this launch); waits for them itself
+__device__ __forceinline__ void sload3(const float* p, float& a, float& b, float& c) {
+  asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %3, 0x4\n\ts_load_dword %2, %3, 0x8\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b), "=&s"(c)
+               : "s"(p)
+               : "memory");
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 constexpr int F16S_MAXSLOTS = 16;     // one float per wave for the tile maximum (NPB <= 16)
 
@@ -268,6 +285,232 @@ __global__ __launch_bounds__(1024, 5) void resample_f16s_kernel(const ResF16Args
   }
 }
 
+
+// ---- the same arithmetic with a deep REGISTER prefetch ("rp") ------------------------------------------------------------------
+// resample_f16s_kernel above measured 0.975 ms per cfg5 share against the float32 MFMA kernel's 1.04 ms (session r04
+// s01): with the matrix time gone it is bound by memory-level parallelism.  Two workgroups per CU with one 30 KB tile
+// in flight each are ~45 KB per CU on average; an LDS-DMA stream needs ~128 KB per CU for 6.4 TB/s on this chip
+// (MI355X_MICROARCH.md, ldsdma-fill) -- 3.8 TB/s is what the bytes in flight buy.  A third workgroup does not fit
+// (LDS, and 96 registers per wave already).  This form trades the second workgroup for depth:
+//   * ONE workgroup per CU (NPB waves, <= 168 registers each): every lane keeps its share of the next D tiles in
+//     registers (D NLD float4: 60 registers at D = 5), i.e. D - 2 .. D - 1 tiles = 90 - 120 KB per CU are in flight at
+//     any time, as plain global loads in a static order (the compiler's counted s_waitcnt vmcnt leaves the younger tiles
+//     in flight: the stores are unconditional -- lanes without an output write a dump line -- so that they are counted);
+//   * the tile maximum is exchanged ONE TILE AHEAD: in the iteration that computes tile k a wave reduces its share of
+//     tile k + 2 (just landed) into maxslot[(k + 2) & 1] and converts its share of tile k + 1 with the maxima written one
+//     iteration earlier -- one workgroup barrier per tile instead of two, and no LDS round trip of the raw samples;
+//   * two plane buffers: tile k + 1 is written while other waves still read tile k.
+// Same numbers as the DMA form bit for bit (same scale, same split, same products in the same order).
+__device__ float g_f16s_dump[64];
+
+constexpr int F16S_RP_THREADS = 704;      // <= 11 waves: three waves per SIMD at most, i.e. a 168-register budget
+template <int NC, int NLD, int D>
+__global__ __launch_bounds__(F16S_RP_THREADS) void resample_f16s_rp_kernel(const ResF16Args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+  float* __restrict__ maxslot = reinterpret_cast<float*>(lds);          // [2][F16S_MAXSLOTS]
+  unsigned* __restrict__ pl = lds + 2 * F16S_MAXSLOTS;                  // [2][4 NLD nthreads]
+  const int t = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int koff = (g & 1) * 16 + (g >> 1) * 8;
+  const int old = A.old_sr;
+  const int buf_dwords = 4 * NLD * nthreads;
+
+  const int64_t tile_id0 = (int64_t)blockIdx.x * A.tiles_per_wg;
+  const int64_t tiles_left = A.n_tiles - tile_id0;
+  const int n_mine = tiles_left < A.tiles_per_wg ? (int)tiles_left : A.tiles_per_wg;
+  if (n_mine <= 0) return;
+
+  u32x4 wh[NC], wl[NC];
+  {
+    const u32x4* __restrict__ wp = A.W + (int64_t)wave * NC * 128 + lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { wh[c] = wp[c * 128]; wl[c] = wp[c * 128 + 64]; }
+  }
+  const int a_base = j * old + A.lo[wave] + koff;
+  if (t < 2 * F16S_MAXSLOTS) maxslot[t] = 0.f;                  // (slots of absent waves stay 0)
+  __syncthreads();
+
+  struct Geom { const float* xr; int64_t a0; int n4; int shift; bool edge; };
+  auto geom = [&](int64_t r, int tl) __attribute__((always_inline)) -> Geom {
+    Geom G;
+    G.xr = A.x + r * A.T;
+    const int64_t gx = (int64_t)tl * 16 * old - A.width;
+    const int64_t word = (int64_t)(reinterpret_cast<uintptr_t>(G.xr) >> 2) + gx;
+    G.shift = (int)(word & 3);
+    G.a0 = gx - G.shift;
+    G.n4 = (A.need + G.shift + 3) >> 2;
+    G.edge = !(G.a0 >= 0 && G.a0 + 4 * (int64_t)G.n4 <= A.T);
+    return G;
+  };
+  f32x4 R[D][NLD];          // register set (k mod D): this lane's share of tile k
+  Geom Gs[D];
+  // load cursor: the next tile of the run to request (stays on the last one past the end: re-reads, never used)
+  int64_t ld_row = tile_id0 / A.tiles_per_row;
+  int ld_tile = (int)(tile_id0 - ld_row * A.tiles_per_row);
+  int ld_k = 0;
+  auto issue = [&](auto slot_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    const Geom G = geom(ld_row, ld_tile);
+    Gs[S] = G;
+    int64_t q_lo64 = G.a0 >= 0 ? 0 : (-G.a0 + 3) >> 2;
+    int64_t q_hi64 = ((A.T - G.a0) >> 2) - 1;
+    if (q_hi64 > G.n4 - 1) q_hi64 = G.n4 - 1;
+    if (q_lo64 > q_hi64) q_lo64 = q_hi64;
+    const int q_lo = (int)q_lo64, q_hi = (int)q_hi64;
+    const char* __restrict__ src = reinterpret_cast<const char*>(G.xr + G.a0);
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      int q = t + l * nthreads;
+      q = q < q_lo ? q_lo : (q > q_hi ? q_hi : q);
+      R[S][l] = *reinterpret_cast<const f32x4*>(src + ((unsigned)q << 4));
+    }
+    if (ld_k + 1 < n_mine) {
+      ++ld_k;
+      if (++ld_tile == A.tiles_per_row) { ld_tile = 0; ++ld_row; }
+    }
+  };
+  // this lane's share of the tile in register set S has landed -> wave maximum of its finite samples -> maxslot[par].
+  // Edge tiles (the first and the last one or two of a row) first get their replicate padding IN REGISTERS: the prefetch
+  // clamped the float4 index into the row, so a lane whose float4 lies (partly) outside holds a neighbour's data; what it
+  // should hold is x[clamp(s, 0, T - 1)] with s within 3 samples of an end of the row -- one of six values that arrive
+  // through the SCALAR cache (s_load + lgkmcnt).  No vector memory operation may sit in this branch: the s_waitcnt pass
+  // merges the counter states of both paths, and a path with its own loads collapsed the counted waits below to
+  // vmcnt(3) -- i.e. one tile in flight instead of D - 2 (seen in the ISA of the first version).
+  auto tile_max = [&](auto slot_c, int par) __attribute__((always_inline)) {
+    constexpr int S = decltype(slot_c)::value;
+    const Geom G = Gs[S];
+    if (G.edge) {
+      float xs0, xs1, xs2, xe0, xe1, xe2;                   // x[0], x[1], x[2]; x[T-3], x[T-2], x[T-1]
+      sload3(G.xr, xs0, xs1, xs2);
+      sload3(G.xr + (A.T - 3), xe0, xe1, xe2);
+      const int64_t d_lo64 = G.a0 < 0 ? -G.a0 : 0, d_hi64 = A.T - 1 - G.a0;
+      const int d_lo = (int)d_lo64, d_hi = d_hi64 > 0x3fffffff ? 0x3fffffff : (int)d_hi64;
+      int64_t q_lo64 = G.a0 >= 0 ? 0 : (-G.a0 + 3) >> 2;
+      int64_t q_hi64 = ((A.T - G.a0) >> 2) - 1;
+      if (q_hi64 > G.n4 - 1) q_hi64 = G.n4 - 1;
+      if (q_lo64 > q_hi64) q_lo64 = q_hi64;
+      const int q_lo = (int)q_lo64, q_hi = (int)q_hi64;
+#pragma unroll
+      for (int l = 0; l < NLD; ++l) {
+        const int q = t + l * nthreads;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int d = 4 * q + e;
+          const int i_lo = d - d_lo;                        // q < q_lo: sample index max(d - d_lo, 0) in 0..2
+          const float v_lo = i_lo <= 0 ? xs0 : (i_lo == 1 ? xs1 : xs2);
+          const int i_hi = d - d_hi;                        // q > q_hi: sample index T - 1 + min(d - d_hi, 0)
+          const float v_hi = i_hi >= 0 ? xe2 : (i_hi == -1 ? xe1 : xe0);
+          const float v = R[S][l][e];
+          R[S][l][e] = q < q_lo ? v_lo : (q > q_hi ? v_hi : v);
+        }
+      }
+    }
+    unsigned mi = 0u;
+#pragma unroll
+    for (int l = 0; l < NLD; ++l)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned a = __builtin_bit_cast(unsigned, R[S][l][e]) & 0x7fffffffu;
+        mi = a < 0x7f800000u ? (a > mi ? a : mi) : mi;
+      }
+    const float m = wave_max_nonneg(__builtin_bit_cast(float, mi));
+    if (lane == 0) maxslot[par * F16S_MAXSLOTS + wave] = m;
+  };
+  // register set S -> scaled fp16 pairs in plane buffer `par`; returns 1 / s
+  auto convert = [&](auto slot_c, int par) __attribute__((always_inline)) -> float {
+    constexpr int S = decltype(slot_c)::value;
+    const f32x4* __restrict__ ms = reinterpret_cast<const f32x4*>(maxslot + par * F16S_MAXSLOTS);
+    f32x4 mm = ms[0];
+#pragma unroll
+    for (int q = 1; q < F16S_MAXSLOTS / 4; ++q) {
+      const f32x4 u = ms[q];
+      mm.x = fmaxf(mm.x, u.x); mm.y = fmaxf(mm.y, u.y); mm.z = fmaxf(mm.z, u.z); mm.w = fmaxf(mm.w, u.w);
+    }
+    const float tm = fmaxf(fmaxf(mm.x, mm.y), fmaxf(mm.z, mm.w));
+    int field = 268 - (int)(__builtin_bit_cast(unsigned, tm) >> 23);
+    field = field < 1 ? 1 : (field > 253 ? 253 : field);
+    const float sc = __builtin_bit_cast(float, (unsigned)field << 23);
+    u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(pl + par * buf_dwords);
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      u32x4 v;
+      v.x = split_pack(R[S][l].x * sc); v.y = split_pack(R[S][l].y * sc);
+      v.z = split_pack(R[S][l].z * sc); v.w = split_pack(R[S][l].w * sc);
+      dst[t + l * nthreads] = v;
+    }
+    return __builtin_bit_cast(float, (unsigned)(254 - field) << 23);
+  };
+
+  // ---- prologue: tiles 0 .. D-1 requested; maxima of tiles 0 and 1; tile 0 converted
+  static_for<0, D>([&](auto ic) __attribute__((always_inline)) { issue(ic); });
+  tile_max(std::integral_constant<int, 0>{}, 0);
+  tile_max(std::integral_constant<int, 1 % D>{}, 1);
+  __syncthreads();
+  float inv = convert(std::integral_constant<int, 0>{}, 0);
+  int shift = Gs[0].shift;
+  __syncthreads();
+
+  int64_t row = tile_id0 / A.tiles_per_row;
+  int tile = (int)(tile_id0 - row * A.tiles_per_row);
+  const int ph = 16 * wave + j;
+
+  // one tile; P = k mod D (compile time: the register sets are arrays indexed by constants)
+  auto body = [&](auto phase_c, int k) __attribute__((always_inline)) {
+    constexpr int P = decltype(phase_c)::value;
+    const int par = k & 1;
+    issue(std::integral_constant<int, P>{});              // tile k + D into the set tile k left (converted an iteration ago)
+    __builtin_amdgcn_sched_barrier(0);                    // ... issued HERE, ahead of the tile's arithmetic
+    f32x4 acc_m = {0.f, 0.f, 0.f, 0.f}, acc_c = {0.f, 0.f, 0.f, 0.f};
+    const unsigned* __restrict__ ap = pl + par * buf_dwords + shift + a_base;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      unsigned d[8];
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) d[s2] = ap[32 * c + s2];
+      u32x4 xh, xl;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xh[q] = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x05040100u);
+        xl[q] = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x07060302u);
+      }
+      const f16x8 ah = __builtin_bit_cast(f16x8, xh), al = __builtin_bit_cast(f16x8, xl);
+      const f16x8 bh = __builtin_bit_cast(f16x8, wh[c]), bl = __builtin_bit_cast(f16x8, wl[c]);
+      acc_m = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc_m, 0, 0, 0);
+      acc_c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_c, 0, 0, 0);
+      acc_c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc_c, 0, 0, 0);
+    }
+    const float scale_out = inv * A.inv_wscale;
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = (acc_m[r] + acc_c[r]) * scale_out;
+    // tile k + 2 has landed: its maximum for the NEXT iteration; tile k + 1 -> the other plane buffer
+    tile_max(std::integral_constant<int, (P + 2) % D>{}, par);
+    inv = convert(std::integral_constant<int, (P + 1) % D>{}, par ^ 1);
+    shift = Gs[(P + 1) % D].shift;
+    __syncthreads();
+    // ---- store (every lane, every r: lanes without an output write the dump line)
+    const int64_t tile_o = (int64_t)tile * 16 * A.new_sr;
+    float* __restrict__ otile = A.out + row * A.out_len + tile_o;
+    const int64_t left64 = A.out_len - tile_o;
+    const int left = left64 > 0x40000000 ? 0x40000000 : (int)left64;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = (4 * g + r) * A.new_sr + ph;
+      float* __restrict__ p = (ph < A.new_sr && o < left) ? otile + (unsigned)o : g_f16s_dump + lane;
+      *p = y[r];
+    }
+    if (++tile == A.tiles_per_row) { tile = 0; ++row; }
+  };
+  for (int k = 0; k < n_mine; k += D) {
+    static_for<0, D>([&](auto ic) __attribute__((always_inline)) {
+      if (k + decltype(ic)::value < n_mine) body(ic, k + decltype(ic)::value);
+    });
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -286,9 +529,10 @@ int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W,
                          int width, int NPB, int NC, int max_lo, int w_scale_log2, float* out, int64_t out_len, void* stream) {
   if (rows == 0) return AT_OK;
   if (!x || !W || !lo || !out || rows < 0 || T <= 0 || old_sr <= 0 || new_sr <= 0 || width <= 0 || NPB <= 0 || NC <= 0 ||
-      max_lo < 0 || out_len < 0 || 16 * NPB < new_sr || w_scale_log2 < -100 || w_scale_log2 > 100)
+      max_lo < 0 || out_len < 0 || w_scale_log2 < -100 || w_scale_log2 > 100)
     return AT_ERR_INVALID;
-  if (!at_resample_f16s_supported(old_sr, new_sr) || NPB > F16S_MAXSLOTS || NC > 6) return AT_ERR_UNSUPPORTED;
+  if (!at_resample_f16s_supported(old_sr, new_sr) || NPB > F16S_MAXSLOTS || NC > 6 || T < 16) return AT_ERR_UNSUPPORTED;
+  if (16 * NPB < new_sr) return AT_ERR_INVALID;
   if (out_len == 0) return AT_OK;
   ResF16Args A;
   A.x = x; A.W = reinterpret_cast<const u32x4*>(W); A.lo = lo; A.out = out; A.T = T; A.out_len = out_len; A.rows = rows;
@@ -302,6 +546,43 @@ int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W,
   const int n4 = (A.need + 3 + 3) / 4;                       // worst shift
   const int NLD = (n4 + threads - 1) / threads;
   if (NLD > 4) return AT_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // register-prefetch form (one workgroup per CU, five tiles deep): the default; AT_RESAMPLE_F16_RP=0 keeps the LDS-DMA form
+  // (AT_RESAMPLE_F16_TUNE=1: the switch is re-read on every call, so that one process can run both forms side by side --
+  //  tools/rsbench.py, tests/test_gpu_parity.py)
+  static const int tune_each_call = at::env_int_once("AT_RESAMPLE_F16_TUNE", 0);
+  static int use_rp = at::env_int_once("AT_RESAMPLE_F16_RP", 1);
+  if (tune_each_call) use_rp = at::env_int_once("AT_RESAMPLE_F16_RP", 1);
+  if (use_rp && threads <= F16S_RP_THREADS) {
+    const size_t lds_rp = (size_t)2 * F16S_MAXSLOTS * 4 + 2 * (size_t)NLD * threads * 16;
+    int64_t blocks = at::device_cu_count();
+    if (blocks > A.n_tiles) blocks = A.n_tiles;
+    A.tiles_per_wg = (int)((A.n_tiles + blocks - 1) / blocks);
+    blocks = (A.n_tiles + A.tiles_per_wg - 1) / A.tiles_per_wg;
+#define AT_F16S_RP(NCV, NLDV)                                                                                           \
+  {                                                                                                                     \
+    int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_f16s_rp_kernel<NCV, NLDV, 5>));                    \
+    if (e != AT_OK) return e;                                                                                           \
+    hipLaunchKernelGGL((resample_f16s_rp_kernel<NCV, NLDV, 5>), dim3((unsigned)blocks), dim3(threads), lds_rp, st, A);  \
+  }
+#define AT_F16S_RP_NLD(NCV)                                                                                             \
+  case NCV:                                                                                                             \
+    switch (NLD) {                                                                                                      \
+      case 1: AT_F16S_RP(NCV, 1) break;                                                                                 \
+      case 2: AT_F16S_RP(NCV, 2) break;                                                                                 \
+      case 3: AT_F16S_RP(NCV, 3) break;                                                                                 \
+      default: AT_F16S_RP(NCV, 4) break;                                                                                \
+    }                                                                                                                   \
+    break;
+    switch (NC) {
+      AT_F16S_RP_NLD(1) AT_F16S_RP_NLD(2) AT_F16S_RP_NLD(3) AT_F16S_RP_NLD(4) AT_F16S_RP_NLD(5) AT_F16S_RP_NLD(6)
+      default: return AT_ERR_UNSUPPORTED;
+    }
+#undef AT_F16S_RP_NLD
+#undef AT_F16S_RP
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+  }
   const size_t lds = (size_t)F16S_MAXSLOTS * 4 + 2 * (size_t)NLD * threads * 16;     // two tile buffers
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 2048 / threads) per_cu = 2048 / threads;
@@ -312,7 +593,6 @@ int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W,
   if (blocks > A.n_tiles) blocks = A.n_tiles;
   A.tiles_per_wg = (int)((A.n_tiles + blocks - 1) / blocks);
   blocks = (A.n_tiles + A.tiles_per_wg - 1) / A.tiles_per_wg;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define AT_F16S_LAUNCH(NCV, NLDV)                                                                              \
   {                                                                                                            \
     int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_f16s_kernel<NCV, NLDV>));                 \

@@ -398,6 +398,7 @@ def test_fp16_split_resampler_model_matches_the_oracle():
         x = (amp * rng.standard_normal((rows, T))).astype(np.float32)
         want = julius_leaf.resample_frac(torch.from_numpy(x)[None].double(), old, new)[0].numpy()
         got = mod.resample(x, old, new, base_word=base_word, n_wg=3)
+        assert np.array_equal(got, mod.resample(x, old, new, base_word=base_word, n_wg=2, form="dma"))
         assert got.shape == want.shape
         m = np.abs(want).max()
         f32 = mod.reference(x, old, new, np.float32)

@@ -39,9 +39,11 @@ def split_pack(e):
     return h.view(np.uint16).astype(np.uint32) | (lo.view(np.uint16).astype(np.uint32) << 16)
 
 
-def resample(x, old_sr, new_sr, base_word=0, n_wg=3):
+def resample(x, old_sr, new_sr, base_word=0, n_wg=3, form="rp"):
     """x (rows, T) float32 -> (rows, floor(new T / old)); ``base_word``: address of x[0, 0] in floats (alignment of the
-    rows); ``n_wg``: workgroups the tiles are dealt to in contiguous runs (exercises the run boundaries)."""
+    rows); ``n_wg``: workgroups the tiles are dealt to in contiguous runs (exercises the run boundaries); ``form``: how the
+    tiles that reach over an end of their row get their replicate padding -- "dma": element-wise re-read (resample_f16s_kernel),
+    "rp": fix-up in registers from six scalar loads (resample_f16s_rp_kernel).  Everything else is common to both kernels."""
     W, lo, old, new, width, NPB, NC, wk = tables.resample_f16_bank(old_sr, new_sr)
     x = np.ascontiguousarray(x, dtype=np.float32)
     rows, T = x.shape
@@ -88,13 +90,26 @@ def resample(x, old_sr, new_sr, base_word=0, n_wg=3):
             assert ((base_word + src) % 4 == 0).all(), "DMA source not 16-byte aligned"
             for e in range(4):
                 buf[4 * (t_idx + l * threads) + e] = flat[src + e]
-        if edge:
+        if edge and form == "dma":
             d_lo, d_hi = (-a0 if a0 < 0 else 0), T - 1 - a0
             for l in range(NLD):
                 q = np.minimum(t_idx + l * threads, n4 - 1)
                 for e in range(4):
                     d = np.clip(4 * q + e, d_lo, d_hi)
                     buf[4 * (t_idx + l * threads) + e] = flat[r * T + a0 + d]
+        elif edge:
+            # register-prefetch form: lanes whose float4 index was clamped take one of x[0..2] / x[T-3..T-1] (scalar loads)
+            xs, xe = x[r, :3], x[r, T - 3:]
+            d_lo, d_hi = (-a0 if a0 < 0 else 0), T - 1 - a0
+            for l in range(NLD):
+                q = t_idx + l * threads
+                for e in range(4):
+                    d = 4 * q + e
+                    i_lo, i_hi = d - d_lo, d - d_hi
+                    v_lo = np.where(i_lo <= 0, xs[0], np.where(i_lo == 1, xs[1], xs[2]))
+                    v_hi = np.where(i_hi >= 0, xe[2], np.where(i_hi == -1, xe[1], xe[0]))
+                    v = buf[4 * q + e]
+                    buf[4 * q + e] = np.where(q < q_lo, v_lo, np.where(q > q_hi, v_hi, v))
         # what the image must hold wherever an operand read can land
         d_all = np.arange(need + shift)
         want = x[r, np.clip(a0 + d_all, 0, T - 1)]

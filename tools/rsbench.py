@@ -1,13 +1,15 @@
 #!/usr/bin/env python
 """Resampler A/B on the cfg5 shapes (development aid): the fp16-split matrix-core kernel (at_resample_f16s_f32) against
 the float32 matrix-core kernel (at_resample_mfma_f32), interleaved in one process, through the raw C ABI.
-usage: python tools/rsbench.py [--batch 256] [--seconds 30] [--iters 20] [--rounds 3] [--only f16|mfma]"""
+f16 = the register-prefetch form (default), f16dma = the LDS-DMA form (AT_RESAMPLE_F16_RP=0).
+usage: python tools/rsbench.py [--batch 256] [--seconds 30] [--iters 20] [--rounds 3] [--only f16,f16dma,mfma]"""
 import argparse
 import math
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("AT_RESAMPLE_F16_TUNE", "1")     # the library re-reads AT_RESAMPLE_F16_RP per call
 import numpy as np
 import torch
 
@@ -41,7 +43,8 @@ y1 = torch.empty(rows, out_len, device=dev)
 y2 = torch.empty(rows, out_len, device=dev)
 
 
-def f16():
+def f16(rp="1"):
+    os.environ["AT_RESAMPLE_F16_RP"] = rp
     rc = lib.at_resample_f16s_f32(_native.ptr(x), rows, T, _native.ptr(Wd), _native.ptr(lod), old, new, width, NPB, NC,
                                   int(lo.max()), wk, _native.ptr(y1), out_len, st)
     assert rc == 0, rc
@@ -65,12 +68,22 @@ def timeit(fn):
     return ev[0].elapsed_time(ev[1]) / args.iters
 
 
-kinds = [k for k in (("f16", f16), ("mfma", mfma)) if not args.only or k[0] == args.only]
+y3 = torch.empty(rows, out_len, device=dev)
+
+
+def f16dma():
+    os.environ["AT_RESAMPLE_F16_RP"] = "0"
+    rc = lib.at_resample_f16s_f32(_native.ptr(x), rows, T, _native.ptr(Wd), _native.ptr(lod), old, new, width, NPB, NC,
+                                  int(lo.max()), wk, _native.ptr(y3), out_len, st)
+    assert rc == 0, rc
+
+
+kinds = [k for k in (("f16", f16), ("f16dma", f16dma), ("mfma", mfma)) if not args.only or k[0] in args.only.split(",")]
 print(f"resample {old}->{new}, rows {rows} x T {T}: {nbytes / 1e9:.3f} GB algorithmic", flush=True)
 for r in range(args.rounds):
     for name, fn in kinds:
         ms = timeit(fn)
         print(f"round {r} {name:5s} {ms:8.3f} ms  {nbytes / ms / 1e6:8.1f} GB/s  ({100 * nbytes / ms / 1e6 / 8000:.1f}% of 8 TB/s)", flush=True)
-if len(kinds) == 2:
+if len(kinds) == 3:
     d = (y1 - y2).abs().amax(-1) / y2.abs().amax(-1)
-    print(f"max per-row |f16 - mfma| / max|mfma| = {float(d.max()):.2e}")
+    print(f"max per-row |f16 - mfma| / max|mfma| = {float(d.max()):.2e};  register-prefetch form == LDS-DMA form: {torch.equal(y1, y3)}")
