@@ -395,7 +395,8 @@ __global__ __launch_bounds__(F16S_RP_THREADS) void resample_f16s_rp_kernel(const
       const int q_lo = (int)q_lo64, q_hi = (int)q_hi64;
 #pragma unroll
       for (int l = 0; l < NLD; ++l) {
-        const int q = t + l * nthreads;
+        int q = t + l * nthreads;
+        q = q < G.n4 ? q : G.n4 - 1;                        // lanes past the tile repeat its last float4 (as the DMA form)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int d = 4 * q + e;
@@ -413,7 +414,8 @@ __global__ __launch_bounds__(F16S_RP_THREADS) void resample_f16s_rp_kernel(const
     for (int l = 0; l < NLD; ++l)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const unsigned a = __builtin_bit_cast(unsigned, R[S][l][e]) & 0x7fffffffu;
+        const float fv = R[S][l][e];      // (a copy: __builtin_bit_cast applied to the vector-element lvalue itself read
+        const unsigned a = __builtin_bit_cast(unsigned, fv) & 0x7fffffffu;       //  element 0 four times -- seen in the ISA)
         mi = a < 0x7f800000u ? (a > mi ? a : mi) : mi;
       }
     const float m = wave_max_nonneg(__builtin_bit_cast(float, mi));

@@ -102,14 +102,14 @@ def resample(x, old_sr, new_sr, base_word=0, n_wg=3, form="rp"):
             xs, xe = x[r, :3], x[r, T - 3:]
             d_lo, d_hi = (-a0 if a0 < 0 else 0), T - 1 - a0
             for l in range(NLD):
-                q = t_idx + l * threads
+                q = np.minimum(t_idx + l * threads, n4 - 1)
                 for e in range(4):
                     d = 4 * q + e
                     i_lo, i_hi = d - d_lo, d - d_hi
                     v_lo = np.where(i_lo <= 0, xs[0], np.where(i_lo == 1, xs[1], xs[2]))
                     v_hi = np.where(i_hi >= 0, xe[2], np.where(i_hi == -1, xe[1], xe[0]))
-                    v = buf[4 * q + e]
-                    buf[4 * q + e] = np.where(q < q_lo, v_lo, np.where(q > q_hi, v_hi, v))
+                    v = buf[4 * (t_idx + l * threads) + e]
+                    buf[4 * (t_idx + l * threads) + e] = np.where(q < q_lo, v_lo, np.where(q > q_hi, v_hi, v))
         # what the image must hold wherever an operand read can land
         d_all = np.arange(need + shift)
         want = x[r, np.clip(a0 + d_all, 0, T - 1)]
