@@ -409,16 +409,24 @@ __global__ __launch_bounds__(F16S_RP_THREADS) void resample_f16s_rp_kernel(const
         }
       }
     }
-    unsigned mi = 0u;
+    // |x| of the finite samples, 0 for the others, reduced as a tree (one select per sample, v_max3_f32 steps).
+    // (Copies of the elements: __builtin_bit_cast applied to a vector-element lvalue read element 0 four times.)
+    float pm[NLD];
 #pragma unroll
-    for (int l = 0; l < NLD; ++l)
+    for (int l = 0; l < NLD; ++l) {
+      float av[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float fv = R[S][l][e];      // (a copy: __builtin_bit_cast applied to the vector-element lvalue itself read
-        const unsigned a = __builtin_bit_cast(unsigned, fv) & 0x7fffffffu;       //  element 0 four times -- seen in the ISA)
-        mi = a < 0x7f800000u ? (a > mi ? a : mi) : mi;
+        const float fv = R[S][l][e];
+        const float a = fabsf(fv);
+        av[e] = a < __builtin_inff() ? a : 0.f;              // false for inf and NaN
       }
-    const float m = wave_max_nonneg(__builtin_bit_cast(float, mi));
+      pm[l] = fmaxf(fmaxf(av[0], av[1]), fmaxf(av[2], av[3]));
+    }
+    float mloc = pm[0];
+#pragma unroll
+    for (int l = 1; l < NLD; ++l) mloc = fmaxf(mloc, pm[l]);
+    const float m = wave_max_nonneg(mloc);
     if (lane == 0) maxslot[par * F16S_MAXSLOTS + wave] = m;
   };
   // register set S -> scaled fp16 pairs in plane buffer `par`; returns 1 / s
@@ -555,6 +563,8 @@ int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W,
   static const int tune_each_call = at::env_int_once("AT_RESAMPLE_F16_TUNE", 0);
   static int use_rp = at::env_int_once("AT_RESAMPLE_F16_RP", 1);
   if (tune_each_call) use_rp = at::env_int_once("AT_RESAMPLE_F16_RP", 1);
+  static int rp_depth = at::env_int_once("AT_RESAMPLE_F16_D", 5);       // measurement knob: 4 tiles deep (NC = 6, NLD = 3 only)
+  if (tune_each_call) rp_depth = at::env_int_once("AT_RESAMPLE_F16_D", 5);
   if (use_rp && threads <= F16S_RP_THREADS) {
     const size_t lds_rp = (size_t)2 * F16S_MAXSLOTS * 4 + 2 * (size_t)NLD * threads * 16;
     int64_t blocks = at::device_cu_count();
@@ -576,6 +586,13 @@ int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W,
       default: AT_F16S_RP(NCV, 4) break;                                                                                \
     }                                                                                                                   \
     break;
+    if (rp_depth == 4 && NC == 6 && NLD == 3) {
+      int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_f16s_rp_kernel<6, 3, 4>));
+      if (e != AT_OK) return e;
+      hipLaunchKernelGGL((resample_f16s_rp_kernel<6, 3, 4>), dim3((unsigned)blocks), dim3(threads), lds_rp, st, A);
+      AT_LAUNCH_CHECK();
+      return AT_OK;
+    }
     switch (NC) {
       AT_F16S_RP_NLD(1) AT_F16S_RP_NLD(2) AT_F16S_RP_NLD(3) AT_F16S_RP_NLD(4) AT_F16S_RP_NLD(5) AT_F16S_RP_NLD(6)
       default: return AT_ERR_UNSUPPORTED;

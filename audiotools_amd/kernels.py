@@ -373,6 +373,53 @@ def integrated_loudness(audio_bct: torch.Tensor, rate: int, filter_class: str = 
     return out
 
 
+def integrated_loudness_fir(audio_bct: torch.Tensor, rate: int, firs: np.ndarray, gains, block_size: float = 0.400,
+                            floor_db: float = float("nan")) -> torch.Tensor:
+    """BS.1770 loudness with the weighting stages as truncated impulse responses -- the reference's FIR approximation
+    (loudness.py:69-100: zero padding, ``fft_conv1d`` with the reversed impulse response, gain, ``[1 : nt + 1]``, i.e. the
+    causal filter y[n] = g sum_i h[i] x[n - i] with a zero initial state) -- on a (B, C, T) float32 HIP tensor.
+    ``firs`` (n_stages, L): impulse responses h, ``gains`` the pass-band gains.  Each stage is one block-FFT launch of
+    ``at_fir_fft_f32`` (taps[j] = h[L - 1 - j], centre L - 1: what the reference convolves with); its replicate padding
+    differs from zero padding in the first L - 1 outputs by x[0] * sum_{i > n} h[i], taken off on that slice.  Hop
+    energies and gating: ``at_lufs_f32`` with a pass-through stage."""
+    _require_native_ok(audio_bct)
+    B, C, T = audio_bct.shape
+    x = audio_bct.contiguous()
+    dev = x.device
+    tw = tables.stft_twiddles(2048, dev)
+    lib = _native.lib()
+    for h, g in zip(np.asarray(firs, dtype=np.float64), gains):
+        L = int(h.shape[0])
+        Lp = _pad8(L)
+        half = L - 1
+        tp_np = np.zeros((1, Lp), dtype=np.float32)
+        tp_np[0, :L] = (float(g) * h[::-1]).astype(np.float32)
+        tail = np.concatenate([np.cumsum(h[::-1])[::-1][1:], [0.0]]) * float(g)       # sum_{i > n} h[i], n = 0 .. L - 1
+        key = ("lufs_fir", int(rate), L, hash(tp_np.tobytes()))
+        tp, fix = tables.device_table(key, dev, lambda: (tp_np, tail[: L - 1].astype(np.float32)))
+        y = torch.empty_like(x)
+        code = lib.at_fir_fft_f32(_native.ptr(x), B, C, T, _native.ptr(tp), 1, Lp, half, 0, _native.ptr(tw), _native.ptr(y),
+                                  _native.current_stream(dev))
+        _native.check(code, "at_fir_fft_f32")
+        n = min(L - 1, T)
+        y[..., :n] -= x[..., :1] * fix[:n]
+        x = y
+    ident = np.asarray([[1.0, 0.0, 0.0, 1.0, 0.0, 0.0]], dtype=np.float64)
+    one = np.asarray([1.0], dtype=np.float64)
+    K, S = lufs_block_params(rate, block_size)
+    if K <= 0 or S <= 0:
+        raise ValueError("block_size * rate must be at least 4 samples")
+    need = lib.at_lufs_workspace_bytes(B, C, T, K, S)
+    if need < 0:
+        _native.check(int(need), "at_lufs_workspace_bytes")
+    ws = _workspace(int(need), dev)
+    out = torch.empty((B,), dtype=torch.float32, device=dev)
+    code = lib.at_lufs_f32(_native.ptr(x), B, C, T, ident.ctypes.data, one.ctypes.data, 1, K, S, 1.0 / (block_size * rate),
+                           floor_db, 0, _native.ptr(out), _native.ptr(ws), ws.numel(), _native.current_stream(dev))
+    _native.check(code, "at_lufs_f32")
+    return out
+
+
 def have(symbol: str) -> bool:
     """Diagnostic only (never a dispatch switch): the loader already refuses a library that lacks
     any declared entry point, so there is no silent fallback to route around a missing kernel."""

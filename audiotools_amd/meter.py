@@ -6,7 +6,7 @@ Differences from the reference, by design (SURVEY.md 5.9 / north star): on a
 GPU the reference silently switches to a 512-tap FIR *approximation* of the
 weighting filters (``loudness.py:143-146``); here the GPU path evaluates the
 exact IIR cascade, i.e. it reproduces the reference's CPU branch.
-``use_fir=True`` is honoured only on the torch path (CPU tensors).
+``use_fir=True`` on HIP tensors runs the reference's FIR approximation on the block-FFT FIR kernel (round 4).
 """
 import copy
 
@@ -114,6 +114,11 @@ class Meter(torch.nn.Module):
             # HIP path: (nb, nt, nch) -> contiguous (nb, nch, nt) rows for the kernel
             return kernels.integrated_loudness(x.detach().permute(0, 2, 1).contiguous(), self.rate,
                                                self.filter_class, self.block_size)
+        if self.use_fir and kernels.is_native(x.detach()) and x.shape[-1] <= 5:
+            # the reference's FIR approximation (loudness.py:69-100) on the block-FFT FIR kernel + native gating
+            firs = self._fir_bank("cpu")[:, 0].flip(-1).double().numpy()        # impulse responses, un-reversed
+            return kernels.integrated_loudness_fir(x.detach().permute(0, 2, 1).contiguous(), self.rate, firs,
+                                                   [float(g) for g in self._gains], self.block_size)
 
         nb, nt, nch = x.shape
         x = self.apply_filter(x)

@@ -43,3 +43,27 @@ def test_transform_against_reference_golden(name, device):
         assert float(far) < 1e-3, (name, float(far))
     else:
         assert _rows_err(y, ref) < 1e-4, name
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_fir_meter_against_reference_golden(device):
+    """Meter(use_fir=True) -- the reference's 512-tap FIR approximation of the weighting cascade (loudness.py:69-100), the
+    branch it takes on a GPU -- against values computed by the unmodified reference (mono: its FIR branch mis-shapes
+    multi-channel input).  CPU: the torch formulation; HIP: block-FFT FIR kernel per stage + native hop energies / gating
+    (kernels.integrated_loudness_fir), also through AudioSignal.loudness(use_fir=True) and with two channels against the
+    package's CPU path."""
+    from audiotools_amd.meter import Meter
+    d = np.load(os.path.join(G, "loudness_fir_r04.npz"))
+    for key, sr in (("16", 16000), ("44", 44100)):
+        x = torch.from_numpy(d["x" + key].astype(np.float32)).to(device)
+        ref = torch.from_numpy(d["l" + key])
+        got = Meter(sr, use_fir=True).to(device).integrated_loudness(x.permute(0, 2, 1))
+        assert float((got.cpu() - ref).abs().max()) < 1e-2, (key, got, ref)
+        got2 = A.AudioSignal(x.clone(), sr).loudness(use_fir=True)
+        assert float((got2.cpu() - ref).abs().max()) < 1e-2
+    if device == "cuda":
+        xs = torch.from_numpy(d["x44"].astype(np.float32))
+        st = torch.cat([xs, 0.5 * xs.flip(-1)], 1)          # (2, 2, T)
+        cpu = Meter(44100, use_fir=True).integrated_loudness(st.permute(0, 2, 1))
+        hip = Meter(44100, use_fir=True).to("cuda").integrated_loudness(st.cuda().permute(0, 2, 1))
+        assert float((hip.cpu() - cpu).abs().max()) < 1e-2

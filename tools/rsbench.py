@@ -43,8 +43,9 @@ y1 = torch.empty(rows, out_len, device=dev)
 y2 = torch.empty(rows, out_len, device=dev)
 
 
-def f16(rp="1"):
+def f16(rp="1", depth="5"):
     os.environ["AT_RESAMPLE_F16_RP"] = rp
+    os.environ["AT_RESAMPLE_F16_D"] = depth
     rc = lib.at_resample_f16s_f32(_native.ptr(x), rows, T, _native.ptr(Wd), _native.ptr(lod), old, new, width, NPB, NC,
                                   int(lo.max()), wk, _native.ptr(y1), out_len, st)
     assert rc == 0, rc
@@ -78,12 +79,12 @@ def f16dma():
     assert rc == 0, rc
 
 
-kinds = [k for k in (("f16", f16), ("f16dma", f16dma), ("mfma", mfma)) if not args.only or k[0] in args.only.split(",")]
+kinds = [k for k in (("f16", f16), ("f16d4", lambda: f16("1", "4")), ("f16dma", f16dma), ("mfma", mfma)) if not args.only or k[0] in args.only.split(",")]
 print(f"resample {old}->{new}, rows {rows} x T {T}: {nbytes / 1e9:.3f} GB algorithmic", flush=True)
 for r in range(args.rounds):
     for name, fn in kinds:
         ms = timeit(fn)
         print(f"round {r} {name:5s} {ms:8.3f} ms  {nbytes / ms / 1e6:8.1f} GB/s  ({100 * nbytes / ms / 1e6 / 8000:.1f}% of 8 TB/s)", flush=True)
-if len(kinds) == 3:
+if len(kinds) == 4:
     d = (y1 - y2).abs().amax(-1) / y2.abs().amax(-1)
     print(f"max per-row |f16 - mfma| / max|mfma| = {float(d.max()):.2e};  register-prefetch form == LDS-DMA form: {torch.equal(y1, y3)}")
