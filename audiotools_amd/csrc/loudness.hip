@@ -472,7 +472,7 @@ __device__ __forceinline__ void biquad_stage_q(float (&v)[CHUNK], const LufsArgs
 // Sample indices are 32-bit here (the launcher routes rows of 2^31 - 2^22 samples or more to the
 // register-staged kernel).
 template <int NS>
-__global__ __launch_bounds__(256, AT_LUFS_WPS_DMA) void kweight_hop_energy_dma(const LufsArgs A) {
+__global__ __launch_bounds__(256, (NS <= 2 ? AT_LUFS_WPS_DMA : 3)) void kweight_hop_energy_dma(const LufsArgs A) {
   __shared__ __attribute__((aligned(16))) float lds[4 * SB];
   __shared__ __attribute__((aligned(16))) float4 qtab[NS][3 * 64 + 4];
   const int lane = threadIdx.x & 63;
@@ -824,7 +824,10 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
   int64_t seg;
   {
     const int n_cu = at::device_cu_count();
-    const int64_t slots = (int64_t)n_cu * 4 * (use_dma ? AT_LUFS_WPS_DMA : AT_LUFS_WPS);
+    // resident waves per SIMD: the LDS-DMA kernel holds four with one or two filter stages, three with the per-lane scan
+    // matrices of three or four stages in LDS (Fenton/Lee, Dash: the hint of four was not met there and the segmentation
+    // below planned for a quarter more slots than exist -- a second, nearly empty round)
+    const int64_t slots = (int64_t)n_cu * 4 * (use_dma ? (nstage <= 2 ? AT_LUFS_WPS_DMA : 3) : AT_LUFS_WPS);
     int64_t best_s = 1;
     double best_cost = 1e300;
     for (int64_t sp = 1; sp <= H_data && sp <= 4096; ++sp) {

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(1024, 5) void resample_f16s_kernel(const ResF16Args
 // (MI355X_MICROARCH.md, ldsdma-fill) -- 3.8 TB/s is what the bytes in flight buy.  A third workgroup does not fit
 // (LDS, and 96 registers per wave already).  This form trades the second workgroup for depth:
 //   * ONE workgroup per CU (NPB waves, <= 168 registers each): every lane keeps its share of the next D tiles in
-//     registers (D NLD float4: 60 registers at D = 5), i.e. D - 2 .. D - 1 tiles = 90 - 120 KB per CU are in flight at
+//     registers (D NLD float4: 48 registers at D = 4), i.e. D - 2 .. D - 1 tiles = 60 - 90 KB per CU are in flight at
 //     any time, as plain global loads in a static order (the compiler's counted s_waitcnt vmcnt leaves the younger tiles
 //     in flight: the stores are unconditional -- lanes without an output write a dump line -- so that they are counted);
 //   * the tile maximum is exchanged ONE TILE AHEAD: in the iteration that computes tile k a wave reduces its share of
@@ -557,14 +557,17 @@ int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W,
   const int NLD = (n4 + threads - 1) / threads;
   if (NLD > 4) return AT_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // register-prefetch form (one workgroup per CU, five tiles deep): the default; AT_RESAMPLE_F16_RP=0 keeps the LDS-DMA form
+  // register-prefetch form (one workgroup per CU, four tiles deep): the default; AT_RESAMPLE_F16_RP=0 keeps the LDS-DMA form
   // (AT_RESAMPLE_F16_TUNE=1: the switch is re-read on every call, so that one process can run both forms side by side --
   //  tools/rsbench.py, tests/test_gpu_parity.py)
   static const int tune_each_call = at::env_int_once("AT_RESAMPLE_F16_TUNE", 0);
   static int use_rp = at::env_int_once("AT_RESAMPLE_F16_RP", 1);
   if (tune_each_call) use_rp = at::env_int_once("AT_RESAMPLE_F16_RP", 1);
-  static int rp_depth = at::env_int_once("AT_RESAMPLE_F16_D", 5);       // measurement knob: 4 tiles deep (NC = 6, NLD = 3 only)
-  if (tune_each_call) rp_depth = at::env_int_once("AT_RESAMPLE_F16_D", 5);
+  // tiles requested ahead: 4 (session r04 s04, interleaved on one box: 0.845-0.862 ms at D = 4, 0.870-0.872 at D = 5,
+  // 0.98 for the LDS-DMA form, 1.04 for the float32 MFMA kernel); AT_RESAMPLE_F16_D=5 keeps the deeper one measurable
+  // (NC = 6, NLD = 3 only)
+  static int rp_depth = at::env_int_once("AT_RESAMPLE_F16_D", 4);
+  if (tune_each_call) rp_depth = at::env_int_once("AT_RESAMPLE_F16_D", 4);
   if (use_rp && threads <= F16S_RP_THREADS) {
     const size_t lds_rp = (size_t)2 * F16S_MAXSLOTS * 4 + 2 * (size_t)NLD * threads * 16;
     int64_t blocks = at::device_cu_count();
@@ -573,9 +576,9 @@ int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W,
     blocks = (A.n_tiles + A.tiles_per_wg - 1) / A.tiles_per_wg;
 #define AT_F16S_RP(NCV, NLDV)                                                                                           \
   {                                                                                                                     \
-    int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_f16s_rp_kernel<NCV, NLDV, 5>));                    \
+    int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_f16s_rp_kernel<NCV, NLDV, 4>));                    \
     if (e != AT_OK) return e;                                                                                           \
-    hipLaunchKernelGGL((resample_f16s_rp_kernel<NCV, NLDV, 5>), dim3((unsigned)blocks), dim3(threads), lds_rp, st, A);  \
+    hipLaunchKernelGGL((resample_f16s_rp_kernel<NCV, NLDV, 4>), dim3((unsigned)blocks), dim3(threads), lds_rp, st, A);  \
   }
 #define AT_F16S_RP_NLD(NCV)                                                                                             \
   case NCV:                                                                                                             \
@@ -586,10 +589,10 @@ int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W,
       default: AT_F16S_RP(NCV, 4) break;                                                                                \
     }                                                                                                                   \
     break;
-    if (rp_depth == 4 && NC == 6 && NLD == 3) {
-      int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_f16s_rp_kernel<6, 3, 4>));
+    if (rp_depth == 5 && NC == 6 && NLD == 3) {
+      int e = at::allow_big_lds(reinterpret_cast<const void*>(resample_f16s_rp_kernel<6, 3, 5>));
       if (e != AT_OK) return e;
-      hipLaunchKernelGGL((resample_f16s_rp_kernel<6, 3, 4>), dim3((unsigned)blocks), dim3(threads), lds_rp, st, A);
+      hipLaunchKernelGGL((resample_f16s_rp_kernel<6, 3, 5>), dim3((unsigned)blocks), dim3(threads), lds_rp, st, A);
       AT_LAUNCH_CHECK();
       return AT_OK;
     }

@@ -37,6 +37,70 @@ def lowpass_torch(audio: torch.Tensor, cutoffs: torch.Tensor, zeros: float, high
     return out
 
 
+def needs_native_grad(audio: torch.Tensor) -> bool:
+    """A HIP float32 tensor whose gradient is wanted: the FIR family keeps it on the kernels (forward kernel + the
+    adjoint below) instead of the torch formulation."""
+    return audio.is_cuda and audio.dtype == torch.float32 and audio.requires_grad and torch.is_grad_enabled()
+
+
+class _NativeFir(torch.autograd.Function):
+    """``kernels.fir_per_item`` (per-item FIR h of odd length L = 2 H + 1, replicate padding, optionally x - FIR(x)) with
+    its exact adjoint with respect to the audio, evaluated by the SAME kernel (reference: low_pass / high_pass /
+    equalizer must stay differentiable, tests/core/test_grad.py:44-66).
+    Forward  y[n] = sum_j h[j] x[clamp(n - H + j)].  With g = dL/dy zero-extended and u[m] = sum_j h[j] g[m + H - j]:
+        dL/dx[m] = u[m] (0 < m < T-1),   dL/dx[0] = sum_{m' <= 0} u[m'],   dL/dx[T-1] = sum_{m' >= T-1} u[m'].
+    u on [0, T) is the kernel run on g with the taps flipped, minus what its replicate padding adds within H samples of
+    either end (g[0] times a suffix sum of h, g[T-1] times a prefix sum); the two folds are dot products of the first /
+    last H gradient samples with prefix / suffix sums of h.  All tap sums come from one cumsum of the (B, L) table."""
+
+    @staticmethod
+    def forward(ctx, audio, tp, L, highpass):
+        ctx.save_for_backward(tp)
+        ctx.L, ctx.highpass = int(L), bool(highpass)
+        return kernels.fir_per_item(audio.detach(), tp, highpass=bool(highpass), L=int(L))
+
+    @staticmethod
+    def backward(ctx, g):
+        (tp,) = ctx.saved_tensors
+        return fir_adjoint(g, tp, ctx.L, ctx.highpass, lambda a, t: kernels.fir_per_item(a, t, highpass=False, L=ctx.L)), None, None, None
+
+
+def fir_adjoint(g: torch.Tensor, tp: torch.Tensor, L: int, highpass: bool, fir) -> torch.Tensor:
+    """dL/dx of y = FIR_h(x) (replicate padding; ``highpass``: y = x - FIR_h(x)) from g = dL/dy (B, C, T), T >= L.
+    ``tp`` (rows, >= L) tap table with rows in (1, B); ``fir(a, table)`` applies a table of this shape with replicate
+    padding (the kernel; the CPU test passes a torch formulation)."""
+    H = (L - 1) // 2
+    g = g.contiguous()
+    T = g.shape[-1]
+    h = tp[:, :L]
+    flipped = torch.zeros_like(tp)
+    flipped[:, :L] = h.flip(-1)
+    z = fir(g, flipped.contiguous())
+    if H > 0:
+        pre = torch.cumsum(h.double(), -1)                      # pre[j] = h[0] + .. + h[j]
+        tot = pre[:, -1:]
+        m = torch.arange(H, device=g.device)
+        # replicate padding of g inside the kernel: output m < H got g[0] * sum_{j > m + H} h[j], output T - H + i got
+        # g[T-1] * sum_{j <= i} h[j]
+        A = (tot - pre[:, H + m]).to(g.dtype)                   # (rows, H)
+        Bp = pre[:, m].to(g.dtype)
+        z[..., :H] -= g[..., :1] * A[:, None, :]
+        z[..., T - H:] -= g[..., -1:] * Bp[:, None, :]
+        # folds of the virtual positions outside [0, T) onto the clamped end samples
+        P = pre[:, (H - 1 - m)].to(g.dtype)                     # n = 0 .. H-1: sum_{j <= H-1-n} h[j]
+        S = (tot - pre[:, (2 * H - 1 - m)]).to(g.dtype)         # n = T-H+i: sum_{j >= 2H-i} h[j]
+        z[..., 0] += (g[..., :H] * P[:, None, :]).sum(-1)
+        z[..., T - 1] += (g[..., T - H:] * S[:, None, :]).sum(-1)
+    return (g - z) if highpass else z
+
+
+def fir_native_or_grad(audio: torch.Tensor, tp: torch.Tensor, L: int, highpass: bool = False) -> torch.Tensor:
+    """The FIR kernels on a padded tap table (kernels.sinc_taps_native / eq_taps_native), differentiable in ``audio``."""
+    if needs_native_grad(audio):
+        return _NativeFir.apply(audio, tp, L, highpass)
+    return kernels.fir_per_item(audio, tp, highpass=highpass, L=L)
+
+
 def resample_torch(audio: torch.Tensor, old_sr: int, new_sr: int) -> torch.Tensor:
     """Torch formulation of julius.resample_frac (audio_signal.py:732)."""
     plan = tables.resample_bank(int(old_sr), int(new_sr))
@@ -161,6 +225,15 @@ class DSPMixin:
             # the host twin goes through the same float32 division as the device tensor
             host = None if host is None else host.to(cutoffs.dtype) / self.sample_rate
             filtered = kernels.sinc_filter(audio, cutoffs, zeros, highpass, host_cutoffs=host)
+        elif needs_native_grad(audio) and not cutoffs.requires_grad:
+            # gradient with respect to the audio wanted: forward kernel + its adjoint on the same kernel (_NativeFir)
+            host = None if host is None else host.to(cutoffs.dtype) / self.sample_rate
+            tp, L = kernels.sinc_taps_native(cutoffs.detach().to(audio.device).reshape(self.batch_size), zeros,
+                                             None if host is None else host.reshape(self.batch_size))
+            if L <= audio.shape[-1]:
+                filtered = _NativeFir.apply(audio, tp, L, highpass)
+            else:
+                filtered = lowpass_torch(audio, cutoffs, zeros, highpass)
         else:
             filtered = lowpass_torch(audio, cutoffs, zeros, highpass)
         self.audio_data = filtered

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import kernels, tables, util
+from . import filters, kernels, tables, util
 
 
 def _roll_to_peak(ir: torch.Tensor) -> torch.Tensor:
@@ -394,6 +394,16 @@ class EffectMixin:
                 w = weights.to(audio.device).expand(self.batch_size, n_bands)
                 tp, L = kernels.eq_taps_native(w, bank_d, half)
                 self.audio_data = kernels.fir_per_item(audio, tp, replicate=True, L=L)
+        elif (filters.needs_native_grad(audio) and not weights.requires_grad and self.batch_size <= 65535
+              and tables.band_split_bank(int(self.sample_rate), int(n_bands))[0] is not None
+              and tables.band_split_bank(int(self.sample_rate), int(n_bands))[0].shape[1] <= audio.shape[-1]):
+            # gradient with respect to the audio wanted: composite FIR per item, forward kernel + adjoint (filters._NativeFir)
+            bank, half = tables.band_split_bank(int(self.sample_rate), int(n_bands))
+            bank_d = tables.device_table(("band_split_bank", int(self.sample_rate), int(n_bands)), audio.device,
+                                         lambda: (bank.numpy(),))[0]
+            w = weights.to(audio.device).expand(self.batch_size, n_bands)
+            tp, L = kernels.eq_taps_native(w, bank_d, half)
+            self.audio_data = filters._NativeFir.apply(audio, tp, L, False)
         else:
             fbank = self.mel_filterbank(n_bands)
             self.audio_data = (fbank * weights.to(self.device)[:, None, None, :]).sum(-1)

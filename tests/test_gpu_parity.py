@@ -148,6 +148,35 @@ def test_mel_loss_grid(win, n_mels):
     assert rel_err(torch.view_as_real(s.stft_data), torch.view_as_real(X_ref)) < REL
 
 
+@pytest.mark.parametrize("op", ["low_pass", "high_pass", "equalizer"])
+def test_fir_family_native_gradient_vs_float64(op):
+    """low_pass / high_pass / equalizer on a HIP tensor that requires grad stay on the FIR kernels (forward kernel + the
+    adjoint on the same kernel, filters._NativeFir; the reference promises gradients through them,
+    tests/core/test_grad.py:44-66): value and dL/daudio against a float64 evaluation of the torch formulation."""
+    from audiotools_amd import filters
+    sr, T = 16000, 12000
+    x = synth.audio_batch(3, 2, T, seed=77, gaps=False, sample_rate=sr)
+    g = torch.Generator().manual_seed(3)
+    wgt = torch.randn(3, 2, T, generator=g)
+    arg = torch.tensor([1000.0, 2500.0, 4000.0]) if op != "equalizer" else -torch.rand(3, 6, generator=g)
+
+    # float64 yardstick: the torch formulation of the same filter (the reference's float32 taps, applied in float64)
+    x64 = x.double().clone().requires_grad_(True)
+    if op == "equalizer":
+        from audiotools_amd import fx
+        taps, half = fx.equalizer_taps(sr, (10 ** arg).float())
+        y64 = torch.stack([filters._conv_rows_replicate(x64[b], taps[b].double(), half) for b in range(3)])
+    else:
+        y64 = filters.lowpass_torch(x64, (arg / sr)[:, None], 51, op == "high_pass")
+    (g64,) = torch.autograd.grad((y64 * wgt.double()).sum(), x64)
+    a = x.cuda().clone().requires_grad_(True)
+    y32 = getattr(A.AudioSignal(a, sr), op)(arg.clone()).audio_data
+    assert "NativeFir" in type(y32.grad_fn).__name__, type(y32.grad_fn).__name__     # the kernels ran, not the torch formulation
+    (g32,) = torch.autograd.grad((y32 * wgt.cuda()).sum(), a)
+    assert rel_err(y32.detach(), y64.detach()) < REL
+    assert rel_err(g32, g64) < REL
+
+
 def test_mel_generic_size_short_clip_falls_back_to_dense_basis():
     """mel_spectrogram on generic transform sizes (4096 @ 96 kHz ...) goes to the banded mel stage of the TILED
     kernel; a clip that kernel does not take (shorter than its two-frame tile: T < n_fft + hop) must keep working through

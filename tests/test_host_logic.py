@@ -421,3 +421,35 @@ def test_fp16_split_resampler_model_matches_the_oracle():
     assert np.abs(got[0][clean] - want[0][clean]).max() < 5e-7 * np.abs(want[0][clean]).max()
     centre = 16000 * 3000 // 44100
     assert not np.isfinite(got[0][centre - 5: centre + 5]).any()
+
+
+def test_fir_adjoint_formula_equals_autograd():
+    """filters.fir_adjoint (the backward of the native per-item FIR: the forward kernel on the flipped taps + end corrections
+    and folds from prefix sums of the taps) against torch autograd of a float64 replicate-padded correlation: per-item and
+    shared taps, high-pass form, L = 1, L = T."""
+    import torch
+    import torch.nn.functional as F
+    from audiotools_amd import filters
+
+    torch.manual_seed(0)
+
+    def fir_cpu(a, table, L):
+        B, C, T = a.shape
+        H = (L - 1) // 2
+        out = torch.empty_like(a)
+        for b in range(B):
+            k = table[b if table.shape[0] > 1 else 0, :L]
+            out[b] = F.conv1d(F.pad(a[b][:, None], (H, H), mode="replicate"), k[None, None])[:, 0]
+        return out
+
+    for (B, C, T, L, rows, hp) in [(3, 2, 50, 9, 3, False), (2, 1, 40, 13, 1, True), (2, 2, 31, 31, 2, False), (1, 1, 20, 1, 1, False),
+                                   (2, 1, 64, 21, 2, True)]:
+        tp = torch.zeros(rows, (L + 7) // 8 * 8, dtype=torch.float64)
+        tp[:, :L] = torch.randn(rows, L, dtype=torch.float64)
+        x = torch.randn(B, C, T, dtype=torch.float64, requires_grad=True)
+        y = fir_cpu(x, tp, L)
+        y = (x - y) if hp else y
+        g = torch.randn_like(y)
+        (gx,) = torch.autograd.grad(y, x, g)
+        got = filters.fir_adjoint(g, tp, L, hp, lambda a, t: fir_cpu(a, t, L))
+        assert float((got - gx).abs().max()) < 1e-12, (B, C, T, L, rows, hp)

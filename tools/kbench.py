@@ -59,6 +59,8 @@ for what in args.what.split(","):
                rows * T * 4 + rows * N * 80 * 4, "mel-only")
     elif what == "lufs":
         timeit(lambda: kernels.integrated_loudness(x, SR), rows * T * 4, "lufs")
+    elif what == "lufs3":       # the three-stage weighting class (three waves per SIMD: scan matrices of three stages in LDS)
+        timeit(lambda: kernels.integrated_loudness(x, SR, "Fenton/Lee 1"), rows * T * 4, "lufs FL1")
     elif what == "istft":
         X, _ = kernels.stft_mel(x, win, n_fft, hop)
         timeit(lambda: kernels.istft(X, win, n_fft, hop, T), rows * T * 4 + rows * N * F * 8, "istft")

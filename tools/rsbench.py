@@ -43,7 +43,7 @@ y1 = torch.empty(rows, out_len, device=dev)
 y2 = torch.empty(rows, out_len, device=dev)
 
 
-def f16(rp="1", depth="5"):
+def f16(rp="1", depth="4"):
     os.environ["AT_RESAMPLE_F16_RP"] = rp
     os.environ["AT_RESAMPLE_F16_D"] = depth
     rc = lib.at_resample_f16s_f32(_native.ptr(x), rows, T, _native.ptr(Wd), _native.ptr(lod), old, new, width, NPB, NC,
@@ -79,7 +79,7 @@ def f16dma():
     assert rc == 0, rc
 
 
-kinds = [k for k in (("f16", f16), ("f16d4", lambda: f16("1", "4")), ("f16dma", f16dma), ("mfma", mfma)) if not args.only or k[0] in args.only.split(",")]
+kinds = [k for k in (("f16", f16), ("f16d5", lambda: f16("1", "5")), ("f16dma", f16dma), ("mfma", mfma)) if not args.only or k[0] in args.only.split(",")]
 print(f"resample {old}->{new}, rows {rows} x T {T}: {nbytes / 1e9:.3f} GB algorithmic", flush=True)
 for r in range(args.rounds):
     for name, fn in kinds:
