@@ -301,7 +301,7 @@ __global__ __launch_bounds__(1024, 5) void resample_f16s_kernel(const ResF16Args
 //     iteration earlier -- one workgroup barrier per tile instead of two, and no LDS round trip of the raw samples;
 //   * two plane buffers: tile k + 1 is written while other waves still read tile k.
 // Same numbers as the DMA form bit for bit (same scale, same split, same products in the same order).
-__device__ float g_f16s_dump[64];
+__device__ __attribute__((aligned(16))) float g_f16s_dump[256];       // one float4 per lane
 
 constexpr int F16S_RP_THREADS = 704;      // <= 11 waves: three waves per SIMD at most, i.e. a 168-register budget
 template <int NC, int NLD, int D>
@@ -317,6 +317,12 @@ __global__ __launch_bounds__(F16S_RP_THREADS) void resample_f16s_rp_kernel(const
   const int koff = (g & 1) * 16 + (g >> 1) * 8;
   const int old = A.old_sr;
   const int buf_dwords = 4 * NLD * nthreads;
+  // the outputs of a tile ([16 frames][new phases] floats, contiguous in the row) pass through LDS so that they leave as
+  // 1 KB runs (one float4 per lane): written from the accumulator layout as 64-byte pieces -- a wave's four store
+  // instructions each touch four half cache lines, the other halves belonging to other waves -- pure stores of this
+  // tile shape run at 3.3 TB/s, as 1 KB runs at 5.4 TB/s (tools/micro/segbench.hip, session r04 s05)
+  float* __restrict__ ylds = reinterpret_cast<float*>(pl + 2 * buf_dwords);   // [2][16 new]
+  const int ytile_floats = 16 * A.new_sr;
 
   const int64_t tile_id0 = (int64_t)blockIdx.x * A.tiles_per_wg;
   const int64_t tiles_left = A.n_tiles - tile_id0;
@@ -496,21 +502,33 @@ __global__ __launch_bounds__(F16S_RP_THREADS) void resample_f16s_rp_kernel(const
     float y[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) y[r] = (acc_m[r] + acc_c[r]) * scale_out;
+    float* __restrict__ ytile = ylds + par * ytile_floats;       // (read after this iteration's barrier, rewritten two later)
+    if (ph < A.new_sr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ytile[(4 * g + r) * A.new_sr + ph] = y[r];
+    }
     // tile k + 2 has landed: its maximum for the NEXT iteration; tile k + 1 -> the other plane buffer
     tile_max(std::integral_constant<int, (P + 2) % D>{}, par);
     inv = convert(std::integral_constant<int, (P + 1) % D>{}, par ^ 1);
     shift = Gs[(P + 1) % D].shift;
     __syncthreads();
-    // ---- store (every lane, every r: lanes without an output write the dump line)
+    // ---- store (every lane on every path: lanes without an output write the dump line, so the stores are counted)
     const int64_t tile_o = (int64_t)tile * 16 * A.new_sr;
     float* __restrict__ otile = A.out + row * A.out_len + tile_o;
     const int64_t left64 = A.out_len - tile_o;
     const int left = left64 > 0x40000000 ? 0x40000000 : (int)left64;
+    if (left >= ytile_floats && (reinterpret_cast<uintptr_t>(otile) & 15) == 0) {      // wave-uniform: a whole, aligned tile
+      const int nq = ytile_floats >> 2;
+      const f32x4 v = reinterpret_cast<const f32x4*>(ytile)[t < nq ? t : 0];
+      f32x4* __restrict__ p = t < nq ? reinterpret_cast<f32x4*>(otile) + t : reinterpret_cast<f32x4*>(g_f16s_dump) + lane;
+      *p = v;
+    } else {                                             // the last tile of a row / rows at odd addresses: element stores
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int o = (4 * g + r) * A.new_sr + ph;
-      float* __restrict__ p = (ph < A.new_sr && o < left) ? otile + (unsigned)o : g_f16s_dump + lane;
-      *p = y[r];
+      for (int r = 0; r < 4; ++r) {
+        const int o = (4 * g + r) * A.new_sr + ph;
+        float* __restrict__ p = (ph < A.new_sr && o < left) ? otile + (unsigned)o : g_f16s_dump + lane;
+        *p = y[r];
+      }
     }
     if (++tile == A.tiles_per_row) { tile = 0; ++row; }
   };
@@ -569,7 +587,7 @@ int at_resample_f16s_f32(const float* x, int64_t rows, int64_t T, const void* W,
   static int rp_depth = at::env_int_once("AT_RESAMPLE_F16_D", 4);
   if (tune_each_call) rp_depth = at::env_int_once("AT_RESAMPLE_F16_D", 4);
   if (use_rp && threads <= F16S_RP_THREADS) {
-    const size_t lds_rp = (size_t)2 * F16S_MAXSLOTS * 4 + 2 * (size_t)NLD * threads * 16;
+    const size_t lds_rp = (size_t)2 * F16S_MAXSLOTS * 4 + 2 * (size_t)NLD * threads * 16 + 2 * (size_t)16 * new_sr * 4;
     int64_t blocks = at::device_cu_count();
     if (blocks > A.n_tiles) blocks = A.n_tiles;
     A.tiles_per_wg = (int)((A.n_tiles + blocks - 1) / blocks);
