@@ -238,6 +238,15 @@ struct RowLayout {          // buf[row slot][point]
   __device__ __forceinline__ void split(int id, int nb, int& batch, int& j) const { batch = id >= nb ? 1 : 0; j = id - (batch ? nb : 0); }
   __device__ __forceinline__ int addr(int batch, int p) const { return batch * N + (sw ? (p ^ ((p >> 4) & 15)) : p); }
 };
+struct RowLayoutN {         // buf[row slot][point], any number of rows (the run-time-plan STFT tile: up to 64 short frames)
+  int N, sw;
+  // id / nb through a float reciprocal: exact for id < 2^13 (see stft_generic_tiled_kernel)
+  __device__ __forceinline__ void split(int id, int nb, int& batch, int& j) const {
+    batch = (int)(((float)id + 0.5f) * (1.0f / (float)nb));
+    j = id - batch * nb;
+  }
+  __device__ __forceinline__ int addr(int batch, int p) const { return batch * N + (sw ? (p ^ ((p >> 4) & 15)) : p); }
+};
 
 // Per-pass twiddle blocks.  A pass of radix R behind NS = (product of the earlier radices) multiplies input q of the
 // butterfly with k = j mod NS by w_{NS R}^{k q}.  Gathering these from ONE table w_N^t (index k q N / (NS R)) is a

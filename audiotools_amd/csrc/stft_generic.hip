@@ -172,16 +172,23 @@ struct Gen2Args {
 constexpr int G2_LOADS = at::gfft::TILE_POINTS / 256;     // float2 samples of a tile per thread
 constexpr int G2_KB = at::gfft::TILE_POINTS / 256 + 1;    // bins of a tile per thread (FB (M + 1) <= 4098)
 
-template <int PLAN /* 0: run-time pass list; 1: M = 2048 as 16 16 8 (two frames); 2: M = 4096 as 16 16 16 */>
-__global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Args A) {
+#ifndef AT_GENERIC_SMALL_WGS
+#define AT_GENERIC_SMALL_WGS 3     // workgroups per CU (168 registers: 4-6 spilled, still 8-12 % faster than two at 174 -- session r04 s09); the register allocation of the speech-window plans must allow
+#endif
+// PLAN 0: run-time pass list, FB frames per tile;  1: M = 2048 as 16 16 8 (two frames);  2: M = 4096 as 16 16 16;
+// round 4, the speech windows with a full tile and a compile-time pass list (no plan in SGPRs, index arithmetic folded):
+// 3: n_fft 400 (M = 200 = 25 8, 20 frames);  4: n_fft 1200 (M = 600 = 25 3 8, 6 frames);  5: n_fft 1920 (M = 960 = 5 3 16 4, 4 frames)
+template <int PLAN>
+__global__ __launch_bounds__(256, (PLAN >= 3 ? AT_GENERIC_SMALL_WGS : 2)) void stft_generic_tiled_kernel(const Gen2Args A) {
   extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
-  const int M = PLAN == 1 ? 2048 : (PLAN == 2 ? 4096 : A.M);
-  const int FB = PLAN == 1 ? 2 : (PLAN == 2 ? 1 : A.FB);
+  constexpr bool POW2 = PLAN == 1 || PLAN == 2;        // window in registers, at most two frames per tile
+  const int M = PLAN == 1 ? 2048 : PLAN == 2 ? 4096 : PLAN == 3 ? 200 : PLAN == 4 ? 600 : PLAN == 5 ? 960 : A.M;
+  const int FB = PLAN == 1 ? 2 : PLAN == 2 ? 1 : PLAN == 3 ? 20 : PLAN == 4 ? 6 : PLAN == 5 ? 4 : A.FB;
   const int N = 2 * M;
   float2* buf = gbuf;                             // [FB][M]
   float2* tw = gbuf + FB * M;                     // [M]: w_M^t
   float2* win = tw + M;                           // [M]: window pairs (PLAN 0; the fixed plans keep theirs in registers)
-  float2* stw = PLAN == 0 ? win + M : tw + M;     // [M / 2 + 1]: split twiddles w_N^j
+  float2* stw = !POW2 ? win + M : tw + M;         // [M / 2 + 1]: split twiddles w_N^j
   float* melw = reinterpret_cast<float*>(stw + M / 2 + 2);     // [n_chunks][16]
   int* mtab = reinterpret_cast<int*>(melw + 16 * A.n_chunks);  // [n_chunks] first bins, then [n_mels][2]
   float* part = reinterpret_cast<float*>(mtab + A.n_chunks + 2 * A.n_mels);   // [FB][n_chunks] partial sums
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
   // window pairs of this thread's points: n = (tid + 256 i) mod M is the same for every tile
   constexpr int NWR = PLAN == 1 ? 8 : (PLAN == 2 ? 16 : 1);
   float2 wreg[NWR];
-  if constexpr (PLAN == 0) {
+  if constexpr (!POW2) {
     for (int i = threadIdx.x; i < M; i += 256) win[i] = reinterpret_cast<const float2*>(A.window)[i];
   } else {
 #pragma unroll
@@ -204,9 +211,19 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
     for (int i = threadIdx.x; i < 2 * A.n_mels; i += 256) mtab[A.n_chunks + i] = A.band[i];
   }
   __syncthreads();
-  const at::gfft::RowLayout lay{M, (M & 15) == 0 ? 1 : 0};
+  using Lay = std::conditional_t<!POW2, at::gfft::RowLayoutN, at::gfft::RowLayout>;
+  const Lay lay{M, (M & 15) == 0 ? 1 : 0};
   const int npts = FB * M, nbins = FB * (M + 1);
   const int Ti = (int)A.T, n_out = (int)A.n_out, tpr = (int)A.tiles_per_row, hop = A.hop;
+  // frame of a tile index: the fixed plans hold at most two frames; the run-time plan holds FB = up to 64 frames of a
+  // short window (n_fft 400: 20 frames per tile -- with two, 16 of the 256 threads had a radix-25 butterfly), so the
+  // split is a division by a run-time length: exact through a float reciprocal for indices < 2^13 (the quotient's
+  // fractional part stays >= 0.5 / len away from an integer, the product's error is ~1e-3 of that)
+  const float inv_M = 1.0f / (float)M, inv_M1 = 1.0f / (float)(M + 1);
+  auto frame_of = [&](int e, int len, float inv_len) __attribute__((always_inline)) -> int {
+    if constexpr (POW2) return e >= len ? 1 : 0;
+    else return (int)(((float)e + 0.5f) * inv_len);
+  };
 
   const int n_x = (int)gridDim.x < A.n_xcd ? (int)gridDim.x : A.n_xcd;
   const int xcd = blockIdx.x % n_x, lblk = blockIdx.x / n_x;
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
     for (int i = 0; i < G2_LOADS; ++i) {
       if (256 * i < npts) {                               // uniform; lanes past the end repeat the last point
         const int e = min(tid + 256 * i, npts - 1);
-        const int fi = e >= M ? 1 : 0, n = e - fi * M;    // FB <= 2
+        const int fi = frame_of(e, M, inv_M), n = e - fi * M;
         r[i] = *reinterpret_cast<const float2*>(xs + fi * hop + 2 * n);
       }
     }
@@ -251,17 +268,17 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
       for (int i = 0; i < G2_LOADS; ++i) {
         if (256 * i < npts) {
           const int e = min(tid + 256 * i, npts - 1);
-          const int fi = e >= M ? 1 : 0, n = e - fi * M;
-          const float2 w = PLAN == 0 ? win[n] : wreg[i & (NWR - 1)];
+          const int fi = frame_of(e, M, inv_M), n = e - fi * M;
+          const float2 w = !POW2 ? win[n] : wreg[i & (NWR - 1)];
           buf[lay.addr(fi, n)] = make_float2(r[i].x * w.x, r[i].y * w.y);
         }
       }
     } else {
 #pragma unroll 1
       for (int e = tid; e < npts; e += 256) {
-        const int fi = e >= M ? 1 : 0, n = e - fi * M;
+        const int fi = frame_of(e, M, inv_M), n = e - fi * M;
         const int64_t sidx = (int64_t)s0 + fi * hop + 2 * n;
-        const float2 w = PLAN == 0 ? win[n] : reinterpret_cast<const float2*>(A.window)[n];
+        const float2 w = !POW2 ? win[n] : reinterpret_cast<const float2*>(A.window)[n];
         buf[lay.addr(fi, n)] = make_float2(at::fetch_padded(xr, sidx, A.T, A.T2, A.pad, A.pad_mode) * w.x,
                              at::fetch_padded(xr, sidx + 1, A.T, A.T2, A.pad, A.pad_mode) * w.y);
       }
@@ -276,6 +293,18 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
       at::gfft::pass_inplace<16, 1, 256>(buf, tw, 4096, 1, 256, lay);
       at::gfft::pass_inplace<16, 1, 256>(buf, tw, 4096, 16, 256, lay);
       at::gfft::pass_inplace<16, 1, 256>(buf, tw + 240, 4096, 256, 256, lay);     // block 1: 256 x 15
+    } else if constexpr (PLAN == 3) {                     // 20 frames of 200 points: 160 radix-25, 500 radix-8 butterflies
+      at::gfft::pass_inplace<25, 1, 256>(buf, tw, 200, 1, 160, lay);
+      at::gfft::pass_inplace<8, 2, 256>(buf, tw, 200, 25, 500, lay);              // block 0: 25 x 7
+    } else if constexpr (PLAN == 4) {                     // 6 frames of 600 points
+      at::gfft::pass_inplace<25, 1, 256>(buf, tw, 600, 1, 144, lay);
+      at::gfft::pass_inplace<3, 5, 256>(buf, tw, 600, 25, 1200, lay);             // block 0: 25 x 2
+      at::gfft::pass_inplace<8, 2, 256>(buf, tw + 50, 600, 75, 450, lay);         // block 1: 75 x 7
+    } else if constexpr (PLAN == 5) {                     // 4 frames of 960 points
+      at::gfft::pass_inplace<5, 3, 256>(buf, tw, 960, 1, 768, lay);
+      at::gfft::pass_inplace<3, 5, 256>(buf, tw, 960, 5, 1280, lay);              // block 0: 5 x 2
+      at::gfft::pass_inplace<16, 1, 256>(buf, tw + 10, 960, 15, 240, lay);        // block 1: 15 x 15
+      at::gfft::pass_inplace<4, 4, 256>(buf, tw + 235, 960, 240, 960, lay);       // block 2: 240 x 3
     } else {
       at::gfft::run_passes<256>(buf, tw, M, A.pl, FB, lay);
     }
@@ -286,9 +315,9 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
     for (int it = 0; it < G2_KB; ++it) {
       const int e = tid + 256 * it;
       mg[it] = 0.f;
-      if ((PLAN != 0 && it < G2_KB - 1) || e < nbins) {   // full-size tiles (PLAN 1 / 2): only the last slot can lie past the tile
+      if ((POW2 && it < G2_KB - 1) || e < nbins) {        // full-size tiles (PLAN 1 / 2): only the last slot can lie past the tile
         const int ec = min(e, nbins - 1);
-        const int fi = ec >= M + 1 ? 1 : 0, k = ec - fi * (M + 1);
+        const int fi = frame_of(ec, M + 1, inv_M1), k = ec - fi * (M + 1);
         const float2 zk = buf[lay.addr(fi, k == M ? 0 : k)], zm = buf[lay.addr(fi, (k == 0 || k == M) ? 0 : M - k)];
         // w_N^k from the quarter table stw[j] = w_N^j, j <= M / 2, by the symmetry w_N^(M - j) = -conj(w_N^j)
         float2 w = stw[k <= M / 2 ? k : M - k];
@@ -300,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
         const float qq = fmaf(sn, di, c * dr);
         float2 X = make_float2(0.5f * (sr - pp), 0.5f * (si - qq));
         if (k == 0 || k == M) X.y = 0.f;                  // exactly real
-        if (PLAN != 0 && it < G2_KB - 1) orow[e] = X;     // frame f0 + 1 follows frame f0: e indexes both rows
+        if (POW2 && it < G2_KB - 1) orow[e] = X;          // frame f0 + 1 follows frame f0: e indexes both rows
         else if (e < nbins) orow[e] = X;
         mg[it] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));
       }
@@ -314,9 +343,10 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
       }
       __syncthreads();
       const int nch = A.n_chunks;
+      const float inv_nch = 1.0f / (float)nch, inv_nm = 1.0f / (float)A.n_mels;
 #pragma unroll 1
       for (int task = tid; task < FB * nch; task += 256) {
-        const int fi = task >= nch ? 1 : 0, c = task - fi * nch;
+        const int fi = frame_of(task, nch, inv_nch), c = task - fi * nch;
         const float* __restrict__ mrow = mag + fi * (M + 1) + mtab[c];
         const float4* __restrict__ wq = reinterpret_cast<const float4*>(melw + 16 * c);
         float acc = 0.f;
@@ -333,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void stft_generic_tiled_kernel(const Gen2Ar
       __syncthreads();
       float* __restrict__ mel0 = A.mel + ((int64_t)row * n_out + f0) * A.n_mels;
       for (int task = tid; task < FB * A.n_mels; task += 256) {
-        const int fi = task >= A.n_mels ? 1 : 0, m = task - fi * A.n_mels;
+        const int fi = frame_of(task, A.n_mels, inv_nm), m = task - fi * A.n_mels;
         const int c0 = mtab[nch + 2 * m], cn = mtab[nch + 2 * m + 1];
         float acc = 0.f;
         for (int c = 0; c < cn; ++c) acc += part[fi * nch + c0 + c];
@@ -995,7 +1025,20 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
                  hipStream_t st) {
   static const int force_old = env_int_once("AT_STFT_GENERIC_OLD", 0);    // A/B: the round-2 one-frame-per-workgroup kernel
   const int M = n_fft / 2;
-  const int FBv = M <= gfft::TILE_POINTS / 2 ? 2 : 1;
+  // frames per tile: two for the hand-addressed M = 2048 plan, one above it; the run-time plan fills its 4096-point
+  // tile (round 4: n_fft 400 -> 20 frames, 1200 -> 6, 1920 -> 4; with two, a radix-25 pass of n_fft 400 had 16 of 256
+  // threads busy and the tile's barriers were most of its time), within what the row holds
+  int FBv = M <= gfft::TILE_POINTS / 2 ? 2 : 1;
+  static const int fb_cap = env_int_once("AT_STFT_GENERIC_FB", 64);       // A/B: 2 = the round-3 tile
+  if (M != 2048 && M <= gfft::TILE_POINTS / 2) {
+    int fb = gfft::TILE_POINTS / M;
+    if (fb > (gfft::TILE_POINTS + 2) / (M + 1)) fb = (gfft::TILE_POINTS + 2) / (M + 1);
+    if (fb > fb_cap) fb = fb_cap;
+    if (fb > n_frames_out) fb = (int)n_frames_out;
+    while (fb > 1 && T < (int64_t)n_fft + (int64_t)(fb - 1) * hop) --fb;
+    if (mel_out) while (fb > 2 && ((size_t)fb * M + 2 * (size_t)M + M / 2 + 2) * 8 + 64 + (size_t)n_chunks * (16 + 1 + fb) * 4 + (size_t)2 * n_mels * 4 > 160 * 1024) --fb;
+    FBv = fb < 1 ? 1 : fb;
+  }
   // the tiled kernel needs FB whole frames per row and an interior position for its clamped prefetch
   const bool tiled_ok = M <= gfft::TILE_POINTS && n_frames_out >= FBv && T >= (int64_t)n_fft + (int64_t)(FBv - 1) * hop &&
                         (int64_t)n_frames_out * hop + n_fft < (1LL << 31);
@@ -1010,7 +1053,10 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
     G.tiles_per_row = (n_frames_out + G.FB - 1) / G.FB;
     G.total_tiles = rows * G.tiles_per_row;
     G.vec2 = ((T % 2) == 0 && (hop % 2) == 0 && (M % 2) == 0 && (reinterpret_cast<uintptr_t>(x) % 8) == 0) ? 1 : 0;
+    static const int small_plans = env_int_once("AT_STFT_GENERIC_PLANS", 1);     // A/B: 0 = run-time plan for the speech windows
     const int plan = (M == 2048 && G.FB == 2) ? 1 : (M == 4096 ? 2 : 0);
+    // compile-time pass lists of the speech windows (full tiles only; their factorisation is what gfft::factor returns)
+    const int splan = !small_plans ? 0 : (M == 200 && G.FB == 20) ? 3 : (M == 600 && G.FB == 6) ? 4 : (M == 960 && G.FB == 4) ? 5 : 0;
     // transform buffer (+ |X| slack), pass twiddles, [window: run-time plans only], split twiddles
     static const int old_tile = env_int_once("AT_STFT_TILED_OLD", 0);      // A/B: the generic tile for the fixed plans
     // hand-addressed tile (its mel stage holds <= 3 chunk tasks per thread)
@@ -1029,6 +1075,9 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
                                                    : reinterpret_cast<const void*>(stft_tiled_pow2_kernel<2, false>)))
                     : plan == 1 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<1>)
                     : plan == 2 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<2>)
+                    : splan == 3 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<3>)
+                    : splan == 4 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<4>)
+                    : splan == 5 ? reinterpret_cast<const void*>(stft_generic_tiled_kernel<5>)
                                 : reinterpret_cast<const void*>(stft_generic_tiled_kernel<0>);
     int e = allow_big_lds(kfn);
     if (e != AT_OK) return e;
@@ -1036,7 +1085,7 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
     int per_cu = (int)((160 * 1024) / lds);
     // the hand-addressed tile needs ~155 registers: three workgroups (12 waves) per CU where the LDS allows it (M = 2048 without mel)
     static const int cap_env = env_int_once("AT_STFT_TILED_WGS", 0);         // A/B
-    const int cap = cap_env > 0 ? cap_env : (pow2 ? 3 : 2);
+    const int cap = cap_env > 0 ? cap_env : (pow2 ? 3 : (splan ? AT_GENERIC_SMALL_WGS : 2));
     per_cu = per_cu > cap ? cap : (per_cu < 1 ? 1 : per_cu);
     int64_t blocks = (int64_t)n_cu * per_cu;
     if (blocks > G.total_tiles) blocks = G.total_tiles;
@@ -1058,6 +1107,9 @@ int stft_generic(const float* x, int64_t rows, int64_t T, const float* window, c
     else if (pow2) hipLaunchKernelGGL((stft_tiled_pow2_kernel<2, false>), dim3((unsigned)blocks), dim3(256), lds, st, G);
     else if (plan == 1) hipLaunchKernelGGL(stft_generic_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, G);
     else if (plan == 2) hipLaunchKernelGGL(stft_generic_tiled_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+    else if (splan == 3) hipLaunchKernelGGL(stft_generic_tiled_kernel<3>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+    else if (splan == 4) hipLaunchKernelGGL(stft_generic_tiled_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+    else if (splan == 5) hipLaunchKernelGGL(stft_generic_tiled_kernel<5>, dim3((unsigned)blocks), dim3(256), lds, st, G);
     else hipLaunchKernelGGL(stft_generic_tiled_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, st, G);
     AT_LAUNCH_CHECK();
     return AT_OK;

@@ -1273,6 +1273,22 @@ def test_stft_generic_sizes_vs_oracle(n_fft, hop, wt):
         assert rel_err(y, yr) < REL and float((y.cpu() - x).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("sr,n_fft,hop,T", [(16000, 400, 160, 32000 + 3), (16000, 400, 160, 400 + 5 * 160), (16000, 400, 100, 20000),
+                                            (24000, 1200, 300, 48000), (48000, 1920, 480, 96000 + 1), (8000, 100, 33, 12345),
+                                            (44100, 882, 441, 44100)])
+def test_stft_generic_many_frames_per_tile(sr, n_fft, hop, T):
+    """The run-time-plan tile holds as many frames as fit 4096 complex points (round 4: 20 at n_fft 400, 6 at 1200, 4 at
+    1920, 64 at 100): rows long enough for full tiles, rows whose frame count is not a multiple of the tile (the last tile
+    overlaps its predecessor), a row that holds fewer frames than a tile, spectrum and fused mel against the oracle."""
+    x = synth.audio_batch(3, 2, T, seed=T + n_fft, gaps=False, sample_rate=sr)
+    s = A.AudioSignal(x.clone(), sr).to("cuda")
+    ref = restate.stft(x, n_fft, hop, "hann")
+    assert rel_err(s.stft(n_fft, hop, "hann"), ref) < REL
+    mel = s.mel_spectrogram(40, window_length=n_fft, hop_length=hop, window_type="hann")
+    assert rel_err(mel, restate.mel_spectrogram(ref, sr, 40)) < REL
+    assert rel_err(s.stft_data, ref) < REL
+
+
 @pytest.mark.parametrize("n_fft,T,B", [(4096, 96000 + 1, 3), (4096, 3 * 1024, 2), (4096, 200000, 5), (8192, 9 * 8192 + 5, 2),
                                        (8192, 6000, 1)])
 def test_istft_tiled_sizes(n_fft, T, B):
