@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, (PLAN >= 3 ? AT_GENERIC_SMALL_WGS : 2)) void s
         if (k == 0 || k == M) X.y = 0.f;                  // exactly real
         if (POW2 && it < G2_KB - 1) orow[e] = X;          // frame f0 + 1 follows frame f0: e indexes both rows
         else if (e < nbins) orow[e] = X;
-        mg[it] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));
+        if (MEL) mg[it] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));     // (uniform: no quarter-rate sqrt without a mel stage)
       }
     }
     if (MEL) {
