@@ -965,6 +965,106 @@ __global__ __launch_bounds__(256, 2) void istft_tiled_pow2_kernel(const GenInv2A
   }
 }
 
+// Inverse frames, many per tile (round 4): the speech windows (n_fft 400 / 1200 / 1920) spent 4.3-6.8 ms per 512 x 10 s rows
+// in the one-frame-per-workgroup kernel below (200 of 256 threads fold, 8-24 carry a butterfly, six barriers per frame)
+// against 0.7-2.5 ms for the forward tile.  Same cure as the forward: FB consecutive frames (frames are contiguous in the
+// spectrum AND in the frame buffer, across rows too, so a tile is one contiguous read and one contiguous write) share the
+// in-place batched passes of generic_fft.h.  a[k] = conj(Z[k]) -> forward FFT -> conj: istft_frames_kernel's identity.
+struct GenInvTileArgs {
+  const float2* X;       // (total, M + 1)
+  const float* window;
+  const float2* tw;      // (N): (cos, -sin)(2 pi k / N)
+  float* frames;         // (total, N)
+  int64_t total;         // rows * n_frames
+  int M, FB;
+  at::gfft::PassList pl;
+};
+
+constexpr int GI_LOADS = at::gfft::TILE_POINTS / 256;
+
+template <int PLAN>
+__global__ __launch_bounds__(256, 3) void istft_frames_generic_tiled_kernel(const GenInvTileArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
+  const int M = PLAN == 3 ? 200 : PLAN == 4 ? 600 : PLAN == 5 ? 960 : A.M;
+  const int FB = PLAN == 3 ? 20 : PLAN == 4 ? 6 : PLAN == 5 ? 4 : A.FB;
+  float2* buf = gbuf;                 // [FB][M]
+  float2* tw = gbuf + FB * M;         // [M]: pass blocks of w_M
+  float2* win = tw + M;               // [M]: window pairs
+  float2* ftw = win + M;              // [M]: fold twiddles w_N^k
+  at::gfft::build_pass_twiddles<256>(tw, A.tw, 2, M, A.pl);
+  for (int i = threadIdx.x; i < M; i += 256) {
+    win[i] = reinterpret_cast<const float2*>(A.window)[i];
+    ftw[i] = A.tw[i];
+  }
+  __syncthreads();
+  const at::gfft::RowLayoutN lay{M, (M & 15) == 0 ? 1 : 0};
+  const int npts = FB * M;
+  const float inv_M = 1.0f / (float)M, inv_n = 1.0f / (float)(2 * M);
+  const int64_t n_tiles = (A.total + FB - 1) / FB;
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    // the last tile is moved back to hold FB whole frames (its first frames are written twice, same values)
+    const int64_t g0 = min(t * FB, A.total - FB);
+    const float2* __restrict__ Xt = A.X + g0 * (M + 1);
+    float2 xa[GI_LOADS], xm[GI_LOADS];
+#pragma unroll
+    for (int i = 0; i < GI_LOADS; ++i) {
+      if (256 * i < npts) {                                 // uniform; lanes past the end repeat the last point
+        const int e = min(tid + 256 * i, npts - 1);
+        const int fi = (int)(((float)e + 0.5f) * inv_M), k = e - fi * M;
+        const float2* __restrict__ Xf = Xt + fi * (M + 1);
+        xa[i] = Xf[k];
+        xm[i] = Xf[M - k];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GI_LOADS; ++i) {
+      if (256 * i < npts) {
+        const int e = min(tid + 256 * i, npts - 1);
+        const int fi = (int)(((float)e + 0.5f) * inv_M), k = e - fi * M;
+        float2 a = xa[i], m = xm[i];
+        if (k == 0) { a.y = 0.f; m.y = 0.f; }               // c2r ignores the imaginary part of DC and Nyquist
+        const float2 w = ftw[k];
+        const float c = w.x, s = -w.y;
+        const float sr = a.x + m.x, si = a.y - m.y;
+        const float dr = a.x - m.x, di = a.y + m.y;
+        const float zr = sr - s * dr - c * di;
+        const float zi = si + c * dr - s * di;
+        buf[lay.addr(fi, k)] = make_float2(zr, -zi);
+      }
+    }
+    __syncthreads();
+    if constexpr (PLAN == 3) {
+      at::gfft::pass_inplace<25, 1, 256>(buf, tw, 200, 1, 160, lay);
+      at::gfft::pass_inplace<8, 2, 256>(buf, tw, 200, 25, 500, lay);
+    } else if constexpr (PLAN == 4) {
+      at::gfft::pass_inplace<25, 1, 256>(buf, tw, 600, 1, 144, lay);
+      at::gfft::pass_inplace<3, 5, 256>(buf, tw, 600, 25, 1200, lay);
+      at::gfft::pass_inplace<8, 2, 256>(buf, tw + 50, 600, 75, 450, lay);
+    } else if constexpr (PLAN == 5) {
+      at::gfft::pass_inplace<5, 3, 256>(buf, tw, 960, 1, 768, lay);
+      at::gfft::pass_inplace<3, 5, 256>(buf, tw, 960, 5, 1280, lay);
+      at::gfft::pass_inplace<16, 1, 256>(buf, tw + 10, 960, 15, 240, lay);
+      at::gfft::pass_inplace<4, 4, 256>(buf, tw + 235, 960, 240, 960, lay);
+    } else {
+      at::gfft::run_passes<256>(buf, tw, M, A.pl, FB, lay);
+    }
+    float2* __restrict__ out = reinterpret_cast<float2*>(A.frames) + g0 * M;
+#pragma unroll
+    for (int i = 0; i < GI_LOADS; ++i) {
+      const int e = tid + 256 * i;
+      if (e < npts) {
+        const int fi = (int)(((float)e + 0.5f) * inv_M), n = e - fi * M;
+        const float2 y = buf[lay.addr(fi, n)];
+        const float2 w = win[n];
+        out[e] = make_float2(y.x * inv_n * w.x, -y.y * inv_n * w.y);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void istft_frames_generic_kernel(const GenInvArgs A) {
   extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
   const int M = A.M, N = 2 * M;
@@ -1172,6 +1272,41 @@ int istft_tiled(const float* X, int64_t rows, int64_t n_x, const float* window, 
 
 int istft_frames_generic(const float* X, int64_t rows, int64_t n_frames, const float* window, const float* twiddles,
                          int n_fft, float* frames, hipStream_t st) {
+  const int Mh = n_fft / 2;
+  const int64_t total_frames = rows * n_frames;
+  static const int tiled_off = env_int_once("AT_ISTFT_GENERIC_OLD", 0);    // A/B: the one-frame-per-workgroup kernel
+  if (!tiled_off && Mh <= gfft::TILE_POINTS && total_frames > 0) {
+    GenInvTileArgs G;
+    if (!gfft::factor(Mh, &G.pl)) return AT_ERR_UNSUPPORTED;
+    int fb = gfft::TILE_POINTS / Mh;
+    if (fb > 64) fb = 64;
+    if (fb > total_frames) fb = (int)total_frames;
+    G.X = reinterpret_cast<const float2*>(X); G.window = window; G.tw = reinterpret_cast<const float2*>(twiddles);
+    G.frames = frames; G.total = total_frames; G.M = Mh; G.FB = fb;
+    static const int small_plans = env_int_once("AT_STFT_GENERIC_PLANS", 1);
+    const int splan = !small_plans ? 0 : (Mh == 200 && fb == 20) ? 3 : (Mh == 600 && fb == 6) ? 4 : (Mh == 960 && fb == 4) ? 5 : 0;
+    const void* kfn = splan == 3 ? reinterpret_cast<const void*>(istft_frames_generic_tiled_kernel<3>)
+                    : splan == 4 ? reinterpret_cast<const void*>(istft_frames_generic_tiled_kernel<4>)
+                    : splan == 5 ? reinterpret_cast<const void*>(istft_frames_generic_tiled_kernel<5>)
+                                 : reinterpret_cast<const void*>(istft_frames_generic_tiled_kernel<0>);
+    const size_t lds_t = ((size_t)fb * Mh + 3 * (size_t)Mh) * sizeof(float2);
+    int e = allow_big_lds(kfn);
+    if (e != AT_OK) return e;
+    int per_cu = (int)((160 * 1024) / lds_t);
+    // the fixed plans need 74-90 registers (5-6 waves per SIMD): four workgroups where the LDS allows; the run-time plan 168
+    static const int cap_env = env_int_once("AT_ISTFT_GENERIC_WGS", 0);      // A/B
+    const int cap = cap_env > 0 ? cap_env : (splan ? 4 : 3);
+    per_cu = per_cu > cap ? cap : (per_cu < 1 ? 1 : per_cu);
+    const int64_t n_tiles = (total_frames + fb - 1) / fb;
+    int64_t blocks = (int64_t)device_cu_count() * per_cu;
+    if (blocks > n_tiles) blocks = n_tiles;
+    if (splan == 3) hipLaunchKernelGGL(istft_frames_generic_tiled_kernel<3>, dim3((unsigned)blocks), dim3(256), lds_t, st, G);
+    else if (splan == 4) hipLaunchKernelGGL(istft_frames_generic_tiled_kernel<4>, dim3((unsigned)blocks), dim3(256), lds_t, st, G);
+    else if (splan == 5) hipLaunchKernelGGL(istft_frames_generic_tiled_kernel<5>, dim3((unsigned)blocks), dim3(256), lds_t, st, G);
+    else hipLaunchKernelGGL(istft_frames_generic_tiled_kernel<0>, dim3((unsigned)blocks), dim3(256), lds_t, st, G);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+  }
   GenInvArgs A;
   A.npass = generic_fft_plan(n_fft, A.radix);
   if (A.npass == 0) return AT_ERR_UNSUPPORTED;

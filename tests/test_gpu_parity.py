@@ -1287,6 +1287,11 @@ def test_stft_generic_many_frames_per_tile(sr, n_fft, hop, T):
     mel = s.mel_spectrogram(40, window_length=n_fft, hop_length=hop, window_type="hann")
     assert rel_err(mel, restate.mel_spectrogram(ref, sr, 40)) < REL
     assert rel_err(s.stft_data, ref) < REL
+    # ... and back: the inverse frames share tiles the same way (istft_frames_generic_tiled_kernel; tiles run across rows,
+    # the last one is moved back to hold whole frames), against the oracle's istft of the oracle's spectrum and against x
+    y = s.istft(n_fft, hop, "hann").audio_data
+    assert rel_err(y, restate.istft(ref, n_fft, hop, "hann", False, T)) < REL
+    assert float((y.cpu() - x).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("n_fft,T,B", [(4096, 96000 + 1, 3), (4096, 3 * 1024, 2), (4096, 200000, 5), (8192, 9 * 8192 + 5, 2),
@@ -1431,7 +1436,8 @@ def test_stft_mel_structured_inputs(sr, n_fft, hop):
     _bounded_by_torch(mel.cpu(), mel32, mel64, f"mel {n_fft}/{hop}")
 
 
-@pytest.mark.parametrize("sr,n_fft,hop", [(44100, 2048, 512), (16000, 512, 128), (22050, 1024, 256)])
+@pytest.mark.parametrize("sr,n_fft,hop", [(44100, 2048, 512), (16000, 512, 128), (22050, 1024, 256), (16000, 400, 160),
+                                          (48000, 1920, 480)])
 def test_istft_structured_inputs(sr, n_fft, hop):
     from audiotools_amd import tables
     x = synth.structured_batch(40000, sr)

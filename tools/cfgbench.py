@@ -56,6 +56,12 @@ kw = A.util.prepare_batch(kw, dev)
 kc = kw["Compose"]
 # (nothing below writes into x: every stage produces a new tensor, as in bench.py's cfg4 step)
 if "lowpass" in only:
+    if os.environ.get("CFGBENCH_PROFILE"):
+        import cProfile, pstats
+        A.AudioSignal(x, SR).low_pass(kc["0.LowPass"]["cutoff"]); torch.cuda.synchronize()
+        pr = cProfile.Profile(); pr.enable()
+        A.AudioSignal(x, SR).low_pass(kc["0.LowPass"]["cutoff"]); torch.cuda.synchronize()
+        pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
     timed(lambda: A.AudioSignal(x, SR).low_pass(kc["0.LowPass"]["cutoff"]), "cfg4 low_pass (B per-item cutoffs)")
 if "eq" in only:
     timed(lambda: A.AudioSignal(x, SR).equalizer(kc["1.Equalizer"]["eq"]), "cfg4 equalizer (6 bands)")
