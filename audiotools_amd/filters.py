@@ -94,6 +94,22 @@ def fir_adjoint(g: torch.Tensor, tp: torch.Tensor, L: int, highpass: bool, fir) 
     return (g - z) if highpass else z
 
 
+class _NativeResample(torch.autograd.Function):
+    """``kernels.resample`` with its exact adjoint with respect to the audio on the same family of kernels: the transposed
+    polyphase sum is again a polyphase sum with the two rates swapped (``tables.resample_adjoint_bank``), followed by the
+    fold of the replicate padding (reference: ``resample`` stays differentiable, tests/core/test_grad.py:62)."""
+
+    @staticmethod
+    def forward(ctx, audio, old_sr, new_sr):
+        ctx.rates = (int(old_sr), int(new_sr), int(audio.shape[-1]))
+        return kernels.resample(audio.detach(), int(old_sr), int(new_sr))
+
+    @staticmethod
+    def backward(ctx, g):
+        old_sr, new_sr, T = ctx.rates
+        return kernels.resample_adjoint(g.contiguous(), old_sr, new_sr, T), None, None
+
+
 def fir_native_or_grad(audio: torch.Tensor, tp: torch.Tensor, L: int, highpass: bool = False) -> torch.Tensor:
     """The FIR kernels on a padded tap table (kernels.sinc_taps_native / eq_taps_native), differentiable in ``audio``."""
     if needs_native_grad(audio):
@@ -164,6 +180,9 @@ class DSPMixin:
         audio = self.audio_data
         if kernels.is_native(audio) and kernels.resample_supported(self.sample_rate, int(sample_rate)):
             self.audio_data = kernels.resample(audio, self.sample_rate, int(sample_rate))
+        elif (needs_native_grad(audio) and audio.ndim == 3
+              and kernels.resample_adjoint_supported(self.sample_rate, int(sample_rate))):
+            self.audio_data = _NativeResample.apply(audio, self.sample_rate, int(sample_rate))
         else:
             self.audio_data = resample_torch(audio, self.sample_rate, int(sample_rate))
         self.sample_rate = sample_rate

@@ -33,6 +33,70 @@ def _roll_to_peak(ir: torch.Tensor) -> torch.Tensor:
     return torch.gather(ir, -1, src)
 
 
+def _index_reversed(t: torch.Tensor) -> torch.Tensor:
+    """t[(-n) mod T]: circular correlation with t is circular convolution with this."""
+    return torch.roll(torch.flip(t, (-1,)), 1, -1)
+
+
+class _NativeCircConv(torch.autograd.Function):
+    """y = scale * (x circ-conv w) at length T on the native convolution (``kernels.fftconv``: four-step FFT or rocFFT),
+    with its adjoints on the same kernel (reference: ``convolve`` / ``apply_ir`` stay differentiable,
+    tests/core/test_grad.py:47-52; effects.py:102-111):
+        dL/dx = scale * (g circ-conv w~),   dL/dw = scale * (g circ-conv x~)  (summed over the channels one IR serves),
+        dL/dscale = sum_n g y / scale,       t~[n] = t[(-n) mod T].
+    x (B, C, T), w (B, 1 | C, T), scale (B, 1 | C, 1); batch / channel broadcasting is done by the caller with
+    ``expand`` (autograd sums it back)."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale):
+        y = kernels.fftconv(x.detach(), w.detach(), scale.detach())
+        ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, w if ctx.needs_input_grad[0] else None, scale,
+                              y if ctx.needs_input_grad[2] else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, scale, y = ctx.saved_tensors
+        g = g.contiguous()
+        one_ir = scale.shape[1] == 1 and g.shape[1] != 1
+        gx = gw = gs = None
+        if ctx.needs_input_grad[0]:
+            gx = kernels.fftconv(g, _index_reversed(w.detach()), scale.detach())
+        if ctx.needs_input_grad[1]:
+            gw = kernels.fftconv(g, _index_reversed(x.detach()), None) * scale.detach()
+            if one_ir:
+                gw = gw.sum(1, keepdim=True)
+        if ctx.needs_input_grad[2]:
+            gs = (g * y).sum(-1, keepdim=True)
+            if one_ir:
+                gs = gs.sum(1, keepdim=True)
+            gs = gs / scale.detach()
+        return gx, gw, gs
+
+
+def _circ_conv_with_grad(x: torch.Tensor, ir: torch.Tensor, start_at_max: bool) -> torch.Tensor:
+    """The convolution of ``_convolve`` for HIP float32 tensors of which one wants a gradient: the rotation to the peak
+    and the 1 / max|ir| scale by the kernels when the IR is a constant, by (differentiable) torch ops when it is not."""
+    T = x.shape[-1]
+    if ir.requires_grad and torch.is_grad_enabled():
+        if start_at_max:
+            ir = _roll_to_peak(ir)
+        scale = 1 / ir.abs().max(dim=-1, keepdim=True)[0].clamp(1e-5)
+    else:
+        peak, idx = kernels.absmax(ir, want_index=True)
+        if start_at_max:
+            if ir.shape[1] != 1:
+                raise RuntimeError("start_at_max requires a single-channel impulse response")
+            ir = kernels.roll_pad(ir, idx, T)
+        scale = 1 / peak[..., None].clamp(1e-5)
+    B, C = x.shape[0], x.shape[1]
+    if ir.shape[0] != B:
+        ir, scale = ir.expand(B, -1, -1), scale.expand(B, -1, -1)
+    if ir.shape[1] not in (1, C):
+        x = x.expand(-1, ir.shape[1], -1)
+    return _NativeCircConv.apply(x, ir, scale)
+
+
 def _peak(x: torch.Tensor) -> torch.Tensor:
     """max |x| over time, keepdim -- one fused pass on the HIP path."""
     if kernels.is_native(x):
@@ -244,6 +308,10 @@ class EffectMixin:
             if ir.shape[1] not in (1, C):
                 x = x.expand(-1, ir.shape[1], -1)
             y = kernels.fftconv(x, ir, scale)
+        elif ((filters.needs_native_grad(x) or filters.needs_native_grad(ir)) and x.is_cuda and ir.is_cuda
+              and x.dtype == torch.float32 and ir.dtype == torch.float32 and _conv_shapes_ok(x, ir)):
+            # a gradient is wanted: the same kernels under autograd (_NativeCircConv) instead of the rFFT formulation
+            y = _circ_conv_with_grad(x, ir, start_at_max)
         else:
             if start_at_max:
                 ir = _roll_to_peak(ir)

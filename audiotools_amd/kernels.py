@@ -799,6 +799,45 @@ def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
     return out
 
 
+def resample_adjoint(gy: torch.Tensor, old_sr: int, new_sr: int, T: int) -> torch.Tensor:
+    """dL/dx (B, C, T) of ``resample`` from dL/dy (B, C, floor(new T / old)): the transposed polyphase sum on the SAME
+    kernel (``at_resample_f32`` with the rates swapped and ``tables.resample_adjoint_bank``), then the replicate padding
+    folded back (everything the padded positions received goes to x[0] / x[T - 1])."""
+    _require_native_ok(gy)
+    g = math.gcd(int(old_sr), int(new_sr))
+    if int(old_sr) // g == int(new_sr) // g:
+        return gy
+    wg_np, base_np, old, new, width, NG, LG, J = tables.resample_adjoint_bank(int(old_sr) // g, int(new_sr) // g)
+    dev = gy.device
+    B, C, n = gy.shape
+    # one zero sample on either side: the kernel's replicate padding then repeats zeros
+    gin = torch.zeros((B, C, n + 2), dtype=torch.float32, device=dev)
+    gin[..., 1: n + 1] = gy
+    Lp = T + 2 * width + old
+    out = torch.empty((B, C, Lp), dtype=torch.float32, device=dev)
+    wg, base = tables.device_table(("resample_adjoint", old, new), dev, lambda: (wg_np, base_np))
+    code = _native.lib().at_resample_f32(_native.ptr(gin), B * C, n + 2, _native.ptr(wg), _native.ptr(base), new, old,
+                                         J * new - 1, NG, LG, _native.ptr(out), Lp, _native.current_stream(dev))
+    _native.check(code, "at_resample_f32 (adjoint)")
+    gx = out[..., width: width + T].clone()
+    gx[..., 0] += out[..., :width].sum(-1)
+    gx[..., T - 1] += out[..., width + T:].sum(-1)
+    return gx
+
+
+def resample_adjoint_supported(old_sr: int, new_sr: int) -> bool:
+    """The transposed bank fits the kernel's LDS tile (roles swapped: the input advances by ``new`` per frame)."""
+    g = math.gcd(int(old_sr), int(new_sr))
+    old, new = int(old_sr) // g, int(new_sr) // g
+    if old == new:
+        return True
+    if not resample_supported(old_sr, new_sr) or old * new > (1 << 22):
+        return False
+    plan = tables.resample_adjoint_bank(old, new)
+    J, LG = plan[7], plan[6]
+    return (4 * new + 2 * (J * new - 1) + LG + 8) * 4 <= RESAMPLE_LDS_LIMIT
+
+
 _LONGCONV = os.environ.get("AT_LONGCONV", "1") != "0"       # development A/B switch, read once
 
 

@@ -476,6 +476,65 @@ def resample_grouped_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: fl
     return np.ascontiguousarray(wg.transpose(1, 0, 2)), base, old, new, width, NG, LG
 
 
+def group_dense_bank(dense: np.ndarray):
+    """Any banded polyphase bank (phases, taps) in the layout of ``at_resample_f32``: phases grouped by 4, group G keeps
+    the taps base[G] .. base[G] + LG - 1 of the union support of its phases as float4 rows, tap-major.
+    Returns ``(wg float32 (LG, NG, 4), base int32 (NG,), NG, LG)``."""
+    P, K = dense.shape
+    thr = 1e-12 * np.abs(dense).max()
+    nzm = np.abs(dense) > thr
+    NG = (P + 3) // 4
+    lo = np.zeros(NG, dtype=np.int64)
+    hi = np.zeros(NG, dtype=np.int64)
+    for G in range(NG):
+        cols = np.nonzero(nzm[4 * G: 4 * G + 4].any(0))[0]
+        lo[G], hi[G] = (int(cols[0]), int(cols[-1]) + 1) if len(cols) else (0, 1)
+    LG = (int((hi - lo).max()) + 3) // 4 * 4
+    if LG > K:                                   # tiny banks: zero columns up to one block of 4
+        dense = np.concatenate([dense, np.zeros((P, LG - K), dtype=dense.dtype)], 1)
+        K = LG
+    base = np.minimum(lo, K - LG).astype(np.int32)
+    wg = np.zeros((NG, LG, 4), dtype=np.float32)
+    for G in range(NG):
+        for p in range(4):
+            i = 4 * G + p
+            if i < P:
+                seg = dense[i, base[G]: base[G] + LG].copy()
+                seg[np.abs(seg) <= thr] = 0.0
+                wg[G, :, p] = seg
+    return np.ascontiguousarray(wg.transpose(1, 0, 2)), base, NG, LG
+
+
+@functools.lru_cache(32)
+def resample_adjoint_bank(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float = 0.945):
+    """The TRANSPOSE of the resampler as a polyphase bank for the same kernel (``at_resample_f32`` with the roles of the
+    two rates swapped).  Forward (audio_signal.py:732 -> julius.resample_frac), with xp the replicate-padded input and
+    h = resample_bank (new, K):   y[f new + p] = sum_k h[p][k] xp[f old + k].
+    Its adjoint with respect to xp, position i = g old + q:
+        dxp[g old + q] = sum_j sum_p h[p][j old + q] dy[(g - j) new + p]  =  sum_m HT[q][m] dyz[g new + m],
+        m = (J - j) new + p,   HT[q][m] = h[m % new][(J - m // new) old + q]  (0 where that tap does not exist),
+        dyz[i] = dy[i - J new] (zero outside),  J >= (K - 1) // old.
+    -- ``old`` output phases per frame, the input advancing by ``new`` per frame, (J + 1) new taps: the kernel's own form.
+    Returns ``(wg, base, old, new, width, NG, LG, J)`` (reduced rates; ``width`` is the FORWARD padding) or None for
+    equal rates."""
+    plan = resample_bank(old_sr, new_sr, zeros, rolloff)
+    if plan is None:
+        return None
+    bank, old, new, width = plan
+    h = bank.numpy()
+    K = h.shape[1]
+    J = (K - 1) // old
+    if J * new < 2:                 # the kernel needs a left padding >= 1 on top of the one zero sample in front of dy
+        J += 1
+    HT = np.zeros((old, (J + 1) * new), dtype=np.float32)
+    for j in range(J + 1):
+        ks = j * old + np.arange(old)
+        ok = ks < K
+        HT[ok, (J - j) * new: (J - j + 1) * new] = h[:, ks[ok]].T
+    wg, base, NG, LG = group_dense_bank(HT)
+    return wg, base, old, new, width, NG, LG, J
+
+
 # K-slot -> tap offset inside a 32-tap chunk of the MFMA resampler: MFMA number s (0..7) of a chunk
 # consumes taps s + MFMA_KOFF[k], k = lane // 16.  Offsets 0/16 (lanes 0-31) and 8/24 (lanes 32-63)
 # make the 32 lanes of a ds_read_b32 group hit 32 distinct banks for every odd ``old``:

@@ -177,6 +177,72 @@ def test_fir_family_native_gradient_vs_float64(op):
     assert rel_err(g32, g64) < REL
 
 
+@pytest.mark.parametrize("old,new,T", [(44100, 16000, 30000), (16000, 44100, 9000), (48000, 44100, 20001), (16000, 8000, 777)])
+def test_resample_native_gradient_vs_float64(old, new, T):
+    """resample() on a HIP tensor that requires grad stays on the kernels (filters._NativeResample: forward kernel, the
+    transposed polyphase sum on the VALU kernel with the rates swapped, the replicate padding folded back;
+    tests/core/test_grad.py:62): value and dL/daudio against the torch formulation evaluated in float64."""
+    from audiotools_amd import filters, tables
+    x = synth.audio_batch(3, 2, T, seed=old % 97 + T, gaps=False, sample_rate=old)
+    x64 = x.double().clone().requires_grad_(True)
+    bank, o, n, width = tables.resample_bank(old, new)
+    xp = torch.nn.functional.pad(x64.reshape(-1, 1, T), (width, width + o), mode="replicate")
+    y64 = torch.nn.functional.conv1d(xp, bank.double()[:, None], stride=o).transpose(1, 2).reshape(3, 2, -1)[..., : n * T // o]
+    wgt = torch.randn(y64.shape, generator=torch.Generator().manual_seed(5))
+    (g64,) = torch.autograd.grad((y64 * wgt.double()).sum(), x64)
+    a = x.cuda().clone().requires_grad_(True)
+    y32 = A.AudioSignal(a, old).resample(new).audio_data
+    assert "NativeResample" in type(y32.grad_fn).__name__, type(y32.grad_fn).__name__
+    (g32,) = torch.autograd.grad((y32 * wgt.cuda()).sum(), a)
+    assert y32.shape == y64.shape
+    assert rel_err(y32.detach(), y64.detach()) < REL
+    assert rel_err(g32, g64) < REL
+
+
+@pytest.mark.parametrize("T,L,Cir,ir_grad", [(24000, 8000, 1, False), (24000, 8000, 1, True), (16384, 5000, 1, False),
+                                             (9000, 9000, 1, False)])
+def test_convolve_apply_ir_native_gradient_vs_float64(T, L, Cir, ir_grad):
+    """convolve() / apply_ir() with a HIP signal that requires grad keep the native convolution (fx._NativeCircConv:
+    forward kernel, adjoints = the same kernel on index-reversed operands; tests/core/test_grad.py:47-52): values and
+    gradients against the rFFT formulation of effects.py:86-121 in float64."""
+    sr = 16000
+    x = synth.audio_batch(3, 2, T, seed=T + L, gaps=False, sample_rate=sr)
+    gen = torch.Generator().manual_seed(11)
+    ir = torch.randn(3, Cir, L, generator=gen) * torch.exp(-torch.arange(L) / (L / 6.0))
+    ir[:, :, 37] = 3.0                                             # a clear peak away from index 0
+    wgt = torch.randn(3, 2, T, generator=gen)
+
+    def f64(xx, ii):
+        ii = torch.nn.functional.pad(ii, (0, T - L))
+        idx = ii.abs().argmax(-1, keepdim=True)
+        ii = torch.gather(ii, -1, (torch.arange(T)[None, None] + idx) % T)
+        ii = ii / ii.abs().max(-1, keepdim=True)[0].clamp(1e-5)
+        return torch.fft.irfft(torch.fft.rfft(ii, T) * torch.fft.rfft(xx, T), T)
+
+    x64, i64 = x.double().clone().requires_grad_(True), ir.double().clone().requires_grad_(True)
+    y64 = f64(x64, i64)
+    gx64, gi64 = torch.autograd.grad((y64 * wgt.double()).sum(), (x64, i64))
+    a = x.cuda().clone().requires_grad_(True)
+    b = ir.cuda().clone().requires_grad_(ir_grad)
+    y32 = A.AudioSignal(a, sr).convolve(A.AudioSignal(b, sr)).audio_data
+    assert "NativeCircConv" in type(y32.grad_fn).__name__, type(y32.grad_fn).__name__
+    grads = torch.autograd.grad((y32 * wgt.cuda()).sum(), (a, b) if ir_grad else (a,))
+    assert rel_err(y32.detach(), y64.detach()) < REL
+    assert rel_err(grads[0], gx64) < REL
+    if ir_grad:
+        assert rel_err(grads[1], gi64) < REL
+    # apply_ir = convolve + peak restoration (torch ops around the same Function)
+    a2 = x.cuda().clone().requires_grad_(True)
+    y_ir = A.AudioSignal(a2, sr).apply_ir(A.AudioSignal(ir.cuda().clone(), sr)).audio_data
+    x64b = x.double().clone().requires_grad_(True)
+    yb = f64(x64b, ir.double())
+    yb = yb * (x64b.abs().amax(-1, keepdim=True).clamp(1e-8) / yb.abs().amax(-1, keepdim=True).clamp(1e-8))
+    (gb,) = torch.autograd.grad((yb * wgt.double()).sum(), x64b)
+    (ga,) = torch.autograd.grad((y_ir * wgt.cuda()).sum(), a2)
+    assert rel_err(y_ir.detach(), yb.detach()) < REL
+    assert rel_err(ga, gb) < REL
+
+
 def test_mel_generic_size_short_clip_falls_back_to_dense_basis():
     """mel_spectrogram on generic transform sizes (4096 @ 96 kHz ...) goes to the banded mel stage of the TILED
     kernel; a clip that kernel does not take (shorter than its two-frame tile: T < n_fft + hop) must keep working through

@@ -453,3 +453,64 @@ def test_fir_adjoint_formula_equals_autograd():
         (gx,) = torch.autograd.grad(y, x, g)
         got = filters.fir_adjoint(g, tp, L, hp, lambda a, t: fir_cpu(a, t, L))
         assert float((got - gx).abs().max()) < 1e-12, (B, C, T, L, rows, hp)
+
+
+@pytest.mark.parametrize("old_sr,new_sr,T", [(44100, 16000, 1500), (16000, 44100, 400), (2, 1, 50), (1, 2, 50), (3, 2, 64)])
+def test_resample_adjoint_bank_is_the_transpose(old_sr, new_sr, T):
+    """tables.resample_adjoint_bank: the transposed resampler written as a polyphase bank for at_resample_f32 with the
+    rates swapped.  A numpy model of that kernel's sum (groups of 4 phases, dense taps from base[G], replicate padding by
+    `width`) on dL/dy with one zero sample on either side, then the fold of the padding, equals autograd's dL/dx of the
+    torch formulation in float64."""
+    import math
+    from audiotools_amd import tables
+    g = math.gcd(old_sr, new_sr)
+    wg, base, old, new, width, NG, LG, J = tables.resample_adjoint_bank(old_sr // g, new_sr // g)
+    assert J * new - 1 >= 1 and (base >= 0).all() and (base <= new + 2 * (J * new - 1)).all()
+    rng = np.random.default_rng(1)
+    x = torch.tensor(rng.standard_normal(T), dtype=torch.float64, requires_grad=True)
+    bank = tables.resample_bank(old_sr, new_sr)[0].double()
+    xp = torch.nn.functional.pad(x[None, None], (width, width + old), mode="replicate")
+    n = new * T // old
+    y = torch.nn.functional.conv1d(xp, bank[:, None], stride=old).transpose(1, 2).reshape(-1)[:n]
+    gy = rng.standard_normal(n)
+    (y * torch.from_numpy(gy)).sum().backward()
+    gin = np.concatenate([[0.0], gy, [0.0]])
+    Lp = T + 2 * width + old
+    wk = J * new - 1
+    frames = (Lp + old - 1) // old
+    out = np.zeros(frames * old)
+    for f in range(frames):
+        for G in range(NG):
+            idx = np.clip(f * new + base[G] + np.arange(LG) - wk, 0, len(gin) - 1)
+            v = gin[idx] @ wg[:, G, :].astype(np.float64)
+            for p in range(4):
+                if 4 * G + p < old:
+                    out[f * old + 4 * G + p] = v[p]
+    out = out[:Lp]
+    gx = out[width: width + T].copy()
+    gx[0] += out[:width].sum()
+    gx[-1] += out[width + T:].sum()
+    assert np.abs(gx - x.grad.numpy()).max() < 1e-12 * max(1.0, np.abs(x.grad.numpy()).max())
+
+
+def test_circular_convolution_adjoints(monkeypatch):
+    """fx._NativeCircConv's backward (the forward kernel on index-reversed operands, channel / scale reductions) against
+    autograd through the rFFT formulation, with a float64 torch stand-in for the kernel."""
+    from audiotools_amd import fx, kernels
+
+    def stand_in(x, ir, scale=None, engine=None):
+        T = x.shape[-1]
+        y = torch.fft.irfft(torch.fft.rfft(ir, T) * torch.fft.rfft(x, T), T)
+        return y if scale is None else y * scale.reshape(ir.shape[0], ir.shape[1], 1)
+
+    monkeypatch.setattr(kernels, "fftconv", stand_in)
+    torch.manual_seed(0)
+    for B, C, Cir, T in [(3, 2, 1, 50), (3, 2, 2, 51), (2, 1, 1, 64)]:
+        x = torch.randn(B, C, T, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(B, Cir, T, dtype=torch.float64, requires_grad=True)
+        s = (torch.rand(B, Cir, 1, dtype=torch.float64) + 0.5).requires_grad_(True)
+        g = torch.randn(B, C, T, dtype=torch.float64)
+        got = torch.autograd.grad((fx._NativeCircConv.apply(x, w, s) * g).sum(), (x, w, s))
+        ref = torch.autograd.grad((torch.fft.irfft(torch.fft.rfft(w, T) * torch.fft.rfft(x, T), T) * s * g).sum(), (x, w, s))
+        for a, b in zip(got, ref):
+            assert (a - b).abs().max() < 1e-11
