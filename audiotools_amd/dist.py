@@ -50,46 +50,65 @@ def barrier():
         dist.barrier()
 
 
-def broadcast_table(key, builder, device, src: int = 0):
-    """Build a table (numpy array / tuple of arrays) on ``src`` only, broadcast it, and install
-    it in the per-device table cache of every rank.  Returns the device tensor(s)."""
+def broadcast_tables(items, device, src: int = 0):
+    """Build every table of ``items`` = [(key, builder), ...] (numpy array / tuple of arrays each) on ``src`` only and
+    install them in the per-device table cache of every rank with TWO collectives for the whole list: one small object
+    broadcast (keys' shapes / dtypes / offsets) and one broadcast of a single packed byte buffer on ``device`` (RCCL on
+    HIP devices) -- not one pickled round trip + one broadcast per table.  Returns the list of device tensor(s)."""
     import numpy as np
 
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     if world == 1:
-        return tables.device_table(key, device, builder)
+        return [tables.device_table(key, device, builder) for key, builder in items]
     rank = dist.get_rank()
     meta = [None]
-    arrays = None
+    packed = None
     if rank == src:
-        val = builder()
-        arrays = list(val) if isinstance(val, tuple) else [val]
-        arrays = [np.ascontiguousarray(a) for a in arrays]
-        meta = [([(a.shape, str(a.dtype)) for a in arrays], isinstance(val, tuple))]
+        specs, chunks, off = [], [], 0
+        for _key, builder in items:
+            val = builder()
+            arrays = [np.ascontiguousarray(a) for a in (val if isinstance(val, tuple) else (val,))]
+            entry = []
+            for a in arrays:
+                entry.append((tuple(a.shape), str(a.dtype), off, a.nbytes))
+                chunks.append((off, a))
+                off = (off + a.nbytes + 255) // 256 * 256          # every table starts on a 256-byte boundary
+            specs.append((entry, isinstance(val, tuple)))
+        packed = np.zeros(max(off, 256), dtype=np.uint8)
+        for o, a in chunks:
+            packed[o: o + a.nbytes] = a.reshape(-1).view(np.uint8)
+        meta = [(specs, int(packed.size))]
     dist.broadcast_object_list(meta, src=src)
-    specs, is_tuple = meta[0]
+    specs, total = meta[0]
+    buf = torch.from_numpy(packed).to(device) if rank == src else torch.empty(total, dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src=src)
     out = []
-    for i, (shape, dtype) in enumerate(specs):
-        if rank == src:
-            t = torch.from_numpy(arrays[i]).to(device)
-        else:
-            t = torch.empty(shape, dtype=getattr(torch, dtype), device=device)
-        dist.broadcast(t, src=src)
-        out.append(t)
-    val = tuple(out) if is_tuple else out[0]
-    tables.install_table(key, device, val)
-    return val
+    for (key, _builder), (entry, is_tuple) in zip(items, specs):
+        ts = []
+        for shape, dtype, off, nbytes in entry:
+            t = buf[off: off + nbytes].view(getattr(torch, dtype)).reshape(shape).clone()     # own storage per table
+            ts.append(t)
+        val = tuple(ts) if is_tuple else ts[0]
+        tables.install_table(key, device, val)
+        out.append(val)
+    return out
+
+
+def broadcast_table(key, builder, device, src: int = 0):
+    """One table (see ``broadcast_tables``).  Returns the device tensor(s)."""
+    return broadcast_tables([(key, builder)], device, src)[0]
 
 
 def broadcast_stft_mel_tables(sample_rate, n_fft, window_type, n_mels, device, fmin=0.0, fmax=None):
     """The shared tables of the STFT+mel kernel: window, twiddles, mel unit tables (info, weights)."""
-    def tw():
-        return _twiddles_np(n_fft)
+    broadcast_tables(_stft_mel_items(sample_rate, n_fft, window_type, n_mels, fmin, fmax), device)
 
-    broadcast_table(("window", window_type, n_fft), lambda: tables.window_np(window_type, n_fft), device)
-    broadcast_table(("stft_tw", n_fft), tw, device)
-    broadcast_table(("mel_units", sample_rate, n_fft, n_mels, fmin, fmax),
-                    lambda: tables.mel_units_np(tables.mel_filters_np(sample_rate, n_fft, n_mels, fmin, fmax)), device)
+
+def _stft_mel_items(sample_rate, n_fft, window_type, n_mels, fmin=0.0, fmax=None):
+    return [(("window", window_type, n_fft), lambda: tables.window_np(window_type, n_fft)),
+            (("stft_tw", n_fft), lambda: _twiddles_np(n_fft)),
+            (("mel_units", sample_rate, n_fft, n_mels, fmin, fmax),
+             lambda: tables.mel_units_np(tables.mel_filters_np(sample_rate, n_fft, n_mels, fmin, fmax)))]
 
 
 def _twiddles_np(n_fft):
@@ -111,8 +130,8 @@ def broadcast_cfg4_tables(sample_rate, n_bands, device):
         b, _half = tables.band_split_bank(int(sample_rate), int(n_bands))
         return (b.numpy(),)
 
-    broadcast_table(("band_split_bank", int(sample_rate), int(n_bands)), bank, device)
-    broadcast_table(("stft_tw", 2048), lambda: _twiddles_np(2048), device)
+    broadcast_tables([(("band_split_bank", int(sample_rate), int(n_bands)), bank),
+                      (("stft_tw", 2048), lambda: _twiddles_np(2048))], device)
 
 
 def broadcast_cfg5_tables(old_sr, new_sr, n_fft, n_mels, device, window_type="hann", fmin=0.0, fmax=None):
@@ -136,16 +155,17 @@ def broadcast_cfg5_tables(old_sr, new_sr, n_fft, n_mels, device, window_type="ha
         W, lo = tables.resample_f16_bank(int(old_sr), int(new_sr))[:2]
         return (W.view(np.int32), lo)
 
+    items = []
     if old != new:
         # the bank of whichever kernel kernels.resample() dispatches to (odd reduced source rate:
         # the matrix-core forms -- fp16-split for 64..256 output phases --; otherwise the VALU form)
         if (old & 1) and 64 <= new <= 256:
-            broadcast_table(("resample_f16", old, new), f16_bank, device)
+            items.append((("resample_f16", old, new), f16_bank))
         elif old & 1:
-            broadcast_table(("resample_mfma", old, new), mfma_bank, device)
+            items.append((("resample_mfma", old, new), mfma_bank))
         else:
-            broadcast_table(("resample_grouped", old, new), bank, device)
-    broadcast_stft_mel_tables(int(new_sr), n_fft, window_type, n_mels, device, fmin, fmax)
+            items.append((("resample_grouped", old, new), bank))
+    broadcast_tables(items + _stft_mel_items(int(new_sr), n_fft, window_type, n_mels, fmin, fmax), device)
 
 
 def gather_items(local: torch.Tensor, n_items: int):

@@ -48,6 +48,27 @@ def _worker(rank, world, port, q):
     # a tuple-valued table
     tup = adist.broadcast_table(("t", 1), lambda: (np.arange(6, dtype=np.int32).reshape(3, 2), np.ones(4, np.float32)), device)
     assert tup[0].shape == (3, 2) and tup[0].dtype == torch.int32 and float(tup[1].sum()) == 4.0
+    # a whole configuration's tables in ONE packed broadcast (mixed dtypes, odd sizes, a tuple): only rank 0 builds them
+    items = [(("p", 0), lambda: np.arange(7, dtype=np.float32) if rank == 0 else None),
+             (("p", 1), lambda: (np.arange(5, dtype=np.int32), np.arange(3, dtype=np.uint32) + 7) if rank == 0 else None),
+             (("p", 2), lambda: np.linspace(0, 1, 301).astype(np.float64).reshape(7, 43) if rank == 0 else None)]
+    calls = {"n": 0}
+    real = dist.broadcast
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    dist.broadcast = counting
+    try:
+        got = adist.broadcast_tables(items, device)
+    finally:
+        dist.broadcast = real
+    assert calls["n"] == 1
+    assert torch.equal(got[0], torch.arange(7, dtype=torch.float32))
+    assert torch.equal(got[1][0], torch.arange(5, dtype=torch.int32)) and got[1][1].dtype == torch.uint32
+    assert got[2].shape == (7, 43) and got[2].dtype == torch.float64 and float(got[2][-1, -1]) == 1.0
+    assert tables.device_table(("p", 0), device, lambda: None) is got[0]          # installed in the cache
     # the data path: each rank processes its slab, no collective
     sig = A.AudioSignal(x[lo:hi].clone(), 16000)
     lufs_local = sig.loudness()
