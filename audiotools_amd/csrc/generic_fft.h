@@ -381,6 +381,13 @@ int64_t istft_tiled_workspace_floats(int64_t n_frames, int n_fft, int hop);
 int istft_tiled(const float* X, int64_t rows, int64_t n_x, const float* window, const float* twiddles, int n_fft, int hop,
                 int lead, int64_t n_frames, int64_t length, float* out, float* workspace, hipStream_t st);
 
+// One-pass inverse of the run-time sizes (speech windows ...): transform tiles + overlap-add in LDS (stft_generic.hip,
+// istft_generic_ola_kernel).  lead = 0, every frame stored.  `workspace`: istft_generic_ola_workspace_floats floats (envelope).
+bool istft_generic_ola_supported(int n_fft, int hop);
+int64_t istft_generic_ola_workspace_floats(int64_t n_frames, int n_fft, int hop);
+int istft_generic_ola(const float* X, int64_t rows, int64_t n_frames, const float* window, const float* twiddles, int n_fft,
+                      int hop, int64_t length, float* out, float* workspace, hipStream_t st);
+
 // Inverse transform of every frame: X (rows, n_frames, n_fft/2+1) -> windowed frames (rows, n_frames, n_fft),
 // the input of istft_ola_kernel.
 int istft_frames_generic(const float* X, int64_t rows, int64_t n_frames, const float* window, const float* twiddles,

@@ -771,6 +771,7 @@ int64_t at_istft_workspace_bytes(int64_t rows, int64_t n_frames, int n_fft, int 
     return ((n_frames - 1) * hop + n_fft + DUMP_FLOATS + ZERO_PAGE_FLOATS) * 4;
   static const int tiled_off = at::env_int_once("AT_ISTFT_TILED_OFF", 0);       // A/B: frame buffer + gather for 4096 / 8192
   if (!tiled_off && at::istft_tiled_supported(n_fft, hop)) return at::istft_tiled_workspace_floats(n_frames, n_fft, hop) * 4;
+  if (at::istft_generic_ola_supported(n_fft, hop)) return at::istft_generic_ola_workspace_floats(n_frames, n_fft, hop) * 4;
   return rows * n_frames * (int64_t)n_fft * 4;
 }
 
@@ -799,6 +800,9 @@ static int istft_run(const float* X, int64_t rows, int64_t n_x, const float* win
                              reinterpret_cast<float*>(workspace), st);
     // generic sizes (4096 ..., non powers of two): mixed-radix frames + the gather kernel
     if (lead != 0 || n_frames != n_x) return AT_ERR_UNSUPPORTED;
+    if (at::istft_generic_ola_supported(n_fft, hop))      // one pass: overlap-add in LDS, no frame buffer
+      return at::istft_generic_ola(X, rows, n_frames, window, twiddles, n_fft, hop, length, out,
+                                   reinterpret_cast<float*>(workspace), st);
     int rc = at::istft_frames_generic(X, rows, n_frames, window, twiddles, n_fft, reinterpret_cast<float*>(workspace), st);
     if (rc != AT_OK) return rc;
     const int64_t total = rows * length;
@@ -840,6 +844,9 @@ static int istft_run(const float* X, int64_t rows, int64_t n_x, const float* win
   if (edit) return AT_ERR_UNSUPPORTED;
   // generic hop: frame buffer + gather.  Virtual zero frames are not supported here.
   if (lead != 0 || n_frames != n_x) return AT_ERR_UNSUPPORTED;
+  if (at::istft_generic_ola_supported(n_fft, hop))        // even hops: transform tiles + overlap-add in LDS (workspace = envelope)
+    return at::istft_generic_ola(X, rows, n_frames, window, twiddles, n_fft, hop, length, out,
+                                 reinterpret_cast<float*>(workspace), st);
   IstftArgs A;
   A.X = reinterpret_cast<const float2*>(X); A.window = window; A.tw = reinterpret_cast<const float2*>(twiddles);
   A.frames = reinterpret_cast<float*>(workspace); A.rows = rows; A.n_frames = (int)n_frames;

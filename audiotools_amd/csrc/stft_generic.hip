@@ -1065,6 +1065,159 @@ __global__ __launch_bounds__(256, 3) void istft_frames_generic_tiled_kernel(cons
   }
 }
 
+// Inverse transform of the run-time sizes in ONE pass (round 4): the tile above, with the overlap-add done in LDS instead
+// of through a (rows, frames, n_fft) buffer in HBM and a gather kernel (n_fft 400: 2 x 1.3 GB of frame traffic for 0.33 GB
+// of audio).  A workgroup walks a run of consecutive tiles of one row.  The LDS keeps R + FB frame slots in a row: the
+// last R = ceil(N / hop) - 1 transformed frames of the previous tile ("history") in front of the FB frames of this one, so
+// every output sample of the tile's FB hops -- centre-padded positions [f0 hop, (f0 + FB) hop) -- finds all its <= R + 1
+// frames in LDS: sum in ascending frame order (as istft_ola_kernel), window and 1 / N folded into one LDS table, times
+// 1 / envelope (table of istft_env_generic_kernel), one coalesced store.  Then the last R slots move to the front.
+// Frames outside [0, n_frames) are zero spectra (nothing is loaded); a run that starts inside a row first transforms
+// the tile in front of it for its history.  hop and n_fft / 2 even (sample PAIRS stay aligned between frames), FB >= R.
+struct GenOlaArgs {
+  const float2* X;         // (rows, n_frames, M + 1)
+  const float* window;
+  const float2* tw;
+  const float* inv_env;    // (env_n)
+  float* out;              // (rows, length)
+  int64_t rows, length, env_n, total_runs;
+  int n_frames, M, FB, R, h2 /* hop / 2 */, tiles_per_row, runs_per_row, tiles_per_run, vec2;
+  at::gfft::PassList pl;
+};
+
+template <int PLAN>
+__global__ __launch_bounds__(256, 2) void istft_generic_ola_kernel(const GenOlaArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
+  const int M = PLAN == 3 ? 200 : PLAN == 4 ? 600 : PLAN == 5 ? 960 : A.M;
+  const int FB = PLAN == 3 ? 20 : PLAN == 4 ? 6 : PLAN == 5 ? 4 : A.FB;
+  const int R = A.R, h2 = A.h2;
+  float2* slots = gbuf;               // [R + FB][M]: history, then this tile's frames
+  float2* buf = slots + R * M;
+  float2* tw = buf + FB * M;          // [M]: pass blocks of w_M
+  float2* win2 = tw + M;              // [M]: (w[2n] / N, -w[2n+1] / N): the conj of the transform's identity folded in
+  float2* ftw = win2 + M;             // [M]: fold twiddles w_N^k
+  at::gfft::build_pass_twiddles<256>(tw, A.tw, 2, M, A.pl);
+  {
+    const float inv_n = 1.0f / (float)(2 * M);
+    for (int i = threadIdx.x; i < M; i += 256) {
+      const float2 w = reinterpret_cast<const float2*>(A.window)[i];
+      win2[i] = make_float2(w.x * inv_n, -w.y * inv_n);
+      ftw[i] = A.tw[i];
+    }
+  }
+  __syncthreads();
+  const at::gfft::RowLayoutN lay{M, (M & 15) == 0 ? 1 : 0};
+  const int npts = FB * M, npairs = FB * h2;
+  const float inv_M = 1.0f / (float)M, inv_h2 = 1.0f / (float)h2;
+  const int half = M / 2;             // output sample p = 2 j - M: pair j - M / 2 of the row (M even)
+
+  auto transform = [&](int64_t row, int f0) __attribute__((always_inline)) {
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const float2* __restrict__ Xt = A.X + (row * A.n_frames + f0) * (int64_t)(M + 1);
+    float2 xa[GI_LOADS], xm[GI_LOADS];
+#pragma unroll
+    for (int i = 0; i < GI_LOADS; ++i) {
+      if (256 * i < npts) {
+        const int e = min(tid + 256 * i, npts - 1);
+        const int fi = (int)(((float)e + 0.5f) * inv_M), k = e - fi * M;
+        xa[i] = make_float2(0.f, 0.f);
+        xm[i] = make_float2(0.f, 0.f);
+        if (f0 + fi < A.n_frames) {
+          const float2* __restrict__ Xf = Xt + fi * (M + 1);
+          xa[i] = Xf[k];
+          xm[i] = Xf[M - k];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GI_LOADS; ++i) {
+      if (256 * i < npts) {
+        const int e = min(tid + 256 * i, npts - 1);
+        const int fi = (int)(((float)e + 0.5f) * inv_M), k = e - fi * M;
+        float2 a = xa[i], m = xm[i];
+        if (k == 0) { a.y = 0.f; m.y = 0.f; }
+        const float2 w = ftw[k];
+        const float c = w.x, s = -w.y;
+        const float sr = a.x + m.x, si = a.y - m.y;
+        const float dr = a.x - m.x, di = a.y + m.y;
+        const float zr = sr - s * dr - c * di;
+        const float zi = si + c * dr - s * di;
+        buf[lay.addr(fi, k)] = make_float2(zr, -zi);
+      }
+    }
+    __syncthreads();
+    if constexpr (PLAN == 3) {
+      at::gfft::pass_inplace<25, 1, 256>(buf, tw, 200, 1, 160, lay);
+      at::gfft::pass_inplace<8, 2, 256>(buf, tw, 200, 25, 500, lay);
+    } else if constexpr (PLAN == 4) {
+      at::gfft::pass_inplace<25, 1, 256>(buf, tw, 600, 1, 144, lay);
+      at::gfft::pass_inplace<3, 5, 256>(buf, tw, 600, 25, 1200, lay);
+      at::gfft::pass_inplace<8, 2, 256>(buf, tw + 50, 600, 75, 450, lay);
+    } else if constexpr (PLAN == 5) {
+      at::gfft::pass_inplace<5, 3, 256>(buf, tw, 960, 1, 768, lay);
+      at::gfft::pass_inplace<3, 5, 256>(buf, tw, 960, 5, 1280, lay);
+      at::gfft::pass_inplace<16, 1, 256>(buf, tw + 10, 960, 15, 240, lay);
+      at::gfft::pass_inplace<4, 4, 256>(buf, tw + 235, 960, 240, 960, lay);
+    } else {
+      at::gfft::run_passes<256>(buf, tw, M, A.pl, FB, lay);
+    }
+  };
+  auto keep_history = [&]() __attribute__((always_inline)) {      // slots [FB, FB + R) -> [0, R); FB >= R: no overlap
+    for (int i = threadIdx.x; i < R * M; i += 256) slots[i] = slots[FB * M + i];
+    __syncthreads();
+  };
+
+  for (int64_t run = blockIdx.x; run < A.total_runs; run += gridDim.x) {
+    const int64_t row = run / A.runs_per_row;
+    const int t_first = (int)(run - row * A.runs_per_row) * A.tiles_per_run;
+    const int t_last = min(t_first + A.tiles_per_run, A.tiles_per_row);
+    if (t_first == 0) {
+      for (int i = threadIdx.x; i < R * M; i += 256) slots[i] = make_float2(0.f, 0.f);
+      __syncthreads();
+    } else {
+      transform(row, (t_first - 1) * FB);
+      keep_history();
+    }
+    float* __restrict__ orow = A.out + row * A.length;
+    for (int t = t_first; t < t_last; ++t) {
+      const int f0 = t * FB;
+      transform(row, f0);
+      // pair jj of the tile: centre-padded samples 2 (f0 h2 + jj), +1; newest frame q = jj / h2, then q - 1 ... q - R
+      const int64_t j0 = (int64_t)f0 * h2;
+      for (int jj = threadIdx.x; jj < npairs; jj += 256) {
+        const int q = (int)(((float)jj + 0.5f) * inv_h2);
+        const int rem = jj - q * h2;
+        float2 acc = make_float2(0.f, 0.f);
+        for (int k = R; k >= 0; --k) {                          // ascending frame order
+          const int n2 = rem + k * h2;
+          if (n2 < M) {
+            const float2 v = slots[lay.addr(R + q - k, n2)];
+            const float2 w = win2[n2];
+            acc.x = fmaf(v.x, w.x, acc.x);
+            acc.y = fmaf(v.y, w.y, acc.y);
+          }
+        }
+        const int64_t j = j0 + jj;
+        const int64_t p = 2 * j - M;
+        if (A.vec2) {
+          if (p >= 0 && p + 1 < A.length) {
+            float2 ie = make_float2(0.f, 0.f);
+            if (2 * j + 1 < A.env_n) ie = *reinterpret_cast<const float2*>(A.inv_env + 2 * j);
+            *reinterpret_cast<float2*>(orow + p) = make_float2(acc.x * ie.x, acc.y * ie.y);
+          }
+        } else {
+          if (p >= 0 && p < A.length) orow[p] = 2 * j < A.env_n ? acc.x * A.inv_env[2 * j] : 0.f;
+          if (p + 1 >= 0 && p + 1 < A.length) orow[p + 1] = 2 * j + 1 < A.env_n ? acc.y * A.inv_env[2 * j + 1] : 0.f;
+        }
+      }
+      (void)half;
+      __syncthreads();
+      keep_history();
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void istft_frames_generic_kernel(const GenInvArgs A) {
   extern __shared__ __attribute__((aligned(16))) float2 gbuf[];
   const int M = A.M, N = 2 * M;
@@ -1266,6 +1419,85 @@ int istft_tiled(const float* X, int64_t rows, int64_t n_x, const float* window, 
   if (blocks > G.total_units) blocks = G.total_units;
   if (plan == 1) hipLaunchKernelGGL(istft_tiled_pow2_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, st, G);
   else hipLaunchKernelGGL(istft_tiled_pow2_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+// One-pass inverse of the run-time sizes (istft_generic_ola_kernel): frames per tile and history depth for (n_fft, hop),
+// false when the shape keeps the frame buffer + gather path (odd hop or n_fft / 2, more history than a tile holds, LDS).
+static bool generic_ola_plan(int n_fft, int hop, int* FBo, int* Ro) {
+  static const int off = env_int_once("AT_ISTFT_GENERIC_OLA", 1) == 0;     // A/B: 0 = frame buffer + gather
+  if (off || n_fft < 8 || (n_fft & 3) || (hop & 1) || hop <= 0 || hop > n_fft) return false;
+  const int M = n_fft / 2;
+  gfft::PassList pl;
+  if (M > gfft::TILE_POINTS || !gfft::factor(M, &pl)) return false;
+  const int R = (n_fft + hop - 1) / hop - 1;
+  int fb = gfft::TILE_POINTS / M;
+  if (fb > 64) fb = 64;
+  // two workgroups per CU where the tile allows it
+  while (fb > R && fb > 2 && (size_t)(R + fb + 3) * M * sizeof(float2) > 80 * 1024) --fb;
+  if (fb < R || fb < 1 || (size_t)(R + fb + 3) * M * sizeof(float2) > 160 * 1024) return false;
+  if (R > 16) return false;
+  *FBo = fb; *Ro = R;
+  return true;
+}
+
+bool istft_generic_ola_supported(int n_fft, int hop) {
+  int fb, r;
+  return generic_ola_plan(n_fft, hop, &fb, &r);
+}
+
+int64_t istft_generic_ola_workspace_floats(int64_t n_frames, int n_fft, int hop) { return (n_frames - 1) * hop + n_fft; }
+
+int istft_generic_ola(const float* X, int64_t rows, int64_t n_frames, const float* window, const float* twiddles, int n_fft,
+                      int hop, int64_t length, float* out, float* workspace, hipStream_t st) {
+  GenOlaArgs G;
+  if (!generic_ola_plan(n_fft, hop, &G.FB, &G.R)) return AT_ERR_UNSUPPORTED;
+  const int M = n_fft / 2;
+  if (!gfft::factor(M, &G.pl)) return AT_ERR_UNSUPPORTED;
+  const int64_t env_n = (n_frames - 1) * hop + n_fft;
+  {
+    int64_t eb = (env_n + 255) / 256;
+    if (eb > 4096) eb = 4096;
+    hipLaunchKernelGGL(istft_env_generic_kernel, dim3((unsigned)eb), dim3(256), 0, st, window, workspace, (int)n_frames, n_fft,
+                       hop, env_n, (int64_t)0);
+    AT_LAUNCH_CHECK();
+  }
+  G.X = reinterpret_cast<const float2*>(X); G.window = window; G.tw = reinterpret_cast<const float2*>(twiddles);
+  G.inv_env = workspace; G.out = out; G.rows = rows; G.length = length; G.env_n = env_n;
+  G.n_frames = (int)n_frames; G.M = M; G.h2 = hop / 2;
+  static const int small_plans = env_int_once("AT_STFT_GENERIC_PLANS", 1);
+  const int splan = !small_plans ? 0 : (M == 200 && G.FB == 20) ? 3 : (M == 600 && G.FB == 6) ? 4 : (M == 960 && G.FB == 4) ? 5 : 0;
+  // pairs to produce per row: every output sample p = 2 j - M < length
+  const int64_t need_pairs = (length + M + 1) / 2;
+  const int64_t per_tile = (int64_t)G.FB * G.h2;
+  G.tiles_per_row = (int)((need_pairs + per_tile - 1) / per_tile);
+  G.vec2 = ((length & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0) ? 1 : 0;
+  const size_t lds = (size_t)(G.R + G.FB + 3) * M * sizeof(float2);
+  const void* kfn = splan == 3 ? reinterpret_cast<const void*>(istft_generic_ola_kernel<3>)
+                  : splan == 4 ? reinterpret_cast<const void*>(istft_generic_ola_kernel<4>)
+                  : splan == 5 ? reinterpret_cast<const void*>(istft_generic_ola_kernel<5>)
+                               : reinterpret_cast<const void*>(istft_generic_ola_kernel<0>);
+  int e = allow_big_lds(kfn);
+  if (e != AT_OK) return e;
+  int per_cu = (int)((160 * 1024) / lds);
+  static const int cap_env = env_int_once("AT_ISTFT_GENERIC_WGS", 0);
+  const int cap = cap_env > 0 ? cap_env : 3;
+  per_cu = per_cu > cap ? cap : (per_cu < 1 ? 1 : per_cu);
+  const int64_t slots = (int64_t)device_cu_count() * per_cu;
+  // runs: >= 4 per workgroup slot for balance, >= 8 tiles each (a run that starts inside a row pays one extra tile)
+  int64_t k = (4 * slots + rows - 1) / rows;
+  const int64_t kmax = G.tiles_per_row / 8 > 0 ? G.tiles_per_row / 8 : 1;
+  if (k > kmax) k = kmax;
+  if (k < 1) k = 1;
+  G.tiles_per_run = (int)((G.tiles_per_row + k - 1) / k);
+  G.runs_per_row = (G.tiles_per_row + G.tiles_per_run - 1) / G.tiles_per_run;
+  G.total_runs = rows * G.runs_per_row;
+  int64_t blocks = slots < G.total_runs ? slots : G.total_runs;
+  if (splan == 3) hipLaunchKernelGGL(istft_generic_ola_kernel<3>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+  else if (splan == 4) hipLaunchKernelGGL(istft_generic_ola_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+  else if (splan == 5) hipLaunchKernelGGL(istft_generic_ola_kernel<5>, dim3((unsigned)blocks), dim3(256), lds, st, G);
+  else hipLaunchKernelGGL(istft_generic_ola_kernel<0>, dim3((unsigned)blocks), dim3(256), lds, st, G);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }
