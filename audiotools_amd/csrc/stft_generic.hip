@@ -39,6 +39,16 @@ struct GenInvArgs {
 using at::gfft::cmulf;
 using at::gfft::dft_r;
 
+// A pointer every lane of the wave agrees on, kept in scalar registers: indexing it with an UNSIGNED 32-bit element
+// offset gives the "scalar base + vector offset" addressing mode (one shift per access instead of a 64-bit multiply-add
+// chain: the speech-window tiles are VALU-issue bound, logs/s16/pmc.txt)
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+
 template <int R>
 __device__ __forceinline__ void stockham_pass(const float2* __restrict__ src, float2* __restrict__ dst,
                                               const float2* __restrict__ tw, int M, int NS) {
@@ -244,13 +254,13 @@ __global__ __launch_bounds__(256, (PLAN >= 3 ? AT_GENERIC_SMALL_WGS : 2)) void s
     int row = 0, f0 = 0, s0 = 0;
     if (valid) geom(g, row, f0, s0);
     const bool ok = valid && interior(s0);
-    const float* __restrict__ xs = A.x + (int64_t)row * A.T + (ok ? s0 : 0);
+    const float* __restrict__ xs = uniform_ptr(A.x + (int64_t)row * A.T + (ok ? s0 : 0));
 #pragma unroll
     for (int i = 0; i < G2_LOADS; ++i) {
       if (256 * i < npts) {                               // uniform; lanes past the end repeat the last point
         const int e = min(tid + 256 * i, npts - 1);
         const int fi = frame_of(e, M, inv_M), n = e - fi * M;
-        r[i] = *reinterpret_cast<const float2*>(xs + fi * hop + 2 * n);
+        r[i] = *reinterpret_cast<const float2*>(xs + (unsigned)(fi * hop + 2 * n));
       }
     }
   };
@@ -308,9 +318,41 @@ __global__ __launch_bounds__(256, (PLAN >= 3 ? AT_GENERIC_SMALL_WGS : 2)) void s
     } else {
       at::gfft::run_passes<256>(buf, tw, M, A.pl, FB, lay);
     }
-    // ---- split step, one ascending sweep over k = 0 .. M per frame; |X| kept for the mel stage
-    float mg[G2_KB];
-    float2* __restrict__ orow = A.out + ((int64_t)row * n_out + f0) * (M + 1);
+    // ---- split step; |X| kept for the mel stage
+    float mg[G2_KB + 1];                                  // bins (PLAN 1 / 2) or 9 pairs of bins per thread
+    float2* __restrict__ orow = uniform_ptr(A.out + ((int64_t)row * n_out + f0) * (M + 1));
+    if constexpr (!POW2) {
+      // round 4: X[k] and X[M - k] from ONE evaluation of the pair (Z[k], Z[M - k]), k = 0 .. M / 2 per frame (half the
+      // LDS reads, index splits and twiddle look-ups of the bin-by-bin sweep below; the quarter table needs no symmetry).
+      // mg[2 i], mg[2 i + 1] = |X[k]|, |X[M - k]| of the thread's i-th pair.
+      const int hp = M / 2 + 1, npair = FB * hp;
+      const float inv_hp = 1.0f / (float)hp;
+#pragma unroll
+      for (int it = 0; it < G2_KB / 2 + 1; ++it) {
+        const int e = tid + 256 * it;
+        mg[2 * it] = 0.f; mg[2 * it + 1] = 0.f;
+        if (256 * it < npair && e < npair) {
+          const int fi = frame_of(e, hp, inv_hp), k = e - fi * hp;
+          const float2 zk = buf[lay.addr(fi, k)], zm = buf[lay.addr(fi, k == 0 ? 0 : M - k)];
+          const float2 w = stw[k];
+          const float c = w.x, sn = -w.y;
+          const float sr = zk.x + zm.x, si = zk.y - zm.y;
+          const float dr = zk.x - zm.x, di = zk.y + zm.y;
+          const float pp = fmaf(sn, dr, -c * di);
+          const float qq = fmaf(sn, di, c * dr);
+          float2 Xa = make_float2(0.5f * (sr - pp), 0.5f * (si - qq));       // X[k]
+          float2 Xb = make_float2(0.5f * (sr + pp), -0.5f * (si + qq));      // X[M - k]
+          if (k == 0) { Xa.y = 0.f; Xb.y = 0.f; }           // DC and Nyquist: exactly real
+          const unsigned o = (unsigned)(fi * (M + 1) + k);
+          orow[o] = Xa;
+          if (2 * k != M) orow[o + (unsigned)(M - 2 * k)] = Xb;               // (k = M / 2 is its own partner)
+          if (MEL) {
+            mg[2 * it] = __builtin_amdgcn_sqrtf(fmaf(Xa.x, Xa.x, Xa.y * Xa.y));
+            mg[2 * it + 1] = __builtin_amdgcn_sqrtf(fmaf(Xb.x, Xb.x, Xb.y * Xb.y));
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int it = 0; it < G2_KB; ++it) {
       const int e = tid + 256 * it;
@@ -334,12 +376,27 @@ __global__ __launch_bounds__(256, (PLAN >= 3 ? AT_GENERIC_SMALL_WGS : 2)) void s
         if (MEL) mg[it] = __builtin_amdgcn_sqrtf(fmaf(X.x, X.x, X.y * X.y));     // (uniform: no quarter-rate sqrt without a mel stage)
       }
     }
+    }
     if (MEL) {
       __syncthreads();                                    // every Z has been read: the buffer becomes |X|
+      if constexpr (!POW2) {
+        const int hp = M / 2 + 1, npair = FB * hp;
+        const float inv_hp = 1.0f / (float)hp;
+#pragma unroll
+        for (int it = 0; it < G2_KB / 2 + 1; ++it) {
+          const int e = tid + 256 * it;
+          if (256 * it < npair && e < npair) {
+            const int fi = frame_of(e, hp, inv_hp), k = e - fi * hp;
+            mag[fi * (M + 1) + k] = mg[2 * it];
+            if (2 * k != M) mag[fi * (M + 1) + M - k] = mg[2 * it + 1];
+          }
+        }
+      } else {
 #pragma unroll
       for (int it = 0; it < G2_KB; ++it) {
         const int e = tid + 256 * it;
         if (e < nbins) mag[e] = mg[it];
+      }
       }
       __syncthreads();
       const int nch = A.n_chunks;
