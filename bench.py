@@ -574,7 +574,9 @@ def main():
                          "items_per_gpu": n_local, "parallelism": f"batch-shard x{world} + RCCL broadcast of the resample bank / tables",
                          "inputs": "device-resident (H2D excluded)"}
         if os.environ.get("AT_RESAMPLE_F16", "1") != "0" and _native.lib().at_resample_f16s_supported(441, 160):
-            rs_kernel, rs_sub = "resample_f16s_kernel (banded-GEMM polyphase 441->160, fp16-split products on v_mfma_f32_16x16x32_f16)", "resample_f16s_kernel"
+            rp = os.environ.get("AT_RESAMPLE_F16_RP", "1") != "0"        # the shipped register-prefetch form; 0 = the LDS-DMA form
+            rs_sub = "resample_f16s_rp_kernel" if rp else "resample_f16s_kernel"
+            rs_kernel = rs_sub + " (banded-GEMM polyphase 441->160, fp16-split products on v_mfma_f32_16x16x32_f16)"
         elif _native.lib().at_resample_mfma_supported(441, 160) and os.environ.get("AT_RESAMPLE_MFMA", "1") != "0":
             rs_kernel, rs_sub = "resample_mfma_ws_kernel (banded-GEMM polyphase 441->160 on v_mfma_f32_16x16x4_f32)", "resample_mfma_ws_kernel"
         else:
