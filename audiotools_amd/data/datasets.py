@@ -202,15 +202,21 @@ class AudioLoader:
             else:
                 for j, b in enumerate(members):
                     out[b] = sig[j]
+        # per-item metadata, the same on both routes: what AudioSignal(path, offset, duration) records, then the row's
+        # columns -- which win, as in the reference (datasets.py:117-124 writes them after the load)
+        metas = []
+        for b, plan in enumerate(plans):
+            m = {}
+            if plan.mem is not None and b not in singles:
+                m["offset"], m["duration"] = plan.offset_s, duration
+            m.update(plan.row)
+            metas.append(m)
         if whole is None:
-            for b, plan in enumerate(plans):
-                for k, v in plan.row.items():
-                    out[b].metadata[k] = v
-                if plan.mem is not None and b not in singles:               # what AudioSignal(path, offset, duration) records
-                    out[b].metadata["offset"], out[b].metadata["duration"] = plan.offset_s, duration
+            for b in range(B):
+                out[b].metadata.update(metas[b])
             whole = out if as_list else (AudioSignal.batch(out, pad_signals=True) if B > 1 else out[0])
 
-        item = {"signal": whole,
+        item = {"signal": whole, "metadata": metas,
                 "source_idx": [p.source_idx for p in plans], "item_idx": [p.item_idx for p in plans],
                 "source": [str(self.sources[p.source_idx]) for p in plans], "path": [str(p.path) for p in plans]}
         if self.transform is not None:
@@ -224,5 +230,5 @@ class AudioLoader:
         (datasets.py:126-136)."""
         got = self.batch([state], sample_rate, duration, loudness_cutoff=loudness_cutoff, num_channels=num_channels,
                          offset=offset, source_idx=source_idx, item_idx=item_idx, global_idx=global_idx, as_list=True)
-        item = {k: v[0] for k, v in got.items()}
+        item = {k: v[0] for k, v in got.items() if k != "metadata"}       # (the signal carries it: the reference's item keys)
         return item

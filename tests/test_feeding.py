@@ -97,6 +97,29 @@ def test_audio_loader_call(reference, memory_sources, kw):
         assert _same_state(sa, sr)
 
 
+def test_audio_loader_batch_metadata_both_routes(reference, memory_sources):
+    """AudioLoader.batch records every item's metadata whether or not one source layout covers the batch (the stacked
+    route used to return none), and a row's own columns win over the loader's offset / duration as in the reference
+    (datasets.py:117-124 writes the row after the load).  ADVICE r03."""
+    lists = [[{"path": memory_sources["a"], "loudness": "-16.5", "duration": "tagged"}, {"path": memory_sources["b"]}]]
+    ours = AudioLoader(sources=[list(l) for l in lists])
+    ours.sources = ["src0"]
+    states = [np.random.RandomState(s) for s in range(4)]
+    whole = ours.batch(states, 22050, 0.5, num_channels=1)                 # one layout: the stacked route
+    assert isinstance(whole["signal"], A.AudioSignal) and whole["signal"].batch_size == 4
+    states = [np.random.RandomState(s) for s in range(4)]
+    listed = ours.batch(states, 22050, 0.5, num_channels=1, as_list=True)  # per-item route
+    assert whole["metadata"] == listed["metadata"] and len(whole["metadata"]) == 4
+    for m, sig, item_idx in zip(listed["metadata"], listed["signal"], listed["item_idx"]):
+        assert "offset" in m and {k: sig.metadata[k] for k in m} == m
+        if item_idx == 0:                                                   # the row with its own "duration" column
+            assert m["duration"] == "tagged" and m["loudness"] == "-16.5"
+        else:
+            assert m["duration"] == 0.5
+    single = ours(np.random.RandomState(0), 22050, 0.5)
+    assert "metadata" not in single                                         # the reference's item keys
+
+
 def test_audio_loader_with_transform(reference, memory_sources):
     ours, theirs = _loaders(reference, memory_sources)
     ours.transform = A.transforms.Compose(A.transforms.VolumeChange(), A.transforms.LowPass())
