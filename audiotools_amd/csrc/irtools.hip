@@ -290,6 +290,40 @@ __global__ __launch_bounds__(RT) void alter_drr_kernel(const float* __restrict__
   }
 }
 
+// ---- windows along the batch axis (dsp.py:70-151) --------------------------------------------------
+// collect: out[(r nw + w), n] = x[r, w hop + n]  (torch unfold + permute + reshape: one gather).
+__global__ __launch_bounds__(256) void collect_windows_kernel(const float* __restrict__ x, int64_t T, int win, int hop, int64_t nw,
+                                                              float* __restrict__ out, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t fr = i / win;
+    const int n = (int)(i - fr * win);
+    const int64_t r = fr / nw, w = fr - r * nw;
+    out[i] = x[r * T + w * hop + n];
+  }
+}
+
+// overlap-add: the reference folds the windows, folds a tensor of ones, divides, then trims `trim` samples from either
+// end -- four passes over window-sized data.  Here every output sample gathers its <= ceil(win / hop) windows (ascending
+// window order) and divides by their number; positions no window covers are 0 / 0 = NaN, as in the reference.
+__global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ fr, int64_t nw, int win, int hop, int64_t trim,
+                                                          int64_t out_len, float* __restrict__ out, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / out_len;
+    const int64_t s = i - r * out_len + trim;          // position in the padded signal
+    int64_t w_hi = s / hop;
+    if (w_hi > nw - 1) w_hi = nw - 1;
+    int64_t w_lo = (s - win + hop) / hop;              // smallest w with w hop + win > s
+    if (s - win + 1 <= 0 || w_lo < 0) w_lo = 0;
+    float acc = 0.f, cnt = 0.f;
+    const float* __restrict__ base = fr + r * nw * win;
+    for (int64_t w = w_lo; w <= w_hi; ++w) {
+      const int64_t n = s - w * hop;
+      if (n >= 0 && n < win) { acc += base[w * win + n]; cnt += 1.f; }
+    }
+    out[i] = acc / cnt;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -341,6 +375,33 @@ int at_alter_drr_peak_f32(const float* x, int64_t B, int64_t C, int64_t T, int t
 int at_alter_drr_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, const float* drr, float* out,
                      void* stream) {
   return at_alter_drr_peak_f32(x, B, C, T, t0, drr, out, nullptr, nullptr, stream);
+}
+
+int at_collect_windows_f32(const float* x, int64_t rows, int64_t T, int win, int hop, float* out, void* stream) {
+  if (rows == 0) return AT_OK;
+  if (!x || !out || rows < 0 || T <= 0 || win <= 0 || hop <= 0) return AT_ERR_INVALID;
+  if (T < win) return AT_OK;                           // no window fits: the result is empty
+  const int64_t nw = (T - win) / hop + 1;
+  const int64_t total = rows * nw * win;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(collect_windows_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, T, win,
+                     hop, nw, out, total);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+int at_overlap_add_f32(const float* frames, int64_t rows, int64_t nw, int win, int hop, int64_t trim, int64_t out_len, float* out,
+                       void* stream) {
+  if (rows == 0 || out_len == 0) return AT_OK;
+  if (!frames || !out || rows < 0 || nw <= 0 || win <= 0 || hop <= 0 || trim < 0 || out_len < 0) return AT_ERR_INVALID;
+  const int64_t total = rows * out_len;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), frames, nw,
+                     win, hop, trim, out_len, out, total);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
 }
 
 }  // extern "C"

@@ -216,6 +216,9 @@ class DSPMixin:
         if preprocess:
             window_length, hop_length = self._preprocess_signal_for_windowing(window_duration, hop_duration)
         rows = self.audio_data.reshape(-1, self.signal_length)
+        if kernels.is_native(rows) and rows.numel() < (1 << 31):
+            self.audio_data = kernels.collect_windows(rows, window_length, hop_length)
+            return self
         frames = rows.unfold(-1, window_length, hop_length)  # (rows, n, L)
         self.audio_data = frames.reshape(-1, 1, window_length)
         return self
@@ -225,6 +228,13 @@ class DSPMixin:
         hop_length = int(hop_duration * self.sample_rate)
         window_length = self.signal_length
         nb, nch = self._original_batch_size, self._original_num_channels
+        a = self.audio_data
+        if (kernels.is_native(a) and a.shape[0] % (nb * nch) == 0 and hop_length > 0
+                and 2 * hop_length <= self._padded_signal_length):
+            # one gather instead of fold + fold(ones) + division + trim; trim(hop, hop) as the reference's last step
+            y = kernels.overlap_add(a, nb * nch, hop_length, self._padded_signal_length, hop_length)
+            self.audio_data = y.reshape(nb, nch, -1)
+            return self
         unfolded = self.audio_data.reshape(nb * nch, -1, window_length).permute(0, 2, 1)
         size = dict(output_size=(1, self._padded_signal_length), kernel_size=(1, window_length),
                     stride=(1, hop_length))

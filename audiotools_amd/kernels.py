@@ -618,6 +618,34 @@ def roll_pad(x: torch.Tensor, shift: torch.Tensor, T: int) -> torch.Tensor:
     return out
 
 
+def collect_windows(x: torch.Tensor, win: int, hop: int) -> torch.Tensor:
+    """(rows, T) -> (rows * nw, 1, win): windows of ``win`` samples every ``hop`` along the batch axis (dsp.py:70-108)."""
+    _require_native_ok(x)
+    x = x.contiguous()
+    rows, T = x.shape
+    nw = max((T - win) // hop + 1, 0) if T >= win else 0
+    out = torch.empty((rows * nw, 1, win), dtype=torch.float32, device=x.device)
+    code = _native.lib().at_collect_windows_f32(_native.ptr(x), rows, T, int(win), int(hop), _native.ptr(out),
+                                                _native.current_stream(x.device))
+    _native.check(code, "at_collect_windows_f32")
+    return out
+
+
+def overlap_add(frames: torch.Tensor, rows: int, hop: int, padded_len: int, trim: int) -> torch.Tensor:
+    """(rows * nw, 1, win) windows -> (rows, padded_len - 2 trim): overlap-add divided by the overlap count, trimmed
+    (dsp.py:110-151: fold, fold of ones, division, trim -- one gather here)."""
+    _require_native_ok(frames)
+    frames = frames.contiguous()
+    win = frames.shape[-1]
+    nw = frames.shape[0] // rows
+    out_len = max(int(padded_len) - 2 * int(trim), 0)
+    out = torch.empty((rows, out_len), dtype=torch.float32, device=frames.device)
+    code = _native.lib().at_overlap_add_f32(_native.ptr(frames), rows, nw, int(win), int(hop), int(trim), out_len,
+                                            _native.ptr(out), _native.current_stream(frames.device))
+    _native.check(code, "at_overlap_add_f32")
+    return out
+
+
 def alter_drr(x: torch.Tensor, t0: int, drr: torch.Tensor, want_peak: bool = False):
     """alter_drr + ensure_max_of_audio of a batch of impulse responses (B, C, T); ``drr`` (B,).  ``want_peak``: also
     returns what ``absmax(out, want_index=True)`` would (max |out| and its first position per row), found in the kernel's

@@ -275,6 +275,18 @@ int at_phase_vocoder_f32(const float* X, int64_t rows, int64_t n_in, int64_t F, 
  */
 int at_absmax_f32(const float* x, int64_t rows, int64_t T, float* vmax, int64_t* imax, void* stream);
 int at_roll_pad_f32(const float* x, int64_t rows, int64_t L, const int64_t* shift, int64_t T, float* out, void* stream);
+
+/* ---- windows along the batch axis -------------------------------------------------------------
+ * Replaces  audiotools/core/dsp.py:70-108  collect_windows: torch unfold + permute + reshape of the (already padded) signal:
+ *             out (rows * nw, win), nw = (T - win) / hop + 1,  out[(r nw + w), n] = x[r, w hop + n]
+ *           audiotools/core/dsp.py:110-151 overlap_and_add: fold of the windows, fold of a tensor of ones, division and the
+ *             trim of `trim` samples from either end, in one gather:  out (rows, out_len),
+ *             out[r, t] = sum_w frames[r, w, t + trim - w hop] / #{windows covering t + trim}   (0 / 0 = NaN where none does,
+ *             as the reference's folded / norm)
+ */
+int at_collect_windows_f32(const float* x, int64_t rows, int64_t T, int win, int hop, float* out, void* stream);
+int at_overlap_add_f32(const float* frames, int64_t rows, int64_t nw, int win, int hop, int64_t trim, int64_t out_len, float* out,
+                       void* stream);
 int at_alter_drr_f32(const float* x, int64_t B, int64_t C, int64_t T, int t0, const float* drr, float* out,
                      void* stream);
 /* the same, and in its output pass what at_absmax_f32(out) would report: vmax (B*C) and imax (B*C, may be NULL) -- the

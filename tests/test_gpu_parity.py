@@ -243,6 +243,38 @@ def test_convolve_apply_ir_native_gradient_vs_float64(T, L, Cir, ir_grad):
     assert rel_err(ga, gb) < REL
 
 
+@pytest.mark.parametrize("B,C,T,wd,hd", [(3, 2, 16000, 0.1, 0.025), (2, 1, 12345, 0.064, 0.032), (1, 2, 4000, 0.03, 0.011),
+                                          (4, 1, 8000, 0.5, 0.5)])
+def test_collect_windows_overlap_and_add_native(B, C, T, wd, hd):
+    """collect_windows / overlap_and_add on HIP tensors (at_collect_windows_f32, at_overlap_add_f32) against the
+    reference's formulation -- zero_pad(hop, hop), F.unfold, permute / reshape; F.fold of the windows and of ones, division,
+    trim (dsp.py:70-151) -- evaluated by torch on the CPU, including the NaN the reference leaves where no window reaches."""
+    import torch.nn.functional as F
+    sr = 16000
+    x = synth.audio_batch(B, C, T, seed=T, gaps=False, sample_rate=sr)
+    win, hop = int(wd * sr), int(hd * sr)
+    if win % hop:
+        win = (win // hop) * hop
+    xp = F.pad(x, (hop, hop))
+    Tp = xp.shape[-1]
+    unf = F.unfold(xp.reshape(-1, 1, 1, Tp), kernel_size=(1, win), stride=(1, hop))
+    ref_w = unf.permute(0, 2, 1).reshape(-1, 1, win)
+    s = A.AudioSignal(x.clone(), sr).to("cuda")
+    s.collect_windows(wd, hd)
+    assert s.audio_data.shape == ref_w.shape and torch.equal(s.audio_data.cpu(), ref_w)
+    # a per-window gain so that the overlap-add is not the identity
+    gain = 1.0 + 0.1 * torch.arange(ref_w.shape[0], dtype=torch.float32)[:, None, None] / ref_w.shape[0]
+    s.audio_data = s.audio_data * gain.cuda()
+    u = (ref_w * gain).reshape(B * C, -1, win).permute(0, 2, 1)
+    kw = dict(output_size=(1, Tp), kernel_size=(1, win), stride=(1, hop))
+    ref = (F.fold(u, **kw) / F.fold(torch.ones_like(u), **kw)).reshape(B, C, -1)[..., hop:-hop]
+    y = s.overlap_and_add(hd).audio_data.cpu()
+    assert y.shape == ref.shape
+    nan = torch.isnan(ref)
+    assert torch.equal(torch.isnan(y), nan)
+    assert float((y[~nan] - ref[~nan]).abs().max()) <= 1e-6 * float(ref[~nan].abs().max())
+
+
 def test_mel_generic_size_short_clip_falls_back_to_dense_basis():
     """mel_spectrogram on generic transform sizes (4096 @ 96 kHz ...) goes to the banded mel stage of the TILED
     kernel; a clip that kernel does not take (shorter than its two-frame tile: T < n_fft + hop) must keep working through
