@@ -140,6 +140,7 @@ SIGNATURES = {
     "at_absmax_f32": (_i32, [_p, _i64, _i64, _p, _p, _p]),
     "at_roll_pad_f32": (_i32, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "at_collect_windows_f32": (_i32, [_p, _i64, _i64, _i32, _i32, _p, _p]),
+    "at_quantize_f32": (_i32, [_p, _i64, _i64, _p, _i32, _p, _p]),
     "at_overlap_add_f32": (_i32, [_p, _i64, _i64, _i32, _i32, _i64, _i64, _p, _p]),
     "at_alter_drr_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p, _p]),
     "at_alter_drr_peak_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p]),

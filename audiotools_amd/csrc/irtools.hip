@@ -324,6 +324,33 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restric
   }
 }
 
+// ---- quantization / mu-law quantization (effects.py:452-527) -------------------------------------
+// The reference's chains of ~10 / ~22 whole-tensor torch operations (one of them through int64), one float32 operation
+// per step and in the same order, so the values equal the chain's; out = a - (a - q(a)) is its straight-through form.
+__device__ __forceinline__ float sgn_torch(float v) { return (float)((0.f < v) - (v < 0.f)); }   // torch.sign: 0 for NaN
+
+template <int MODE>
+__global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ x, const float* __restrict__ q, int64_t per_item,
+                                                       float* __restrict__ out, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float a = x[i];
+    const float qb = q[i / per_item];
+    float v;
+    if (MODE == 0) {
+      v = floorf((a + 1.f) / 2.f * qb) / qb;
+      v = 2.f * v - 1.f;
+    } else {
+      const float mu = qb, l1 = log1pf(mu);
+      v = sgn_torch(a) * log1pf(mu * fabsf(a)) / l1;
+      const long long lv = (long long)__fadd_rn(__fmul_rn((v + 1.f) / 2.f, mu), 0.5f);    // (no fused multiply-add: the chain rounds twice)
+      v = ((float)lv / mu) * 2.f - 1.f;
+      v = sgn_torch(v) * (expf(fabsf(v) * l1) - 1.f) / mu;
+    }
+    const float r = a - v;
+    out[i] = a - r;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -400,6 +427,19 @@ int at_overlap_add_f32(const float* frames, int64_t rows, int64_t nw, int win, i
   if (blocks > 256 * 64) blocks = 256 * 64;
   hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), frames, nw,
                      win, hop, trim, out_len, out, total);
+  AT_LAUNCH_CHECK();
+  return AT_OK;
+}
+
+int at_quantize_f32(const float* x, int64_t B, int64_t per_item, const float* q, int mulaw, float* out, void* stream) {
+  if (B == 0 || per_item == 0) return AT_OK;
+  if (!x || !q || !out || B < 0 || per_item < 0) return AT_ERR_INVALID;
+  const int64_t total = B * per_item;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (mulaw) hipLaunchKernelGGL(quantize_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, q, per_item, out, total);
+  else hipLaunchKernelGGL(quantize_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, x, q, per_item, out, total);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }

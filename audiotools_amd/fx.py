@@ -480,15 +480,23 @@ class EffectMixin:
     # ----------------------------------------------------------- distortions
     def clip_distortion(self, clip_percentile: typing.Union[torch.Tensor, np.ndarray, float]):
         clip_percentile = util.ensure_tensor(clip_percentile, ndim=1).to(self.device)
-        lo = torch.quantile(self.audio_data, clip_percentile / 2, dim=-1)
-        hi = torch.quantile(self.audio_data, 1 - (clip_percentile / 2), dim=-1)
+        # The reference takes every percentile of every row -- quantile(audio, q)[Q, B, C] -- and then keeps
+        # [:, :num_channels, :] of it (effects.py:441-449): only the first num_channels ITEMS are ever read (for a mono
+        # batch: item 0's percentiles become everybody's thresholds).  Same values, but only those rows are sorted:
+        # 6.45 -> 0.3 ms at 256 x 5 s (tools/tfmbench.py).
         nc = self.audio_data.shape[1]
-        self.audio_data = self.audio_data.clamp(lo[:, :nc, :], hi[:, :nc, :])
+        head = self.audio_data[:nc]
+        lo = torch.quantile(head, clip_percentile / 2, dim=-1)
+        hi = torch.quantile(head, 1 - (clip_percentile / 2), dim=-1)
+        self.audio_data = self.audio_data.clamp(lo, hi)
         return self
 
     def quantization(self, quantization_channels: typing.Union[torch.Tensor, np.ndarray, int]):
         q = util.ensure_tensor(quantization_channels, ndim=3).to(self.device)
         x = self.audio_data
+        if kernels.is_native(x) and x.ndim == 3 and x.shape[0] > 0 and q.numel() in (1, x.shape[0]) and not q.requires_grad:
+            self.audio_data = kernels.quantize(x, q, False)
+            return self
         x = ((x + 1) / 2 * q).floor() / q
         x = 2 * x - 1
         residual = (self.audio_data - x).detach()
@@ -498,6 +506,9 @@ class EffectMixin:
     def mulaw_quantization(self, quantization_channels: typing.Union[torch.Tensor, np.ndarray, int]):
         mu = util.ensure_tensor(quantization_channels - 1.0, ndim=3).to(self.device)
         x = self.audio_data
+        if kernels.is_native(x) and x.ndim == 3 and x.shape[0] > 0 and mu.numel() in (1, x.shape[0]) and not mu.requires_grad:
+            self.audio_data = kernels.quantize(x, mu, True)
+            return self
         x = torch.sign(x) * torch.log1p(mu * torch.abs(x)) / torch.log1p(mu)
         x = ((x + 1) / 2 * mu + 0.5).to(torch.int64)
         x = (x / mu) * 2 - 1.0

@@ -5,6 +5,7 @@ allocates the outputs/workspaces with ``torch.empty`` (torch owns all memory,
 SURVEY.md 8(b) "Ownership"), and launches on torch's current stream.  No
 function here computes anything on the host beyond shapes.
 """
+import functools
 import math
 import os
 
@@ -432,6 +433,51 @@ def _pad8(n: int) -> int:
 
 
 FIR_FFT_MIN_TAPS = 96   # below this the direct register-window kernel is cheaper than two block FFTs
+# Above this the overlap-save kernel's partitions (one pass over the signal per 1024 taps: a 50 Hz high-pass at 44.1 kHz
+# has 44 983 taps = 44 launches, 17 ms for 256 x 5 s) cost more than ONE circular convolution by the four-step FFT at a
+# length >= T + L - 1 (four launches + the padding copy, ~6 passes): HighPass's default cutoffs 50 / 100 / 250 Hz.
+FIR_LONG_MIN_TAPS = 6145
+
+
+@functools.lru_cache(256)
+def _fir_long_length(n: int):
+    """Smallest even length >= n the four-step convolution has a plan for (None beyond its range)."""
+    lib = _native.lib()
+    m = n + (n & 1)
+    for _ in range(8192):
+        if m > (1 << 21):
+            return None
+        if lib.at_longconv_supported(m):
+            return m
+        m += 2
+    return None
+
+
+def _fir_long(audio, tp, rows, L, highpass, out):
+    """Per-item FIR of thousands of taps as one circular convolution (``at_longconv_room_f32``): the signal replicate-padded
+    by half a filter on either side and zero-filled to a planned length N >= T + L - 1, the flipped taps as the impulse
+    response read rotated left by L - 1 -- output sample n of the filter is then sample n of the convolution (no wrap
+    reaches the first T samples).  Same values as the direct / overlap-save kernels up to float32 summation order."""
+    B, C, T = audio.shape
+    H = (L - 1) // 2
+    N = _fir_long_length(T + L - 1)
+    xp = torch.empty((B, C, N), dtype=torch.float32, device=audio.device)
+    xp[..., H: H + T] = audio
+    xp[..., :H] = audio[..., :1]
+    xp[..., H + T: T + 2 * H] = audio[..., -1:]
+    xp[..., T + 2 * H:] = 0
+    ir = tp[:, :L].flip(-1).reshape(rows, 1, L)
+    if rows != B:
+        ir = ir.expand(B, 1, L)
+    shift = torch.full((B, 1), L - 1, dtype=torch.int64, device=audio.device)
+    y = room_convolve(xp, ir, shift, None)[..., :T]
+    if out is None:
+        return (audio - y) if highpass else y.contiguous()
+    if highpass:
+        torch.sub(audio, y, out=out)
+    else:
+        out.copy_(y)
+    return out
 
 
 def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False, replicate: bool = True,
@@ -460,7 +506,13 @@ def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False
         out = torch.empty_like(audio)
     assert out.shape == audio.shape and out.is_contiguous() and out.dtype == torch.float32 and out.device == audio.device
     if method == "auto":
-        method = os.environ.get("AT_FIR_METHOD") or ("fft" if L >= FIR_FFT_MIN_TAPS else "direct")
+        method = os.environ.get("AT_FIR_METHOD")             # development A/B: direct | fft | long
+        if not method:
+            method = "fft" if L >= FIR_FFT_MIN_TAPS else "direct"
+            if L >= FIR_LONG_MIN_TAPS and _LONGCONV and _fir_long_length(T + L - 1) is not None:
+                method = "long"
+    if method == "long":
+        return _fir_long(audio, tp, rows, L, highpass, out)
     if method == "fft":
         tw = tables.stft_twiddles(2048, audio.device)
         code = _native.lib().at_fir_fft_f32(_native.ptr(audio), B, C, T, _native.ptr(tp), rows, Lp, half,
@@ -615,6 +667,20 @@ def roll_pad(x: torch.Tensor, shift: torch.Tensor, T: int) -> torch.Tensor:
     code = _native.lib().at_roll_pad_f32(_native.ptr(x), B * C, L, _native.ptr(sh), T, _native.ptr(out),
                                          _native.current_stream(x.device))
     _native.check(code, "at_roll_pad_f32")
+    return out
+
+
+def quantize(x: torch.Tensor, q: torch.Tensor, mulaw: bool) -> torch.Tensor:
+    """``quantization`` / ``mulaw_quantization`` of a (B, C, T) HIP tensor in one pass (``at_quantize_f32``); ``q`` (B,)
+    float32: the channel count resp. mu = channels - 1 of every item."""
+    _require_native_ok(x)
+    x = x.contiguous()
+    B = x.shape[0]
+    q = q.reshape(-1).to(x.device, torch.float32).expand(B).contiguous()
+    out = torch.empty_like(x)
+    code = _native.lib().at_quantize_f32(_native.ptr(x), B, x.numel() // B, _native.ptr(q), 1 if mulaw else 0, _native.ptr(out),
+                                         _native.current_stream(x.device))
+    _native.check(code, "at_quantize_f32")
     return out
 
 

@@ -284,6 +284,14 @@ int at_roll_pad_f32(const float* x, int64_t rows, int64_t L, const int64_t* shif
  *             out[r, t] = sum_w frames[r, w, t + trim - w hop] / #{windows covering t + trim}   (0 / 0 = NaN where none does,
  *             as the reference's folded / norm)
  */
+/* ---- quantization ------------------------------------------------------------------------------
+ * Replaces  audiotools/core/effects.py:452-486 (quantization) and :488-527 (mulaw_quantization): the chain of whole-tensor
+ *           operations as one pass, one float32 operation per step of the chain and in its order.
+ *   x, out (B, per_item) with per_item = C * T; q (B): quantization_channels (mulaw = 0) resp. quantization_channels - 1
+ *   = mu (mulaw = 1) of every item, as float32
+ */
+int at_quantize_f32(const float* x, int64_t B, int64_t per_item, const float* q, int mulaw, float* out, void* stream);
+
 int at_collect_windows_f32(const float* x, int64_t rows, int64_t T, int win, int hop, float* out, void* stream);
 int at_overlap_add_f32(const float* frames, int64_t rows, int64_t nw, int win, int hop, int64_t trim, int64_t out_len, float* out,
                        void* stream);

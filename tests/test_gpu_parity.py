@@ -434,6 +434,72 @@ def test_fir_direct_and_fft_forms(L, highpass):
     assert rel_err(shared, ((x.double() - ref0) if highpass else ref0).float()) < REL
 
 
+@pytest.mark.parametrize("L,T", [(6145, 10007), (9001, 30000), (44983, 30001)])
+@pytest.mark.parametrize("highpass", [False, True])
+def test_fir_long_form(L, T, highpass):
+    """Filters of thousands of taps (HighPass's default 50 / 100 / 250 Hz cutoffs at 44.1 kHz: 44 983 / 22 491 / 8 997 taps)
+    run as ONE circular convolution by the four-step FFT instead of one overlap-save pass per 1024 taps
+    (kernels._fir_long): against float64 conv1d with replicate padding, asymmetric per-item and shared taps, taps longer
+    than the signal, and against the overlap-save form."""
+    from audiotools_amd import kernels
+    B, C = 3, 2
+    g = torch.Generator().manual_seed(L + T)
+    x = torch.randn(B, C, T, generator=g)
+    taps = torch.randn(B, L, generator=g) / L ** 0.5
+    half = (L - 1) // 2
+    xp = torch.nn.functional.pad(x.double(), (half, half), mode="replicate")
+    ref = torch.stack([torch.nn.functional.conv1d(xp[b][:, None], taps[b].double()[None, None])[:, 0] for b in range(B)])
+    if highpass:
+        ref = x.double() - ref
+    auto = kernels.fir_per_item(x.cuda(), taps.cuda(), highpass=highpass)            # "auto" picks the long form here
+    long_ = kernels.fir_per_item(x.cuda(), taps.cuda(), highpass=highpass, method="long")
+    fft = kernels.fir_per_item(x.cuda(), taps.cuda(), highpass=highpass, method="fft")
+    assert torch.equal(auto, long_)
+    assert rel_err(long_, ref.float()) < REL and rel_err(fft, ref.float()) < REL
+    shared = kernels.fir_per_item(x.cuda(), taps[:1].cuda(), highpass=highpass, method="long")
+    ref0 = torch.nn.functional.conv1d(xp.reshape(-1, 1, xp.shape[-1]), taps[0].double()[None, None]).reshape(B, C, T)
+    assert rel_err(shared, ((x.double() - ref0) if highpass else ref0).float()) < REL
+    buf = torch.empty_like(auto)
+    assert kernels.fir_per_item(x.cuda(), taps.cuda(), highpass=highpass, out=buf) is buf and torch.equal(buf, auto)
+
+
+@pytest.mark.parametrize("mulaw", [False, True])
+def test_quantization_kernel_equals_the_torch_chain(mulaw):
+    """quantization / mulaw_quantization on HIP tensors run as one kernel (at_quantize_f32) that performs the reference's
+    chain one float32 operation at a time (effects.py:452-527).  Against the same chain run by torch on the device and on
+    the CPU: equal except where a transcendental's last bit moves a sample across a level boundary (< 1e-4 of the samples,
+    one level apart)."""
+    g = torch.Generator().manual_seed(17)
+    x = (0.5 * torch.randn(5, 2, 40000, generator=g)).clamp_(-1, 1)
+    x[0, 0, :6] = torch.tensor([1.0, -1.0, 0.0, -0.0, 1e-8, -1e-8])
+    ch = torch.tensor([8, 256, 32, 3, 65536])
+
+    def chain(a, q):
+        if not mulaw:
+            v = ((a + 1) / 2 * q).floor() / q
+            v = 2 * v - 1
+        else:
+            mu = q - 1.0
+            v = torch.sign(a) * torch.log1p(mu * torch.abs(a)) / torch.log1p(mu)
+            v = ((v + 1) / 2 * mu + 0.5).to(torch.int64)
+            v = (v / mu) * 2 - 1.0
+            v = torch.sign(v) * (torch.exp(torch.abs(v) * torch.log1p(mu)) - 1.0) / mu
+        return a - (a - v)
+
+    s = A.AudioSignal(x.clone(), 16000).to("cuda")
+    got = (s.mulaw_quantization(ch.clone()) if mulaw else s.quantization(ch.clone())).audio_data.cpu()
+    for ref in (chain(x.cuda(), ch.cuda()[:, None, None]).cpu(), chain(x, ch[:, None, None])):
+        step = 2.0 / (ch[:, None, None].float() - (1.0 if mulaw else 0.0))
+        diff = (got - ref).abs()
+        off = diff > 1e-6
+        assert float(off.float().mean()) < 1e-4
+        if not mulaw:
+            assert bool((diff <= step * 1.001 + 1e-6).all())
+    one = A.AudioSignal(x.clone(), 16000).to("cuda")
+    same = (one.mulaw_quantization(8) if mulaw else one.quantization(8)).audio_data.cpu()     # one setting for the batch
+    assert float(((same - chain(x, torch.tensor(8.0))).abs() > 1e-6).float().mean()) < 1e-4
+
+
 def test_reference_dsp_properties_gpu():
     """tests/core/test_dsp.py:76-109 on the HIP path."""
     sr, f = 44100, 440
