@@ -18,7 +18,17 @@ dev = "cuda"
 
 
 def timed(fn, label, n=3):
+    import gc
     fn(); torch.cuda.synchronize()
+    gc.collect()        # a generation-2 collection of the thousands of parameter objects inside the timed loop read as
+    gc.disable()        # "low_pass 20 ms, host enqueue 19.9 ms" in two sessions (s10, s18) and 0.75 ms in three others
+    try:
+        return _timed(fn, label, n)
+    finally:
+        gc.enable()
+
+
+def _timed(fn, label, n):
     st0 = torch.cuda.memory_stats()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
