@@ -44,9 +44,16 @@ using at::gfft::RowLayout;
 using at::gfft::run_passes;
 using at::gfft::factor;
 
+// A/B builds of the row kernel's organisation (AT_HIPCC_FLAGS): threads per row-pair workgroup and the longest row
+#ifndef AT_ROW_THREADS
+#define AT_ROW_THREADS 256
+#endif
+#ifndef AT_ROW_N2
+#define AT_ROW_N2 2048
+#endif
 constexpr int THREADS = 256;
 constexpr int MAX_N1 = 512;
-constexpr int MAX_N2 = 2048;
+constexpr int MAX_N2 = AT_ROW_N2;
 struct Plan {
   int N1, N2;
   int cw, lcw;              // columns per colfft tile (power of two), log2
@@ -222,9 +229,9 @@ struct RowArgs {
 // 256 x 2 (176 registers) 2.7 ms, 256 x 3 (168 registers, 8 dwords spilled) 2.0 ms, 512 x 2 (98
 // registers) 2.0 ms, 1024 x 2 (59 registers) 2.2 ms: past three independent workgroups per CU the
 // wave organisation does not matter (profiles/r02_notes.md).
-constexpr int RTHREADS = 256;
-constexpr int ROW_WGS = 3;
-constexpr int ROW_LOADS = TILE_POINTS / RTHREADS;     // points of a row pair per thread
+constexpr int RTHREADS = AT_ROW_THREADS;
+constexpr int ROW_WGS = 3 * 256 / RTHREADS;           // three waves per SIMD
+constexpr int ROW_LOADS = 2 * MAX_N2 / RTHREADS;      // points of a row pair per thread
 constexpr int SPEC_ITERS = MAX_N2 / RTHREADS;         // bins of one row per thread
 
 // X[k], X[M-k] of the real signal from Z[k], Z[M-k] of its half-length complex transform; w = w_T^k.
