@@ -1480,6 +1480,25 @@ def test_istft_tiled_sizes(n_fft, T, B):
     assert rel_err(y2.reshape(ref2.shape), ref2) < REL
 
 
+@pytest.mark.parametrize("n_fft,hop,T,B", [(400, 400, 4000, 2), (400, 200, 400, 3), (400, 200, 1000, 1), (1200, 600, 2400 + 7, 2),
+                                          (1920, 96, 12000, 1), (320, 40, 3000, 2), (512, 100, 100000, 2), (400, 160, 160 * 700, 4),
+                                          (1000, 250, 30000, 3)])
+def test_istft_one_pass_edge_shapes(n_fft, hop, T, B):
+    """The one-pass inverse of the run-time sizes (istft_generic_ola_kernel) at its corners: hop = n_fft (no history at
+    all), one to three frames per row, a history of nineteen / seven frames (hop = n_fft / 20, n_fft / 8), a power-of-two
+    size with a hop the fused kernels do not take, rows long enough for several runs with a warm-up tile each; modified
+    spectra against torch.istft with a rectangular window where Hann would violate NOLA."""
+    wt = "hann" if n_fft % hop == 0 and n_fft // hop >= 2 else None
+    win = tables.window("hann", n_fft, "cuda") if wt else torch.ones(n_fft, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(n_fft + hop)
+    n_frames = 1 + T // hop
+    X = torch.randn(B, 2, n_fft // 2 + 1, n_frames, dtype=torch.complex64, device="cuda", generator=g)
+    X = X.transpose(2, 3).contiguous().transpose(2, 3)            # bin-contiguous, as stft() hands it over
+    y = kernels.istft(X, win, n_fft, hop, T)
+    ref = torch.istft(X.reshape(-1, X.shape[-2], X.shape[-1]).cpu(), n_fft, hop, window=win.cpu(), center=True, length=T)
+    assert y.shape[-1] == T and rel_err(y.reshape(ref.shape), ref) < REL
+
+
 def test_stft_generic_match_stride_and_mel():
     x = synth.audio_batch(2, 1, 40000 + 13, seed=3, gaps=False)
     s = A.AudioSignal(x.clone(), 96000).to("cuda")
