@@ -40,6 +40,9 @@
 #ifndef AT_STFT_WPS
 #define AT_STFT_WPS 2           // resident waves per SIMD the register budget allows
 #endif
+#ifndef AT_STFT_PIPE
+#define AT_STFT_PIPE 1           // A/B build: 0 = the groups of the n_fft <= 1024 kernels load behind their predecessor's stores
+#endif
 #ifndef AT_STFT_DEBUGMODES
 #define AT_STFT_DEBUGMODES 0     // 1: honour AT_STFT_DEBUG=1 (no stores) / 2 (store only) at run time
 #endif
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
 #if AT_STFT_DEBUGMODES
 #define STORE_OK(v) (live && !(A.debug == 1 && (v) != 12345.678f))
 #else
-#define STORE_OK(v) (FW == 1 || live)
+#define STORE_OK(v) true        // every frame slot of a wave holds a real frame (slots past the row's last frame repeat it)
 #endif
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   float* s_win = lds_f + NW * 2 * WAVE_LDS_SLOTS;
@@ -198,13 +201,32 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
   const bool can_reuse = (FW == 1) && A.reuse_shift == SH;
   float2 raw[16];          // un-windowed samples of the frame being processed (register reuse)
   float2 nxt[SH];          // the SH new loads of the NEXT frame, issued ahead of this frame's stores
+  // FW > 1 (n_fft <= 1024: 2 ... 32 frames per wave, no overlap between consecutive groups of a wave): ALL sixteen loads
+  // of the next group, issued BEFORE this group's transform (a whole group of lead time: the HBM write stream of the
+  // other waves stretches the load latency, profiles/r04_notes.md 12) and therefore ahead of this group's stores
+  // (vmcnt retires in order: the samples are waited for with the stores still in flight).
+  constexpr bool PIPE = FW > 1 && AT_STFT_PIPE;
+  float2 nxt16[PIPE ? 16 : 1];
 
   // ---- one frame group: window, FFT, split, stores (+ mel).  `a` holds the raw samples.
   // Returns true when the loads of the next consecutive frame were issued into nxt[].
   auto frame_body = [&](float2 (&a)[16], const float* __restrict__ xr, int64_t row, int gb, int64_t s0,
                         bool want_next) __attribute__((always_inline)) -> bool {
-    const int fo = gb * FW + fs;       // output frame index of this thread's frame
-    const bool live = fo < n_out;
+    const int fo = min(gb * FW + fs, n_out - 1);   // output frame of this thread's slot; slots past the row's end repeat its last frame
+    [[maybe_unused]] const bool live = true;
+    bool have_nxt = false;
+    if constexpr (PIPE) {
+      // the next group of this wave's run: same row, every slot a real interior frame (wave-uniform), vector loads
+      if (VEC2 && want_next && (gb + 2) * FW <= n_out) {
+        const int64_t s0n = s0 + (int64_t)FW * A.hop;
+        if (__all(A.pad == 0 && s0n >= 0 && s0n + N <= Ti)) {
+          have_nxt = true;
+          const float2* __restrict__ p = reinterpret_cast<const float2*>(xr + s0n);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) nxt16[q] = p[t + L * q];
+        }
+      }
+    }
     if (can_reuse) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) raw[q] = a[q];
@@ -218,7 +240,6 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
       }
     }
     float2* __restrict__ orow = A.out + ((int64_t)row * n_out + fo) * (M + 1);
-    bool have_nxt = false;
 
     if (AT_STFT_DEBUGMODES && A.debug == 2) {  // store-only experiment: same addresses, no transform
       if (live) {
@@ -398,10 +419,10 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
       const int64_t row = g / gpr;
       int gb = (int)(g - row * gpr);
       const float* __restrict__ xr = A.x + row * A.T;
-      const int fo = gb * FW + fs;
-      const bool live = fo < n_out;
+      const int fo = min(gb * FW + fs, n_out - 1);          // (slots past the row's last frame repeat it)
+      const bool live = true;
       int64_t s0 = ((int64_t)fo + A.frame_lo) * A.hop - M;  // first sample, outer-padded coords
-      const bool interior = !live || (A.pad == 0 && s0 >= 0 && s0 + N <= Ti);
+      const bool interior = A.pad == 0 && s0 >= 0 && s0 + N <= Ti;
       float2 a[16];
       if (__all(interior)) {
         if (!live) {
@@ -440,12 +461,18 @@ __global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const St
       // s_waitcnt for nxt[] tolerates the stores (vmcnt(17+)) instead of draining them.
       while (more) {
         ++gb;
-        s0 += A.hop;
         float2 b[16];
+        if constexpr (PIPE) {
+          s0 += (int64_t)FW * A.hop;
 #pragma unroll
-        for (int q = 0; q < 16 - SH; ++q) b[q] = raw[q + SH];
+          for (int q = 0; q < 16; ++q) b[q] = nxt16[q];
+        } else {
+          s0 += A.hop;
 #pragma unroll
-        for (int q = 0; q < SH; ++q) b[16 - SH + q] = nxt[q];
+          for (int q = 0; q < 16 - SH; ++q) b[q] = raw[q + SH];
+#pragma unroll
+          for (int q = 0; q < SH; ++q) b[16 - SH + q] = nxt[q];
+        }
         more = frame_body(b, xr, row, gb, s0, g + 1 < g_end);
         ++g;
       }
