@@ -514,3 +514,23 @@ def test_circular_convolution_adjoints(monkeypatch):
         ref = torch.autograd.grad((torch.fft.irfft(torch.fft.rfft(w, T) * torch.fft.rfft(x, T), T) * s * g).sum(), (x, w, s))
         for a, b in zip(got, ref):
             assert (a - b).abs().max() < 1e-11
+
+
+def test_istft_workspace_follows_the_inverse_path():
+    """at_istft_workspace_bytes (a host function) sizes the scratch of whichever inverse the shape takes: the one-pass
+    kernels need the overlap-add envelope only, the frame-buffer path rows x frames x n_fft floats.  Round 4: run-time sizes
+    with an even hop and an even, smooth n_fft / 2 -- speech windows, power-of-two sizes with hops the fused kernels do not
+    take -- are one-pass (istft_generic_ola_kernel); odd hops, odd n_fft / 2 and a history deeper than a tile are not."""
+    from audiotools_amd import _native
+    lib = _native.lib()
+    rows, n = 6, 101
+    env = lambda n_fft, hop: ((n - 1) * hop + n_fft) * 4
+    buf = lambda n_fft: rows * n * n_fft * 4
+    for n_fft, hop in [(400, 160), (400, 100), (1200, 300), (1920, 480), (512, 100), (128, 12), (400, 400), (320, 40), (1000, 250)]:
+        assert lib.at_istft_workspace_bytes(rows, n, n_fft, hop) == env(n_fft, hop), (n_fft, hop)
+    for n_fft, hop in [(100, 33), (882, 441), (1764, 441), (4096, 1000), (1920, 96), (16384, 4096)]:
+        assert lib.at_istft_workspace_bytes(rows, n, n_fft, hop) == buf(n_fft), (n_fft, hop)
+    # the fused / tiled sizes keep their own (envelope + dump + zero page) layout: at least the envelope, far below the buffer
+    for n_fft, hop in [(2048, 512), (512, 128), (128, 8), (4096, 1024), (8192, 2048)]:
+        got = lib.at_istft_workspace_bytes(rows, n, n_fft, hop)
+        assert env(n_fft, hop) <= got < env(n_fft, hop) + 64 * 1024 + 4 * n_fft * 4, (n_fft, hop, got)
