@@ -534,3 +534,25 @@ def test_istft_workspace_follows_the_inverse_path():
     for n_fft, hop in [(2048, 512), (512, 128), (128, 8), (4096, 1024), (8192, 2048)]:
         got = lib.at_istft_workspace_bytes(rows, n, n_fft, hop)
         assert env(n_fft, hop) <= got < env(n_fft, hop) + 64 * 1024 + 4 * n_fft * 4, (n_fft, hop, got)
+
+
+def test_one_pass_inverse_model_vs_torch_istft():
+    """tools/emulate_istft_ola.py: tile-level model of istft_generic_ola_kernel's index logic (plan, runs with a warm-up
+    tile, history slots in front of the tile, zero spectra outside the row, pair-wise gather in ascending frame order,
+    envelope bounds, centre trim) -- every output written exactly once, equal to torch.istft; and its plan agrees with
+    the library's (at_istft_workspace_bytes tells which path a shape takes)."""
+    from audiotools_amd import _native
+    m = _load_tool("emulate_istft_ola")
+    lib = _native.lib()
+    rng = np.random.default_rng(5)
+    for n_fft, hop, T, rows, runs in [(400, 160, 2403, 2, 3), (400, 100, 1500, 1, 2), (1200, 300, 4800, 1, 2), (400, 400, 1200, 1, 1),
+                                      (320, 40, 900, 1, 3), (512, 100, 2500, 2, None)]:
+        n_frames = 1 + T // hop
+        X = (rng.standard_normal((rows, n_frames, n_fft // 2 + 1)) + 1j * rng.standard_normal((rows, n_frames, n_fft // 2 + 1))).astype(np.complex64)
+        win = np.hanning(n_fft + 1)[:-1].astype(np.float32) if n_fft % hop == 0 and n_fft // hop >= 2 else np.ones(n_fft, np.float32)
+        got = m.istft(X, win, hop, T, force_runs=runs)
+        ref = torch.istft(torch.from_numpy(X).transpose(1, 2), n_fft, hop, window=torch.from_numpy(win), center=True, length=T).numpy()
+        assert np.abs(got - ref).max() < 2e-6 * np.abs(ref).max(), (n_fft, hop)
+    for n_fft, hop in [(400, 160), (1920, 480), (512, 100), (128, 12), (100, 33), (882, 441), (4096, 1000), (1920, 96), (16384, 4096)]:
+        one_pass = lib.at_istft_workspace_bytes(3, 50, n_fft, hop) == (49 * hop + n_fft) * 4
+        assert one_pass == (m.plan(n_fft, hop) is not None), (n_fft, hop)
