@@ -102,6 +102,10 @@ template <bool NT> __device__ __forceinline__ float4 ldg4(const float4* p) {
 template <bool NT> __device__ __forceinline__ void stg(float* p, float v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
+template <bool NT> __device__ __forceinline__ void stg2(float2* p, float2 v) {        // 8-byte aligned
+  const v2f_t u = {v.x, v.y};
+  if constexpr (NT) __builtin_nontemporal_store(u, reinterpret_cast<v2f_t*>(p)); else *p = v;
+}
 template <bool NT> __device__ __forceinline__ void stg2_a4(float* p, float x, float y) {
   const v2f_a4_t u = {x, y};
   if constexpr (NT) __builtin_nontemporal_store(u, reinterpret_cast<v2f_a4_t*>(p)); else *reinterpret_cast<v2f_a4_t*>(p) = u;
