@@ -556,3 +556,44 @@ def test_one_pass_inverse_model_vs_torch_istft():
     for n_fft, hop in [(400, 160), (1920, 480), (512, 100), (128, 12), (100, 33), (882, 441), (4096, 1000), (1920, 96), (16384, 4096)]:
         one_pass = lib.at_istft_workspace_bytes(3, 50, n_fft, hop) == (49 * hop + n_fft) * 4
         assert one_pass == (m.plan(n_fft, hop) is not None), (n_fft, hop)
+
+
+def test_long_fir_as_one_circular_convolution(monkeypatch):
+    """kernels._fir_long: a per-item FIR of thousands of taps (replicate padding) written as ONE circular convolution at a
+    planned length N >= T + L - 1 -- the padded signal, the flipped taps, the rotation by L - 1, the slice, the high-pass
+    form, shared taps.  The convolution kernel is replaced by a float64 torch stand-in with the documented semantics of
+    at_longconv_room_f32 (IR zero-padded to N and read rotated left by `shift`), so the index algebra is checked on the CPU."""
+    from audiotools_amd import kernels
+
+    def stand_in(x, ir, shift=None, scale=None, want_peaks=False):
+        B, C, N = x.shape
+        L = ir.shape[-1]
+        irz = torch.zeros(ir.shape[0], ir.shape[1], N, dtype=torch.float64)
+        irz[..., :L] = ir.double()
+        if shift is not None:
+            idx = (torch.arange(N)[None, None] + shift.reshape(ir.shape[0], ir.shape[1], 1)) % N
+            irz = torch.gather(irz, -1, idx)
+        return torch.fft.irfft(torch.fft.rfft(irz, N) * torch.fft.rfft(x.double(), N), N).float()
+
+    monkeypatch.setattr(kernels, "room_convolve", stand_in)
+    g = torch.Generator().manual_seed(0)
+    for B, C, T, L in [(2, 2, 3000, 6145), (3, 1, 5000, 8001), (2, 1, 900, 6201)]:
+        x = torch.randn(B, C, T, generator=g)
+        taps = torch.randn(B, L, generator=g) / L ** 0.5
+        H = (L - 1) // 2
+        N = kernels._fir_long_length(T + L - 1)
+        assert N >= T + L - 1 and N % 2 == 0 and kernels.longconv_supported(N)
+        xp = torch.nn.functional.pad(x.double(), (H, H), mode="replicate")
+        ref = torch.stack([torch.nn.functional.conv1d(xp[b][:, None], taps[b].double()[None, None])[:, 0] for b in range(B)])
+        Lp = (L + 7) // 8 * 8
+        tp = torch.zeros(B, Lp)
+        tp[:, :L] = taps
+        for highpass in (False, True):
+            want = (x.double() - ref) if highpass else ref
+            got = kernels._fir_long(x, tp, B, L, highpass, None)
+            assert (got.double() - want).abs().max() < 2e-5 * want.abs().max(), (T, L, highpass)
+            out = torch.empty_like(x)
+            assert kernels._fir_long(x, tp, B, L, highpass, out) is out and torch.equal(out, got)
+        shared = kernels._fir_long(x, tp[:1], 1, L, False, None)
+        ref0 = torch.nn.functional.conv1d(xp.reshape(-1, 1, xp.shape[-1]), taps[0].double()[None, None]).reshape(B, C, T)
+        assert (shared.double() - ref0).abs().max() < 2e-5 * ref0.abs().max()
