@@ -99,6 +99,15 @@ class _Aliased:
         A.AudioSignal.write = lambda self_, path: self_
         # FFMPEGMixin.ffmpeg_loudness shells out to ffmpeg's ebur128 filter (out of scope); the tests only
         # use it to fill metadata["loudness"], which the package's own BS.1770 meter supplies here
+        # apply_codec pipes the audio through an ffmpeg codec (out of scope); test_audio_grad lists it with "no gradient
+        # expected", which a detached copy satisfies -- the other 40 operations of that test run on the package
+        self.had_codec = "apply_codec" in A.AudioSignal.__dict__
+        if not self.had_codec:
+            A.AudioSignal.apply_codec = lambda self_, *a, **k: A.AudioSignal(self_.audio_data.detach().clone(), self_.sample_rate)
+        # the display mixin (specshow / waveplot) is out of scope; test_preemphasis plots before it filters
+        self.had_show = hasattr(A.AudioSignal, "specshow")
+        if not self.had_show:
+            A.AudioSignal.specshow = lambda self_, *a, **k: None
         self.had_ffl = "ffmpeg_loudness" in A.AudioSignal.__dict__
         if not self.had_ffl:
             A.AudioSignal.ffmpeg_loudness = lambda self_, quiet=True: self_.loudness()
@@ -111,6 +120,10 @@ class _Aliased:
         shutil.rmtree(self.tmp, ignore_errors=True)
         if not self.had_ffl:
             del A.AudioSignal.ffmpeg_loudness
+        if not self.had_codec:
+            del A.AudioSignal.apply_codec
+        if not self.had_show:
+            del A.AudioSignal.specshow
         if self.orig_write is not None:
             A.AudioSignal.write = self.orig_write
         else:
@@ -165,7 +178,7 @@ RUN = {
                                   "test_resample", "test_batching"],
     "core/test_util.py": ["test_check_random_state", "test_seed", "test_hz_to_bin", "test_prepare_batch", "test_sample_dist",
                           "test_collate"],
-    "core/test_grad.py": ["test_batch_grad"],
+    "core/test_grad.py": ["test_batch_grad", "test_audio_grad"],
     "core/test_loudness.py": ["test_loudness_short", "test_batch_loudness", "test_fir_accuracy"],
     "data/test_transforms.py": ["test_transform", "test_compose_basic", "test_compose_with_duplicate_transforms",
                                 "test_nested_compose", "test_compose_filtering", "test_sequential_compose", "test_choose_basic",
@@ -174,7 +187,7 @@ RUN = {
     "metrics/test_spectral.py": None,
     "metrics/test_distance.py": None,
     "core/test_dsp.py": ["test_overlap_add", "test_inplace_overlap_add", "test_low_pass", "test_high_pass",
-                         "test_mask_frequencies", "test_mask_timesteps", "test_shift_phase", "test_corrupt_phase"],
+                         "test_mask_frequencies", "test_mask_timesteps", "test_shift_phase", "test_corrupt_phase", "test_preemphasis"],
     "core/test_effects.py": ["test_normalize", "test_volume_change", "test_mix", "test_convolve", "test_mel_filterbank",
                              "test_equalizer", "test_clip_distortion", "test_quantization", "test_mulaw_quantization",
                              "test_impulse_response_augmentation", "test_apply_ir", "test_ensure_max_of_audio"],
@@ -183,15 +196,14 @@ SKIPPED = {
     "core/test_audio_signal.py::test_io": "writes and re-reads audio files",
     "core/test_audio_signal.py::test_salient_excerpt": "writes a wav with soundfile and reads it back",
     "core/test_util.py::test_find_audio / test_chdir": "file-system helpers over the reference's own tree",
-    "core/test_grad.py::test_audio_grad": "its op list includes apply_codec (ffmpeg codecs, out of scope)",
     "core/test_loudness.py (all but three)": "soundfile + the ITU-R BS.2217 recordings (git-lfs pointers here); "
                                              "tests/test_leaf_pins.py holds the EBU Tech 3341 known answers instead",
     "data/test_datasets.py": "AudioDataset / ConcatDataset / samplers are out of scope (SURVEY.md 2.1)",
-    "core/test_dsp.py::test_preemphasis": "calls specshow() (display mixin, out of scope); preemphasis itself: tests/test_api_parity.py",
     "core/test_effects.py::test_pipeline": "writes / reads audio files",
+    "core/test_effects.py::test_pitch_shift / test_time_stretch": "assert batched == single with np.allclose's atol of 1e-8; the CPU "
+        "torch formulation of the phase vocoder differs by one ulp (6e-8) between batch sizes (the reference pipes every item "
+        "through sox on its own); the property holds bit for bit on the HIP path: tests/test_stretch.py",
     "core/test_effects.py::test_codec": "ffmpeg codec round trip (apply_codec is out of scope)",
-    "core/test_effects.py::test_pitch_shift": "sox effects chain of the reference (pitch_shift here is a phase vocoder: tests/test_stretch.py)",
-    "core/test_effects.py::test_time_stretch": "sox effects chain of the reference",
 }
 
 def _functions(module, names):
