@@ -92,6 +92,10 @@ class _Aliased:
         for name in os.listdir(os.path.join(REF_TESTS, "audio")):
             if name.endswith(".csv"):
                 shutil.copy(os.path.join(REF_TESTS, "audio", name), os.path.join(self.tmp, "tests", "audio", name))
+        # (test_find_audio walks "tests/": two empty .wav files give it something to find; nothing opens them)
+        os.makedirs(os.path.join(self.tmp, "tests", "audio", "found"))
+        for name in ("one.wav", "two.wav"):
+            open(os.path.join(self.tmp, "tests", "audio", "found", name), "wb").close()
         os.chdir(self.tmp)
         # file output is out of scope; the regression recordings these calls would be
         # compared with are git-lfs pointers here, so "first run: write the file" is what the tests take
@@ -176,8 +180,8 @@ RUN = {
                                   "test_truncate", "test_trim", "test_to_from_ops", "test_device", "test_stft",
                                   "test_log_magnitude", "test_mel_spectrogram", "test_mfcc", "test_to_mono", "test_float",
                                   "test_resample", "test_batching"],
-    "core/test_util.py": ["test_check_random_state", "test_seed", "test_hz_to_bin", "test_prepare_batch", "test_sample_dist",
-                          "test_collate"],
+    "core/test_util.py": ["test_check_random_state", "test_seed", "test_hz_to_bin", "test_find_audio", "test_chdir",
+                          "test_prepare_batch", "test_sample_dist", "test_collate"],
     "core/test_grad.py": ["test_batch_grad", "test_audio_grad"],
     "core/test_loudness.py": ["test_loudness_short", "test_batch_loudness", "test_fir_accuracy"],
     "data/test_transforms.py": ["test_transform", "test_compose_basic", "test_compose_with_duplicate_transforms",
@@ -195,7 +199,6 @@ RUN = {
 SKIPPED = {
     "core/test_audio_signal.py::test_io": "writes and re-reads audio files",
     "core/test_audio_signal.py::test_salient_excerpt": "writes a wav with soundfile and reads it back",
-    "core/test_util.py::test_find_audio / test_chdir": "file-system helpers over the reference's own tree",
     "core/test_loudness.py (all but three)": "soundfile + the ITU-R BS.2217 recordings (git-lfs pointers here); "
                                              "tests/test_leaf_pins.py holds the EBU Tech 3341 known answers instead",
     "data/test_datasets.py": "AudioDataset / ConcatDataset / samplers are out of scope (SURVEY.md 2.1)",
