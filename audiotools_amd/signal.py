@@ -506,6 +506,33 @@ class AudioSignal(SpectralMixin, EffectMixin, LoudnessMixin, ImpulseResponseMixi
 
     __repr__ = __str__
 
+    def markdown(self):
+        """The signal's description as a two-column markdown table (audio_signal.py:1568-1597)."""
+        rows = ["| Key | Value", "|---|---"] + [f"| {k} | {v} |" for k, v in self._info().items()]
+        return "\n".join(rows) + "\n"
+
+    def __rich__(self):
+        """``rich.print(signal)``: the same description as a rich table (audio_signal.py:1607-1618)."""
+        from rich.table import Table
+
+        table = Table(title=type(self).__name__)
+        table.add_column("Key", style="green")
+        table.add_column("Value", style="cyan")
+        for k, v in self._info().items():
+            table.add_row(k, str(v))
+        return table
+
+    def hash(self):
+        """A name for the audio CONTENT (audio_signal.py:673-703 hashes the bytes of a temporary wav file; here the
+        float32 samples, their shape and the rate go through sha256 directly -- equal audio, equal hash; no file)."""
+        import hashlib
+
+        h = hashlib.sha256()
+        a = self.audio_data.detach().to("cpu", torch.float32).contiguous()
+        h.update(repr((tuple(a.shape), int(self.sample_rate))).encode())
+        h.update(a.numpy().tobytes())
+        return h.hexdigest()
+
     # ---------------------------------------------------- equality/indexing
     def __eq__(self, other):
         for k, v in list(self.__dict__.items()):

@@ -9,8 +9,9 @@ not present in this environment (the files are 130-byte pointers), so the three 
 are served from in-memory synthetic audio through the package's ``mem://`` registry -- the
 assertions these tests make are properties of the operations, not of the recordings.
 
-Skipped (with the reason) are: tests that shell out to ffmpeg / sox, write and re-read audio files,
-plot, or compare against third-party packages that are not installed.  Runs only where
+Skipped (with the reason) are: tests that shell out to ffmpeg / sox or need recordings with a known content.
+``write()`` registers the signal under its path in the package's in-memory source registry (a lossless stand-in for
+encoding a file and decoding it again), ``specshow`` is a no-op, ``apply_codec`` a detached copy.  Runs only where
 ``/root/reference`` exists (the build container); the travelling oracle covers the GPU box.
 """
 import importlib.util
@@ -33,6 +34,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(REF_TESTS), reason="reference 
 # path literal in the reference tests -> (channels, seconds, rate, kind)
 _RECORDINGS = {
     "tests/audio/spk/f10_script4_produced.wav": (1, 30.0, 44100, "speech"),
+    "tests/audio/spk/f10_script4_produced.mp3": (1, 30.0, 44100, "speech"),
     "tests/audio/nz/f5_script2_ipad_balcony1_room_tone.wav": (1, 30.0, 44100, "noise"),
     "tests/audio/ir/h179_Bar_1txts.wav": (1, 1.0, 44100, "ir"),
 }
@@ -100,7 +102,16 @@ class _Aliased:
         # file output is out of scope; the regression recordings these calls would be
         # compared with are git-lfs pointers here, so "first run: write the file" is what the tests take
         self.orig_write = A.AudioSignal.__dict__.get("write")
-        A.AudioSignal.write = lambda self_, path: self_
+        self.written = []
+
+        def _write(self_, path):
+            # ... except that a written signal can be read back: it is registered under its path in the package's
+            # in-memory source registry (the lossless stand-in for soundfile.write + a decoder)
+            A.util._memory_audio[str(path)] = (self_.audio_data[0].detach().cpu().clone(), self_.sample_rate)
+            self.written.append(str(path))
+            return self_
+
+        A.AudioSignal.write = _write
         # FFMPEGMixin.ffmpeg_loudness shells out to ffmpeg's ebur128 filter (out of scope); the tests only
         # use it to fill metadata["loudness"], which the package's own BS.1770 meter supplies here
         # apply_codec pipes the audio through an ffmpeg codec (out of scope); test_audio_grad lists it with "no gradient
@@ -132,7 +143,7 @@ class _Aliased:
             A.AudioSignal.write = self.orig_write
         else:
             del A.AudioSignal.write
-        for path in _RECORDINGS:
+        for path in list(_RECORDINGS) + self.written:
             A.util._memory_audio.pop(path, None)
         if not self.had_ds:
             del A.data.datasets.AudioDataset
@@ -175,7 +186,7 @@ def _param_sets(fn):
 
 # reference test module -> test functions run here (the others: see SKIPPED)
 RUN = {
-    "core/test_audio_signal.py": ["test_copy_and_clone", "test_arithmetic", "test_equality",
+    "core/test_audio_signal.py": ["test_io", "test_salient_excerpt", "test_copy_and_clone", "test_arithmetic", "test_equality",
                                   "test_indexing", "test_zeros", "test_waves", "test_zero_pad", "test_zero_pad_to",
                                   "test_truncate", "test_trim", "test_to_from_ops", "test_device", "test_stft",
                                   "test_log_magnitude", "test_mel_spectrogram", "test_mfcc", "test_to_mono", "test_float",
@@ -197,8 +208,6 @@ RUN = {
                              "test_impulse_response_augmentation", "test_apply_ir", "test_ensure_max_of_audio"],
 }
 SKIPPED = {
-    "core/test_audio_signal.py::test_io": "writes and re-reads audio files",
-    "core/test_audio_signal.py::test_salient_excerpt": "writes a wav with soundfile and reads it back",
     "core/test_loudness.py (all but three)": "soundfile + the ITU-R BS.2217 recordings (git-lfs pointers here); "
                                              "tests/test_leaf_pins.py holds the EBU Tech 3341 known answers instead",
     "data/test_datasets.py": "AudioDataset / ConcatDataset / samplers are out of scope (SURVEY.md 2.1)",
