@@ -203,7 +203,7 @@ RUN = {
     "metrics/test_distance.py": None,
     "core/test_dsp.py": ["test_overlap_add", "test_inplace_overlap_add", "test_low_pass", "test_high_pass",
                          "test_mask_frequencies", "test_mask_timesteps", "test_shift_phase", "test_corrupt_phase", "test_preemphasis"],
-    "core/test_effects.py": ["test_normalize", "test_volume_change", "test_mix", "test_convolve", "test_mel_filterbank",
+    "core/test_effects.py": ["test_normalize", "test_volume_change", "test_mix", "test_convolve", "test_pipeline", "test_mel_filterbank",
                              "test_equalizer", "test_clip_distortion", "test_quantization", "test_mulaw_quantization",
                              "test_impulse_response_augmentation", "test_apply_ir", "test_ensure_max_of_audio"],
 }
@@ -211,7 +211,6 @@ SKIPPED = {
     "core/test_loudness.py (all but three)": "soundfile + the ITU-R BS.2217 recordings (git-lfs pointers here); "
                                              "tests/test_leaf_pins.py holds the EBU Tech 3341 known answers instead",
     "data/test_datasets.py": "AudioDataset / ConcatDataset / samplers are out of scope (SURVEY.md 2.1)",
-    "core/test_effects.py::test_pipeline": "writes / reads audio files",
     "core/test_effects.py::test_pitch_shift / test_time_stretch": "assert batched == single with np.allclose's atol of 1e-8; the CPU "
         "torch formulation of the phase vocoder differs by one ulp (6e-8) between batch sizes (the reference pipes every item "
         "through sox on its own); the property holds bit for bit on the HIP path: tests/test_stretch.py",
