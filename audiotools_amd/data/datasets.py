@@ -38,6 +38,29 @@ from ..signal import AudioSignal
 NUM_TRIES = 8          # AudioSignal.salient_excerpt's default (audio_signal.py:232)
 
 
+def default_matcher(x, y) -> bool:
+    """Two paths belong to the same multitrack item when they sit in the same directory (datasets.py:138-139)."""
+    from pathlib import Path
+    return Path(x).parent == Path(y).parent
+
+
+def align_lists(lists, matcher: Callable = default_matcher):
+    """Line up several source lists (one per stem of a multitrack collection) item by item: walking the longest list,
+    every other list gets a ``{"path": "none"}`` placeholder wherever its entry at that position does not belong to the
+    same item, or where it has run out (datasets.py:142-150).  In place, like the reference; returns ``lists``."""
+    anchor = max(lists, key=len) if lists else []
+    pos = 0
+    while pos < len(anchor):
+        want = anchor[pos]["path"]
+        for other in lists:
+            if pos >= len(other):
+                other.append({"path": "none"})
+            elif not matcher(other[pos]["path"], want):
+                other.insert(pos, {"path": "none"})
+        pos += 1
+    return lists
+
+
 def _probe_uniform(state, lo, hi, n):
     """The next ``n`` values ``state.uniform(lo, hi)`` WOULD return, without consuming them."""
     twin = np.random.RandomState()
