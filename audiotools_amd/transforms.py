@@ -55,6 +55,10 @@ def _unflatten(d):
     return out
 
 
+# the names the reference's module carries (from the flatten_dict package: tuple keys)
+flatten, unflatten = _flatten, _unflatten
+
+
 def _assemble(values: list):
     """The batched value ``util.collate`` builds from B per-item values of one parameter -- where every item first
     became a tensor with ``torch.tensor(v)`` (transforms.py:224-227) and the B tensors were stacked -- assembled ONCE:
@@ -923,3 +927,12 @@ class FrequencyNoise(FrequencyMask):
 
     def _transform(self, signal, fmin_hz: float, fmax_hz: float):
         return _fill_masked_with_noise(signal.mask_frequencies(fmin_hz=fmin_hz, fmax_hz=fmax_hz))
+
+
+def __getattr__(name):
+    # the reference's module also carries the loader class (``from .datasets import AudioLoader``); resolved on first use
+    # here because data.datasets imports this module
+    if name == "AudioLoader":
+        from .data.datasets import AudioLoader
+        return AudioLoader
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

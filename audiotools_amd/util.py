@@ -300,3 +300,16 @@ class chdir:
     def __exit__(self, *exc):
         os.chdir(self._stack.pop())
         return False
+
+
+def flatten(d: dict) -> dict:
+    """Nested dictionary -> ``{(k1, k2, ...): leaf}`` (the default, tuple-keyed form of the ``flatten_dict`` package the
+    reference's util imports; empty dictionaries are kept as leaves)."""
+    from .transforms import _flatten
+    return _flatten(d)
+
+
+def unflatten(d: dict) -> dict:
+    """Inverse of :func:`flatten`."""
+    from .transforms import _unflatten
+    return _unflatten(d)
