@@ -302,14 +302,36 @@ class chdir:
         return False
 
 
-def flatten(d: dict) -> dict:
-    """Nested dictionary -> ``{(k1, k2, ...): leaf}`` (the default, tuple-keyed form of the ``flatten_dict`` package the
-    reference's util imports; empty dictionaries are kept as leaves)."""
+_JOINERS = {"tuple": None, "dot": ".", "underscore": "_", "path": "/"}
+
+
+def flatten(d: dict, reducer="tuple") -> dict:
+    """Nested dictionary -> flat dictionary (the ``flatten_dict`` package the reference's util imports): keys are tuples
+    of the path (``reducer="tuple"``, the default the reference uses) or the path joined with "." / "_" / "/"
+    (``"dot"``, ``"underscore"``, ``"path"``) or passed through a callable ``reducer(parent_key, key)``; empty
+    dictionaries are kept as leaves."""
     from .transforms import _flatten
-    return _flatten(d)
+    flat = _flatten(d)
+    if callable(reducer):
+        out = {}
+        for ks, v in flat.items():
+            key = None
+            for k in ks:
+                key = reducer(key, k)
+            out[key] = v
+        return out
+    if reducer not in _JOINERS:
+        raise ValueError(f"unknown reducer {reducer!r}")
+    sep = _JOINERS[reducer]
+    return flat if sep is None else {sep.join(str(k) for k in ks): v for ks, v in flat.items()}
 
 
-def unflatten(d: dict) -> dict:
-    """Inverse of :func:`flatten`."""
+def unflatten(d: dict, splitter="tuple") -> dict:
+    """Inverse of :func:`flatten` for the same ``splitter`` names (or a callable key -> tuple of path elements)."""
     from .transforms import _unflatten
-    return _unflatten(d)
+    if callable(splitter):
+        return _unflatten({tuple(splitter(k)): v for k, v in d.items()})
+    if splitter not in _JOINERS:
+        raise ValueError(f"unknown splitter {splitter!r}")
+    sep = _JOINERS[splitter]
+    return _unflatten(d if sep is None else {tuple(str(k).split(sep)): v for k, v in d.items()})

@@ -197,3 +197,16 @@ def test_signal_arithmetic_equals_reference(reference, op):
     xg = x.clone().requires_grad_()
     (f(A.AudioSignal(xg, 16000), 2.0).audio_data.sum()).backward()
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+def test_flatten_unflatten_names():
+    """util.flatten / unflatten (the reference re-exports the flatten_dict package's functions; transforms.py:130-131 and
+    util.py:365-371, 463 use the tuple-keyed default) and the names transforms carries."""
+    d = {"a": {"b": 1, "c": {"d": 2}}, "e": 3, "f": {}}
+    flat = A.util.flatten(d)
+    assert flat == {("a", "b"): 1, ("a", "c", "d"): 2, ("e",): 3, ("f",): {}} and A.util.unflatten(flat) == d
+    for name, sep in (("dot", "."), ("underscore", "_"), ("path", "/")):
+        f = A.util.flatten({"a": {"b": 1}, "e": 3}, name)
+        assert f == {"a" + sep + "b": 1, "e": 3} and A.util.unflatten(f, name) == {"a": {"b": 1}, "e": 3}
+    assert A.transforms.flatten(d) == flat and A.transforms.unflatten(flat) == d
+    assert A.transforms.AudioLoader is A.data.datasets.AudioLoader
