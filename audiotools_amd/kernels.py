@@ -511,6 +511,8 @@ def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False
             method = "fft" if L >= FIR_FFT_MIN_TAPS else "direct"
             if L >= FIR_LONG_MIN_TAPS and _LONGCONV and _fir_long_length(T + L - 1) is not None:
                 method = "long"
+    if method == "long" and _fir_long_length(T + L - 1) is None:
+        method = "fft"                                       # (forced, but no planned length: the overlap-save form)
     if method == "long":
         return _fir_long(audio, tp, rows, L, highpass, out)
     if method == "fft":
