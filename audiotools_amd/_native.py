@@ -13,7 +13,13 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-LIB_PATH = os.environ.get("AT_LIB_PATH") or os.path.join(LIB_DIR, "libaudiotools_amd.so")
+# The shipped library has no run-time switches.  AT_DEV_KNOBS=1 (set by the A/B tools under tools/, never by the
+# package) selects the development build of the same sources: -DAT_DEV_KNOBS=1 compiles the AT_* environment switches and
+# the measurement-only kernels in, as lib/libaudiotools_amd_dev.so (`python -m audiotools_amd._native --dev` builds it).
+DEV_KNOBS = os.environ.get("AT_DEV_KNOBS") == "1"
+SHIP_LIB_PATH = os.path.join(LIB_DIR, "libaudiotools_amd.so")
+DEV_LIB_PATH = os.path.join(LIB_DIR, "libaudiotools_amd_dev.so")
+LIB_PATH = os.environ.get("AT_LIB_PATH") or (DEV_LIB_PATH if DEV_KNOBS else SHIP_LIB_PATH)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 SOURCES = ["stft.hip", "istft.hip", "loudness.hip", "fir.hip", "firfft.hip", "irtools.hip", "specedit.hip", "fftconv.hip", "vocoder.hip", "stft_generic.hip", "longconv.hip", "resample_f16.hip"]
 
@@ -46,14 +52,23 @@ def _hipcc():
     return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-def compile_command(src, obj):
-    extra = os.environ.get("AT_HIPCC_FLAGS", "").split()
+def _dev_flags(dev):
+    """Extra compile flags of a development build (AT_HIPCC_FLAGS etc. are honoured there only)."""
+    if not dev:
+        return "", "", "", ""
+    return (os.environ.get("AT_HIPCC_FLAGS", ""), os.environ.get("AT_STFT_SLP", ""), os.environ.get("AT_NOSLP_ALL", ""),
+            os.environ.get("AT_MAXILP_FILES", ""))
+
+
+def compile_command(src, obj, dev=False):
+    hipcc_flags, stft_slp, noslp_all, maxilp_files = _dev_flags(dev)
+    extra = (["-DAT_DEV_KNOBS=1"] if dev else []) + hipcc_flags.split()
     per_file = FILE_FLAGS.get(os.path.basename(src), [])
-    if os.environ.get("AT_STFT_SLP") == "1" and os.path.basename(src) == "stft.hip":
+    if stft_slp == "1" and os.path.basename(src) == "stft.hip":
         per_file = []
-    if os.environ.get("AT_NOSLP_ALL") == "1":          # A/B builds: every source without SLP packing
+    if noslp_all == "1":          # A/B builds: every source without SLP packing
         per_file = ["-fno-slp-vectorize"]
-    if os.path.basename(src) in os.environ.get("AT_MAXILP_FILES", "").split(","):   # A/B builds of the scheduler strategy
+    if os.path.basename(src) in maxilp_files.split(","):   # A/B builds of the scheduler strategy
         per_file = [f for f in per_file if f not in _MAX_ILP] + _MAX_ILP
     return [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + per_file + extra + ["-o", obj, src]
 
@@ -62,23 +77,26 @@ def link_command(objs, out=LIB_PATH):
     return [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + list(objs) + LINK_FLAGS
 
 
-def hipcc_command(out=LIB_PATH):
+def hipcc_command(out=SHIP_LIB_PATH):
     """The build as shell commands (INTEGRATION.md quotes these)."""
     objs = [os.path.join(LIB_DIR, "obj", s.replace(".hip", ".o")) for s in SOURCES]
     cmds = [compile_command(os.path.join(CSRC_DIR, s), o) for s, o in zip(SOURCES, objs)]
     return cmds + [link_command(objs, out)]
 
 
-def build(force: bool = False, verbose: bool = False, out: str = None) -> str:
+def build(force: bool = False, verbose: bool = False, out: str = None, dev: bool = None) -> str:
     """Compile every HIP source for gfx950 (one object per source, in parallel; hipcc cross-compiles
-    without a GPU) and link ``lib/libaudiotools_amd.so``."""
-    out = out or LIB_PATH
-    obj_dir = os.path.join(os.path.dirname(out), "obj" if out == LIB_PATH else "obj_" + os.path.basename(out))
+    without a GPU) and link ``lib/libaudiotools_amd.so`` (``dev=True``: the development build with the A/B
+    switches, ``lib/libaudiotools_amd_dev.so``)."""
+    if dev is None:
+        dev = out is None and DEV_KNOBS and not os.environ.get("AT_LIB_PATH")
+    out = out or (DEV_LIB_PATH if dev else SHIP_LIB_PATH)
+    obj_dir = os.path.join(os.path.dirname(out), "obj" if out == SHIP_LIB_PATH else "obj_" + os.path.basename(out))
     os.makedirs(obj_dir, exist_ok=True)
     hdrs = [os.path.join(CSRC_DIR, h) for h in HEADERS]
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
     flag_stamp = os.path.join(obj_dir, "flags.txt")
-    flags_now = repr((os.environ.get("AT_HIPCC_FLAGS", ""), os.environ.get("AT_STFT_SLP", ""), os.environ.get("AT_NOSLP_ALL", ""), os.environ.get("AT_MAXILP_FILES", ""), FILE_FLAGS))
+    flags_now = repr((dev,) + _dev_flags(dev) + (FILE_FLAGS,))
     flags_same = os.path.exists(flag_stamp) and open(flag_stamp).read() == flags_now
     jobs, objs = [], []
     for s in SOURCES:
@@ -88,7 +106,7 @@ def build(force: bool = False, verbose: bool = False, out: str = None) -> str:
         stale = (force or not flags_same or not os.path.exists(obj)
                  or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time))
         if stale:
-            cmd = compile_command(src, obj)
+            cmd = compile_command(src, obj, dev)
             if verbose:
                 print(" ".join(cmd))
             jobs.append((cmd, subprocess.Popen(cmd)))
@@ -215,3 +233,9 @@ def current_stream(device):
     import torch
 
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+if __name__ == "__main__":      # python -m audiotools_amd._native [--dev] [--force]
+    import sys
+
+    print(build(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))

@@ -68,11 +68,22 @@ inline int device_cu_count() {
   return cu;
 }
 
-// Development switches are environment variables read ONCE per process, never on the launch path:
+// Development switches.  The SHIPPED library has none: kernel selection never depends on the caller's environment
+// (env_int_once folds to its default, the branches behind it are dead code).  A build with -DAT_DEV_KNOBS=1 (what the
+// A/B tools under tools/ load through AT_LIB_PATH; `python -m audiotools_amd._native --dev`) reads them from the
+// environment, ONCE per process and never on the launch path:
 //   static const int v = at::env_int_once("AT_...", default);
+#ifndef AT_DEV_KNOBS
+#define AT_DEV_KNOBS 0
+#endif
 inline int env_int_once(const char* name, int dflt) {
+#if AT_DEV_KNOBS
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
 }
 
 // Streaming global accesses with a compile-time cache policy: NT = true marks the access

@@ -618,8 +618,14 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   const int xcd = blockIdx.x % n_x;
   const int lblk = blockIdx.x / n_x;
   const int nblk_x = ((int)gridDim.x - xcd + n_x - 1) / n_x;
-  const int64_t g_lo = A.total_groups * xcd / n_x;
-  const int64_t g_hi = A.total_groups * (xcd + 1) / n_x;
+#if AT_DEV_KNOBS
+  // flags bits 14-16 (xor mask) and 17-18 (multiplier 1, 3, 5, 7): which span an XCD takes (8 spans only)
+  const int reg = n_x == 8 ? (((xcd * (2 * ((A.flags >> 17) & 3) + 1)) ^ ((A.flags >> 14) & 7)) & 7) : xcd;
+#else
+  const int reg = xcd;
+#endif
+  const int64_t g_lo = A.total_groups * reg / n_x;
+  const int64_t g_hi = A.total_groups * (reg + 1) / n_x;
   const int RUN = A.run;
   const int64_t Wtot = (int64_t)nblk_x * NW;
   const int64_t w0 = g_lo + ((int64_t)lblk * NW + wave) * RUN;
@@ -662,12 +668,29 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
     if constexpr (FLOOR) {
       const int64_t s0n = s0 + A.hop;
       const bool have_nxt = want_next && fo + 1 < gpr && s0n >= 0 && s0n + N <= Ti;
+#if AT_DEV_KNOBS
+      // development twins of the twin (tools/regime.py): flags bit 6 = no sample loads, bit 7 = no stores (the loaded
+      // samples are folded into a value that is stored only if it equals a constant it never takes)
+      if (A.flags & 64) {
+#pragma unroll
+        for (int i = 0; i < SH; ++i) nxt[i] = make_float2(1.f, 2.f);
+      } else
+#endif
       {
         const float2* __restrict__ p2 = reinterpret_cast<const float2*>(xr + (have_nxt ? s0n : 0)) + t + L * (16 - SH);
 #pragma unroll
         for (int i = 0; i < SH; ++i) nxt[i] = ld2<POL>(p2 + L * i);
       }
       float2* __restrict__ orow = A.out + ((int64_t)row * n_out + fo) * (M + 1);
+#if AT_DEV_KNOBS
+      if (A.flags & 128) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += raw[q].x * raw[q].y;
+        if (acc == 12345.678f) st2<POL>(orow + t, make_float2(acc, 0.f));
+        return have_nxt;
+      }
+#endif
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int k0 = 256 * m + t;
@@ -877,13 +900,36 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
     }   // !FLOOR
   };
 
-  for (int64_t gbase = w0; gbase < g_hi; gbase += Wtot * RUN) {
+#if AT_DEV_KNOBS
+  // flags bits 10-13 = k + 1: only the workgroups of XCD k (blockIdx % 8, the observed round-robin placement) work, the
+  // others leave -- with AT_STFT_NX=1 that XCD then writes every 8th group of runs of the whole range (tools/regime.py --affinity)
+  if (((A.flags >> 10) & 15) != 0 && (int)(blockIdx.x % 8) != ((A.flags >> 10) & 15) - 1) return;
+  // development schedules (tools/regime.py): flags bits 8-9 = 1: every XCD span starts its rounds at a different phase
+  // (span k begins k/8 of the way through and wraps); 2: spans are row-interleaved (span k owns rows k, k + 8, ...)
+  const int span_mode = (A.flags >> 8) & 3;
+  const int64_t n_rounds = (g_hi - g_lo + Wtot * RUN - 1) / (Wtot * RUN);
+#else
+  constexpr int span_mode = 0;
+#endif
+  for (int64_t rnd = 0;; ++rnd) {
+    int64_t gbase = w0 + rnd * Wtot * RUN;
+#if AT_DEV_KNOBS
+    if (span_mode == 1) {
+      if (rnd >= n_rounds) break;
+      gbase = w0 + ((rnd + n_rounds * xcd / n_x) % n_rounds) * Wtot * RUN;
+      if (gbase >= g_hi) continue;
+    } else
+#endif
+    if (gbase >= g_hi) break;
     const int64_t g_end = min(gbase + RUN, g_hi);
     int64_t g = gbase;
     while (g < g_end) {
       // ---- first frame of a stretch: all 16 loads (or the edge path), phase 0
-      const int64_t row = g / gpr;
+      int64_t row = g / gpr;
       int fo = (int)(g - row * gpr);
+#if AT_DEV_KNOBS
+      if (span_mode == 2) row = (row - g_lo / gpr) * n_x + xcd;     // (needs rows % n_x == 0: spans hold whole rows)
+#endif
       const float* __restrict__ xr = A.x + row * A.T;
       int64_t s0 = ((int64_t)fo + A.frame_lo) * A.hop - M;
       if (s0 >= 0 && s0 + N <= Ti) {   // wave-uniform
@@ -1011,6 +1057,21 @@ int launch_m(const StftArgs& A, bool vec2, int n_cu, hipStream_t stream) {
 
 using at::device_cu_count;
 using at::env_int_once;
+
+// Measurement knobs of the v2 schedule (development builds only -- at::env_int_once folds to the default in the shipped
+// library): read once; AT_STFT_TUNE=1 re-reads them on every call so that one process can sweep them (tools/stftsweep.py,
+// tools/regime.py).  The kernel and its zero-compute twin take the same values.
+struct V2Tuning { int flags, run_max, n_xcd, stagger; };
+static V2Tuning v2_tuning() {
+  auto read_tuning = [] {
+    return V2Tuning{env_int_once("AT_STFT_FLAGS", -1), env_int_once("AT_STFT_RUNMAX", AT_STFT_RUN_V2), env_int_once("AT_STFT_NX", 0),
+                    env_int_once("AT_STFT_STAGGERV2", 0)};
+  };
+  static const int tune_each_call = env_int_once("AT_STFT_TUNE", 0);
+  static V2Tuning tuning = read_tuning();
+  if (tune_each_call) tuning = read_tuning();
+  return tuning;
+}
 
 extern "C" {
 
@@ -1179,16 +1240,7 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
   static const int dbg_mode = AT_STFT_DEBUGMODES ? env_int_once("AT_STFT_DEBUG", 0) : 0;
   static const int allow_reuse = env_int_once("AT_STFT_REUSE", 1);
   static const int use_v2 = env_int_once("AT_STFT_V2", 1);
-  // measurement knobs of the v2 schedule, read once (AT_STFT_TUNE=1: re-read on every call so that one
-  // process can sweep them, tools/stftsweep.py)
-  struct Tuning { int flags, run_max, n_xcd, stagger; };
-  auto read_tuning = [] {
-    return Tuning{env_int_once("AT_STFT_FLAGS", -1), env_int_once("AT_STFT_RUNMAX", AT_STFT_RUN_V2), env_int_once("AT_STFT_NX", 0),
-                  env_int_once("AT_STFT_STAGGERV2", 0)};
-  };
-  static const int tune_each_call = env_int_once("AT_STFT_TUNE", 0);
-  static Tuning tuning = read_tuning();
-  if (tune_each_call) tuning = read_tuning();
+  const V2Tuning tuning = v2_tuning();
   // default cache policy: `nt` stores of the spectrum when the mel stage runs (3-4 % faster on both
   // boxes measured), plain stores otherwise (nt: +6 % on one box, -2 % on the other)
   A.flags = tuning.flags >= 0 ? tuning.flags : (mel ? 1 : 0);
@@ -1264,12 +1316,20 @@ int at_stft_mel_floor_f32(const float* x, int64_t rows, int64_t T, const float* 
   A.T2 = T; A.pad_mode = pad_mode; A.n_units = mel ? n_units : 0; A.n_mels = n_mels;
   A.groups_per_row = (int)n_frames_out;
   A.total_groups = rows * A.groups_per_row;
+  const V2Tuning tuning = v2_tuning();
   A.flags = mel ? 1 : 0;
-  A.run_max = AT_STFT_RUN_V2;
+#if AT_DEV_KNOBS
+  if (tuning.flags >= 0) A.flags = tuning.flags;
+#endif
+  A.run_max = tuning.run_max < 1 ? 1 : tuning.run_max;
   int auto_x = device_cu_count() / 32;
-  A.n_xcd = auto_x < 1 ? 1 : (auto_x > 8 ? 8 : auto_x);
+  auto_x = auto_x < 1 ? 1 : (auto_x > 8 ? 8 : auto_x);
+  A.n_xcd = tuning.n_xcd >= 1 ? tuning.n_xcd : auto_x;
   A.stagger = 0; A.debug = 0; A.reuse_shift = 4; A.run = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#if AT_DEV_KNOBS
+  if (mel && tuning.flags >= 0 && !(tuning.flags & 1)) return launch_v2<4, 0, 3>(A, device_cu_count(), s);   // twin with plain spectrum stores
+#endif
   return mel ? launch_v2<4, 1, 3>(A, device_cu_count(), s) : launch_v2<0, 0, 2>(A, device_cu_count(), s);
 }
 

@@ -159,12 +159,10 @@ def broadcast_cfg5_tables(old_sr, new_sr, n_fft, n_mels, device, window_type="ha
     if old != new:
         # the bank of whichever kernel kernels.resample() dispatches to (odd reduced source rate:
         # the matrix-core forms -- fp16-split for 64..256 output phases --; otherwise the VALU form)
-        if (old & 1) and 64 <= new <= 256:
-            items.append((("resample_f16", old, new), f16_bank))
-        elif old & 1:
-            items.append((("resample_mfma", old, new), mfma_bank))
-        else:
-            items.append((("resample_grouped", old, new), bank))
+        from . import kernels
+        form = kernels.resample_first_form(old, new)           # the same predicate the dispatcher uses
+        items.append({"f16": (("resample_f16", old, new), f16_bank), "mfma": (("resample_mfma", old, new), mfma_bank),
+                      "grouped": (("resample_grouped", old, new), bank)}[form])
     broadcast_tables(items + _stft_mel_items(int(new_sr), n_fft, window_type, n_mels, fmin, fmax), device)
 
 

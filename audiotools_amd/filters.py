@@ -216,7 +216,8 @@ class DSPMixin:
         if preprocess:
             window_length, hop_length = self._preprocess_signal_for_windowing(window_duration, hop_duration)
         rows = self.audio_data.reshape(-1, self.signal_length)
-        if kernels.is_native(rows) and rows.numel() < (1 << 31):
+        if kernels.is_native(rows) and rows.numel() < (1 << 31) and window_length <= self.signal_length:
+            # (a window longer than the signal goes on to unfold, which raises as the reference does)
             self.audio_data = kernels.collect_windows(rows, window_length, hop_length)
             return self
         frames = rows.unfold(-1, window_length, hop_length)  # (rows, n, L)
@@ -229,7 +230,11 @@ class DSPMixin:
         window_length = self.signal_length
         nb, nch = self._original_batch_size, self._original_num_channels
         a = self.audio_data
-        if (kernels.is_native(a) and a.shape[0] % (nb * nch) == 0 and hop_length > 0
+        # the gather takes exactly what fold accepts (single-channel windows, the window count of the padded length);
+        # every other shape goes on to the fold formulation, which raises as the reference does
+        if (kernels.is_native(a) and a.shape[1] == 1 and a.shape[0] % (nb * nch) == 0 and hop_length > 0
+                and window_length <= self._padded_signal_length
+                and a.shape[0] // (nb * nch) == (self._padded_signal_length - window_length) // hop_length + 1
                 and 2 * hop_length <= self._padded_signal_length):
             # one gather instead of fold + fold(ones) + division + trim; trim(hop, hop) as the reference's last step
             y = kernels.overlap_add(a, nb * nch, hop_length, self._padded_signal_length, hop_length)

@@ -15,6 +15,14 @@ import torch
 
 from . import _native, tables
 
+# Development A/B switches exist only when the process opted in with AT_DEV_KNOBS=1 (the tools under tools/ do, together
+# with a -DAT_DEV_KNOBS=1 build of the library): the shipped path never changes with the caller's environment.
+_DEV_KNOBS = os.environ.get("AT_DEV_KNOBS") == "1"
+
+
+def _knob(name, default):
+    return os.environ.get(name, default) if _DEV_KNOBS else default
+
 PAD_MODES = {"reflect": 0, "constant": 1, "replicate": 2, "circular": 3}
 
 
@@ -168,7 +176,7 @@ def istft_fused_supported(n_fft: int, hop: int) -> bool:
 def istft_tiled_supported(n_fft: int, hop: int) -> bool:
     """True when at_istft_f32 takes the tiled single-pass path of the 96 / 192 kHz default sizes (n_fft 4096 / 8192 with
     hop = n_fft / 4; csrc/stft_generic.hip); like the fused path it takes virtual lead / trail frames without a copy."""
-    return n_fft in (4096, 8192) and hop * 4 == n_fft and os.environ.get("AT_ISTFT_TILED_OFF", "0") in ("", "0")
+    return n_fft in (4096, 8192) and hop * 4 == n_fft and _knob("AT_ISTFT_TILED_OFF", "0") in ("", "0")
 
 
 def istft_edit_supported(n_fft: int, hop: int) -> bool:
@@ -506,7 +514,7 @@ def fir_per_item(audio: torch.Tensor, taps: torch.Tensor, highpass: bool = False
         out = torch.empty_like(audio)
     assert out.shape == audio.shape and out.is_contiguous() and out.dtype == torch.float32 and out.device == audio.device
     if method == "auto":
-        method = os.environ.get("AT_FIR_METHOD")             # development A/B: direct | fft | long
+        method = _knob("AT_FIR_METHOD", None)               # development A/B (dev builds only): direct | fft | long
         if not method:
             method = "fft" if L >= FIR_FFT_MIN_TAPS else "direct"
             if L >= FIR_LONG_MIN_TAPS and _LONGCONV and _fir_long_length(T + L - 1) is not None:
@@ -854,8 +862,19 @@ def resample_supported(old_sr: int, new_sr: int, zeros: int = 24, rolloff: float
     return need <= RESAMPLE_LDS_LIMIT
 
 
-_RESAMPLE_MFMA = os.environ.get("AT_RESAMPLE_MFMA", "1") != "0"     # development A/B switch, read once
-_RESAMPLE_F16 = os.environ.get("AT_RESAMPLE_F16", "1") != "0"       # the fp16-split matrix-core form (round 4)
+_RESAMPLE_MFMA = _knob("AT_RESAMPLE_MFMA", "1") != "0"     # development A/B switch, read once
+_RESAMPLE_F16 = _knob("AT_RESAMPLE_F16", "1") != "0"       # the fp16-split matrix-core form (round 4)
+
+
+def resample_first_form(old: int, new: int) -> str:
+    """Which kernel family ``resample`` tries FIRST for the reduced ratio old -> new ("f16", "mfma" or "grouped"): the one
+    predicate the dispatcher below and the table broadcast of dist.broadcast_cfg5_tables share."""
+    lib = _native.lib()
+    if _RESAMPLE_F16 and lib.at_resample_f16s_supported(old, new):
+        return "f16"
+    if _RESAMPLE_MFMA and lib.at_resample_mfma_supported(old, new):
+        return "mfma"
+    return "grouped"
 
 
 def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
@@ -870,7 +889,8 @@ def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
     out_len = int(math.floor(new * T / old))
     out = torch.empty((B, C, out_len), dtype=torch.float32, device=dev)
     lib = _native.lib()
-    if _RESAMPLE_F16 and T >= 16 and lib.at_resample_f16s_supported(old, new):
+    form = resample_first_form(old, new)
+    if form == "f16" and T >= 16:
         W_np, lo_np, old, new, width, NPB, NC, wk = tables.resample_f16_bank(old, new)
         W, lo = tables.device_table(("resample_f16", old, new), dev, lambda: (W_np.view(np.int32), lo_np))
         code = lib.at_resample_f16s_f32(_native.ptr(audio), B * C, T, _native.ptr(W), _native.ptr(lo), old, new, width,
@@ -878,7 +898,7 @@ def resample(audio: torch.Tensor, old_sr: int, new_sr: int):
         if code != -2:            # AT_ERR_UNSUPPORTED (a tile that does not fit): the f32 kernels below
             _native.check(code, "at_resample_f16s_f32")
             return out
-    if _RESAMPLE_MFMA and lib.at_resample_mfma_supported(old, new):
+    if form != "grouped" and _RESAMPLE_MFMA and lib.at_resample_mfma_supported(old, new):
         W_np, lo_np, old, new, width, NPB, NC = tables.resample_mfma_bank(old, new)
         need = (32 * old + int(lo_np.max()) + 32 * NC + 32 + 4) * 4       # one 32-frame tile of LDS
         if need <= RESAMPLE_LDS_LIMIT:
@@ -934,7 +954,7 @@ def resample_adjoint_supported(old_sr: int, new_sr: int) -> bool:
     return (4 * new + 2 * (J * new - 1) + LG + 8) * 4 <= RESAMPLE_LDS_LIMIT
 
 
-_LONGCONV = os.environ.get("AT_LONGCONV", "1") != "0"       # development A/B switch, read once
+_LONGCONV = _knob("AT_LONGCONV", "1") != "0"       # development A/B switch, read once
 
 
 def longconv_supported(T: int) -> bool:

@@ -114,10 +114,11 @@ class Meter(torch.nn.Module):
             # HIP path: (nb, nt, nch) -> contiguous (nb, nch, nt) rows for the kernel
             return kernels.integrated_loudness(x.detach().permute(0, 2, 1).contiguous(), self.rate,
                                                self.filter_class, self.block_size)
-        if self.use_fir and kernels.is_native(x.detach()) and x.shape[-1] <= 5:
+        if self.use_fir and kernels.is_native(x) and x.shape[-1] <= 5:
+            # (a tensor that needs grad keeps the differentiable conv1d formulation below, as the reference's FIR branch is)
             # the reference's FIR approximation (loudness.py:69-100) on the block-FFT FIR kernel + native gating
             firs = self._fir_bank("cpu")[:, 0].flip(-1).double().numpy()        # impulse responses, un-reversed
-            return kernels.integrated_loudness_fir(x.detach().permute(0, 2, 1).contiguous(), self.rate, firs,
+            return kernels.integrated_loudness_fir(x.permute(0, 2, 1).contiguous(), self.rate, firs,
                                                    [float(g) for g in self._gains], self.block_size)
 
         nb, nt, nch = x.shape

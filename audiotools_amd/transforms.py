@@ -35,11 +35,16 @@ from .signal import AudioSignal
 tt = torch.tensor
 
 
-def _flatten(d, prefix=()):
+def _flatten(d, prefix=(), keep_empty=False):
+    """Tuple-keyed flat view of a nested dict.  Empty sub-dicts are DROPPED (flatten_dict's default ``keep_empty_types=()``,
+    which is what the reference's prepare_batch round trip relies on) unless ``keep_empty``."""
     out = {}
     for k, v in d.items():
-        if isinstance(v, dict) and v:
-            out.update(_flatten(v, prefix + (k,)))
+        if isinstance(v, dict):
+            if v:
+                out.update(_flatten(v, prefix + (k,), keep_empty))
+            elif keep_empty:
+                out[prefix + (k,)] = v
         else:
             out[prefix + (k,)] = v
     return out

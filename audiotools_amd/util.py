@@ -305,13 +305,14 @@ class chdir:
 _JOINERS = {"tuple": None, "dot": ".", "underscore": "_", "path": "/"}
 
 
-def flatten(d: dict, reducer="tuple") -> dict:
+def flatten(d: dict, reducer="tuple", keep_empty_types=()) -> dict:
     """Nested dictionary -> flat dictionary (the ``flatten_dict`` package the reference's util imports): keys are tuples
     of the path (``reducer="tuple"``, the default the reference uses) or the path joined with "." / "_" / "/"
-    (``"dot"``, ``"underscore"``, ``"path"``) or passed through a callable ``reducer(parent_key, key)``; empty
-    dictionaries are kept as leaves."""
+    (``"dot"``, ``"underscore"``, ``"path"``) or passed through a callable ``reducer(parent_key, key)``.  Empty
+    dictionaries are dropped, as flatten_dict does by default; ``keep_empty_types=(dict,)`` keeps them as leaves.
+    With the string reducers, keys are joined through ``str``: non-string keys do not round-trip (5 comes back as "5")."""
     from .transforms import _flatten
-    flat = _flatten(d)
+    flat = _flatten(d, keep_empty=dict in tuple(keep_empty_types))
     if callable(reducer):
         out = {}
         for ks, v in flat.items():

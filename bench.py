@@ -138,6 +138,17 @@ def cpu_baseline_cfg(config, kw_cpu, n_items):
             "host_cpus": ncpu, "sample": f"{n_items} items of {config}, median of 3 passes ({med:.2f} s), oracle/restate.py"}
 
 
+def lib_sha256():
+    """sha256 of the library this process loaded: the bench line and every profiles/*_pmc_summary.json carry it, so that a
+    replayed counter value can be tied to the binary it was measured on."""
+    import hashlib
+    from audiotools_amd import _native
+    try:
+        return hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 def committed_traffic(config, n_local, kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS
     configuration and shape (profiles/r0N_<tag>_pmc_summary.json; FETCH_SIZE and WRITE_SIZE in separate passes,
@@ -148,13 +159,18 @@ def committed_traffic(config, n_local, kernel_substr):
     want_items = CONFIGS[config]["batch"]
     if n_local != want_items:
         return None, None, None
-    for rnd in ("r04", "r03", "r02"):
+    sha = lib_sha256()
+    for rnd in ("r05", "r04", "r03", "r02"):
         name = f"{rnd}_{tag}_pmc_summary.json"
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
         try:
             d = json.load(open(path))
+            if d.get("lib_sha256") != sha:
+                # counters of ANOTHER binary say nothing about this one: traffic stays null (the newest summary decides)
+                return None, (f"profiles/{name} was recorded on library sha256 {str(d.get('lib_sha256'))[:16]}, this run loaded "
+                              f"{str(sha)[:16]}: not replayed"), None
             per_kernel = {}
             for k, v in d["pmc_fetch"].items():
                 w = d["pmc_write"].get(k, {}).get("WRITE_SIZE")
@@ -402,7 +418,7 @@ def main():
         parity = parity_north_star(x, sr, mel, sig.stft_data, lufs)
         # the zero-compute floor of the dominant kernel's traffic on THIS box: its measurement twin (same grid, schedule,
         # addresses, load / store instructions and cache policy, no transform: at_stft_mel_floor_f32), timed the same way
-        floor_ms = floor_iso_ms = None
+        floor_ms = floor_iso_ms = floor_same_ms = None
         try:
             from audiotools_amd import kernels as K, tables as TB
             win = TB.window("hann", n_fft, device)
@@ -432,6 +448,20 @@ def main():
                     torch.cuda.synchronize()
                     iso.append(ie[0].elapsed_time(ie[1]))
                 floor_iso_ms = sum(iso) / len(iso)
+                # ... and on the buffers the KERNEL of the last timed step wrote (parity has been checked above; the twin leaves
+                # garbage in them): the twin's time is a property of where the 7.2 GB spectrum buffer lies physically
+                # (profiles/r05_notes.md section 1: 1.6-1.7 ms on some allocations, 2.0-2.1 ms on others, deterministic per
+                # allocation), so only this figure says which regime the kernel of record ran in
+                own_stft, own_mel = sig.stft_data, mel
+                for _ in range(2):
+                    K.stft_mel_floor(x, win, n_fft, hop, own_stft, (units[0], units[1], N_MELS), own_mel)
+                oe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                oe[0].record()
+                for _ in range(args.steps):
+                    K.stft_mel_floor(x, win, n_fft, hop, own_stft, (units[0], units[1], N_MELS), own_mel)
+                oe[1].record()
+                torch.cuda.synchronize()
+                floor_same_ms = oe[0].elapsed_time(oe[1]) / args.steps
             del fl_stft, fl_mel
         except Exception as e:  # pragma: no cover - the floor is evidence, never a reason to lose the line
             floor_ms = floor_iso_ms = None
@@ -457,14 +487,18 @@ def main():
                            "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": stft_bytes, "avg_launch_ms": stft_ms,
                            "device_copy_GBps": copy_gbs, "frac_of_device_copy": achieved / copy_gbs,
-                           "floor_ms": floor_ms, "floor_ms_one_at_a_time": floor_iso_ms,
+                           "floor_ms": floor_ms, "floor_ms_one_at_a_time": floor_iso_ms, "floor_ms_same_buffers": floor_same_ms,
+                           "frac_of_floor_same_buffers": (floor_same_ms / stft_ms) if floor_same_ms else None,
                            "frac_of_floor": (min(floor_ms, floor_iso_ms) / stft_ms) if floor_ms else None,
                            "floor_frac_of_peak": (stft_bytes / (min(floor_ms, floor_iso_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS)
                            if floor_ms else None,
                            "floor_note": "floor_ms = the same launch with the transform removed (stft_mel_kernel_v2<.., FLOOR>: "
                                          "identical grid, runs, addresses, load/store instructions, nt policy), HIP events: K launches back to "
-                                         "back (floor_ms) and one at a time on an idle device (floor_ms_one_at_a_time); frac_of_floor "
-                                         "uses the smaller: what this read:write mix costs on this box with zero compute"}
+                                         "back (floor_ms) and one at a time on an idle device (floor_ms_one_at_a_time), both into FRESH buffers; frac_of_floor "
+                                         "uses the smaller.  floor_ms_same_buffers = the twin on the output buffers of the last timed step: "
+                                         "the twin's time depends on where the spectrum buffer lies physically (1.6-1.7 or 2.0-2.1 ms, "
+                                         "deterministic per allocation, profiles/r05_notes.md section 1), so this is the figure that says "
+                                         "which regime the kernel of record ran in"}
         out["parity_check"] = parity
         out["kernels_ms"] = {"stft_mel": stft_ms, "lufs_total": lufs_ms, "lufs_GBps": lufs_bytes / (lufs_ms * 1e-3) / 1e9,
                              "timing": timing_note}
@@ -573,11 +607,12 @@ def main():
                                      f"[STFT 2048/512 as the signal keeps its stft_params]", "global_batch": batch,
                          "items_per_gpu": n_local, "parallelism": f"batch-shard x{world} + RCCL broadcast of the resample bank / tables",
                          "inputs": "device-resident (H2D excluded)"}
-        if os.environ.get("AT_RESAMPLE_F16", "1") != "0" and _native.lib().at_resample_f16s_supported(441, 160):
-            rp = os.environ.get("AT_RESAMPLE_F16_RP", "1") != "0"        # the shipped register-prefetch form; 0 = the LDS-DMA form
-            rs_sub = "resample_f16s_rp_kernel" if rp else "resample_f16s_kernel"
+        from audiotools_amd import kernels as K5
+        form = K5.resample_first_form(441, 160)            # the dispatcher's own predicate
+        if form == "f16":
+            rs_sub = "resample_f16s_rp_kernel"
             rs_kernel = rs_sub + " (banded-GEMM polyphase 441->160, fp16-split products on v_mfma_f32_16x16x32_f16)"
-        elif _native.lib().at_resample_mfma_supported(441, 160) and os.environ.get("AT_RESAMPLE_MFMA", "1") != "0":
+        elif form == "mfma":
             rs_kernel, rs_sub = "resample_mfma_ws_kernel (banded-GEMM polyphase 441->160 on v_mfma_f32_16x16x4_f32)", "resample_mfma_ws_kernel"
         else:
             rs_kernel, rs_sub = "resample_kernel (sparse polyphase 441->160)", "resample_kernel"
@@ -595,6 +630,7 @@ def main():
         out["backend"] = torch.distributed.get_backend() if world > 1 else None
         out["per_rank_ms_per_step"] = [1e3 * t / args.steps for t in PER_RANK_S]
         out["host"] = socket.gethostname()
+        out["lib_sha256"] = lib_sha256()
         if world == 1 and not args.no_cpu_baseline:
             if args.config == "north_star":
                 out["cpu_baseline"] = cpu_baseline_north_star(args.cpu_items or 64, args.cpu_iters)

@@ -4,6 +4,7 @@
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden            # the round-1 fixtures
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden --round3   # edits_r03.npz, ir_mix_loader_r03.npz only
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden --round4   # transforms_r04.npz only
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden --round5   # transforms_r05.npz only
 
 Inputs are stored next to the outputs (float16-exact values are not assumed), so the
 fixtures do not depend on torch's RNG staying stable.  Every array is produced by calling
@@ -200,8 +201,36 @@ def round4():
     print("transforms_r04.npz", os.path.getsize(os.path.join(OUT, "transforms_r04.npz")) // 1024, "KiB")
 
 
+R5_TRANSFORMS = ["MaskLowMagnitudes", "SpectralDenoising"]
+
+
+def round5():
+    """Fixture added in round 5: the two transforms that compare a float32 logarithm with a dB
+    threshold, applied by the UNMODIFIED reference to EVERY item (prob = 1; with round 4's prob = 0.5 and states 3..6 the
+    SpectralDenoising row happened to transform no item at all).  tests/test_golden_r05.py replays the states through the
+    package and demands 1e-4 everywhere except in samples reached by a bin that lies within 1e-3 dB of its threshold."""
+    at = import_reference()
+    AudioSignal = at.AudioSignal
+    T = at.data.transforms
+    sr = 44100
+    x = synth.audio_batch(len(R4_STATES), 1, 9000, seed=501, gaps=False, sample_rate=sr)
+    out = {"x": x.numpy(), "states": np.asarray(R4_STATES), "sample_rate": np.asarray(sr)}
+    for name in R5_TRANSFORMS:
+        t = getattr(T, name)(prob=1.0)
+        sig = AudioSignal(x.clone(), sr)
+        kw = t.batch_instantiate(R4_STATES, sig)
+        assert bool(kw[name]["mask"].all())
+        torch.manual_seed(7)
+        y = t(sig.clone(), **kw)
+        out[name] = y.audio_data.numpy()
+    np.savez_compressed(os.path.join(OUT, "transforms_r05.npz"), **out)
+    print("transforms_r05.npz", os.path.getsize(os.path.join(OUT, "transforms_r05.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    if "--round4" in sys.argv:
+    if "--round5" in sys.argv:
+        round5()
+    elif "--round4" in sys.argv:
         round4()
     elif "--round3" in sys.argv:
         round3()

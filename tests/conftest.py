@@ -7,8 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
-# the fp16-split resampler re-reads AT_RESAMPLE_F16_RP per call under this switch: the tests run its two forms side by side
-os.environ.setdefault("AT_RESAMPLE_F16_TUNE", "1")
+# (no AT_* switches here: the suite runs the shipped library exactly as production does; the A/B switches exist only in
+#  the development build, AT_DEV_KNOBS=1, which the tools under tools/ load)
 
 
 def pytest_configure(config):

@@ -203,10 +203,14 @@ def test_flatten_unflatten_names():
     """util.flatten / unflatten (the reference re-exports the flatten_dict package's functions; transforms.py:130-131 and
     util.py:365-371, 463 use the tuple-keyed default) and the names transforms carries."""
     d = {"a": {"b": 1, "c": {"d": 2}}, "e": 3, "f": {}}
+    # empty sub-dicts are dropped, as flatten_dict's default keep_empty_types=() does (ADVICE r04); kept on request
     flat = A.util.flatten(d)
-    assert flat == {("a", "b"): 1, ("a", "c", "d"): 2, ("e",): 3, ("f",): {}} and A.util.unflatten(flat) == d
+    assert flat == {("a", "b"): 1, ("a", "c", "d"): 2, ("e",): 3}
+    assert A.util.unflatten(flat) == {"a": {"b": 1, "c": {"d": 2}}, "e": 3}
+    kept = A.util.flatten(d, keep_empty_types=(dict,))
+    assert kept == {("a", "b"): 1, ("a", "c", "d"): 2, ("e",): 3, ("f",): {}} and A.util.unflatten(kept) == d
     for name, sep in (("dot", "."), ("underscore", "_"), ("path", "/")):
         f = A.util.flatten({"a": {"b": 1}, "e": 3}, name)
         assert f == {"a" + sep + "b": 1, "e": 3} and A.util.unflatten(f, name) == {"a": {"b": 1}, "e": 3}
-    assert A.transforms.flatten(d) == flat and A.transforms.unflatten(flat) == d
+    assert A.transforms.flatten(d) == flat and A.transforms.unflatten(kept) == d
     assert A.transforms.AudioLoader is A.data.datasets.AudioLoader

@@ -1370,17 +1370,12 @@ def test_resample_f16_split_kernel_raw_abi(old, new, T, off):
     ref64 = restate.resample(x.double(), old, new)
     W, lo, o_, n_, width, NPB, NC, wk = tables.resample_f16_bank(old, new)
     Wd, lod = torch.from_numpy(W.view(np.int32)).cuda(), torch.from_numpy(lo).cuda()
-    forms = {}
-    for rp in ("1", "0"):         # register-prefetch form (default) and LDS-DMA form: the same numbers bit for bit
-        os.environ["AT_RESAMPLE_F16_RP"] = rp
-        y = torch.full((3, 2, out_len), float("nan"), device="cuda")
-        rc = lib.at_resample_f16s_f32(_native.ptr(xd), 6, T, _native.ptr(Wd), _native.ptr(lod), old, new, width, NPB, NC,
-                                      int(lo.max()), wk, _native.ptr(y), out_len, st)
-        assert rc == 0 and torch.isfinite(y).all() and rel_err(y, ref) < REL, rp
-        forms[rp] = y
-    os.environ.pop("AT_RESAMPLE_F16_RP")
-    y1 = forms["1"]
-    assert torch.equal(forms["1"], forms["0"])
+    # (the shipped form is the register-prefetch kernel; the LDS-DMA form it was checked against bit for bit in round 4
+    #  lives on in the development build only, tools/rsbench.py)
+    y1 = torch.full((3, 2, out_len), float("nan"), device="cuda")
+    rc = lib.at_resample_f16s_f32(_native.ptr(xd), 6, T, _native.ptr(Wd), _native.ptr(lod), old, new, width, NPB, NC,
+                                  int(lo.max()), wk, _native.ptr(y1), out_len, st)
+    assert rc == 0 and torch.isfinite(y1).all() and rel_err(y1, ref) < REL
     W2, lo2, o_, n_, width, NPB2, NC2 = tables.resample_mfma_bank(old, new)
     W2d, lo2d = torch.from_numpy(W2).cuda(), torch.from_numpy(lo2).cuda()
     y2 = torch.full((3, 2, out_len), float("nan"), device="cuda")

@@ -373,9 +373,15 @@ def test_build_flags_per_source(monkeypatch):
     for s in ("fir.hip", "irtools.hip", "specedit.hip", "fftconv.hip", "vocoder.hip"):
         assert "-fno-slp-vectorize" not in flags[s]
     assert all("--offload-arch=gfx950" in f and "-O3" in f for f in flags.values())
+    # the A/B switches of the build exist in the development build only: the shipped one ignores the environment
     monkeypatch.setenv("AT_MAXILP_FILES", "longconv.hip")
-    assert ilp in _native.compile_command("/x/longconv.hip", "/x/o.o") and ilp not in _native.compile_command("/x/fir.hip", "/x/o.o")
-    assert _native.compile_command("/x/istft.hip", "/x/o.o").count(ilp) == 1
+    monkeypatch.setenv("AT_HIPCC_FLAGS", "-DAT_ROW_THREADS=128")
+    ship = _native.compile_command("/x/longconv.hip", "/x/o.o")
+    assert ilp not in ship and "-DAT_ROW_THREADS=128" not in ship and "-DAT_DEV_KNOBS=1" not in ship
+    dev = _native.compile_command("/x/longconv.hip", "/x/o.o", dev=True)
+    assert ilp in dev and "-DAT_ROW_THREADS=128" in dev and "-DAT_DEV_KNOBS=1" in dev
+    assert ilp not in _native.compile_command("/x/fir.hip", "/x/o.o", dev=True)
+    assert _native.compile_command("/x/istft.hip", "/x/o.o", dev=True).count(ilp) == 1
 
 
 def test_fp16_split_resampler_model_matches_the_oracle():

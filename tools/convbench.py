@@ -3,6 +3,8 @@
 usage: python tools/convbench.py [--batch 1024] [--T 240000] [--iters 10]"""
 import argparse
 import os
+
+os.environ.setdefault("AT_DEV_KNOBS", "1")      # A/B tool: the development build of the library (lib/libaudiotools_amd_dev.so) and its AT_* switches
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -3,6 +3,8 @@
 side through ctypes.  usage: python tools/lufsab.py libA.so libB.so [batch]"""
 import ctypes
 import os
+
+os.environ.setdefault("AT_DEV_KNOBS", "1")      # A/B tool: the development build of the library (lib/libaudiotools_amd_dev.so) and its AT_* switches
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -7,6 +7,8 @@ Round-robin timing (box drift hits both alike); the LUFS outputs of the two kern
 usage: python tools/lufskab.py [batch] [sr]
 """
 import os
+
+os.environ.setdefault("AT_DEV_KNOBS", "1")      # A/B tool: the development build of the library (lib/libaudiotools_amd_dev.so) and its AT_* switches
 import sys
 
 os.environ["AT_LUFS_TUNE"] = "1"

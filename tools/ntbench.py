@@ -2,6 +2,8 @@
 """Per-kernel timings of one library build (AT_LIB_PATH) -- used to A/B cache-policy builds of the
 streaming kernels: LUFS, inverse STFT, overlap-save FIR, resampler.  usage: python tools/ntbench.py [tag]"""
 import os
+
+os.environ.setdefault("AT_DEV_KNOBS", "1")      # A/B tool: the development build of the library (lib/libaudiotools_amd_dev.so) and its AT_* switches
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

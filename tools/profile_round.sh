@@ -25,7 +25,10 @@ try:
     uid = [l.split(":")[-1].strip() for l in subprocess.run(["rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=30).stdout.splitlines() if "Unique ID" in l and "GPU[" in l][0]
 except Exception:
     uid = "unknown"
-out = {"box": "MI355X unique id " + uid, "stats_command": "bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-share", "command": "bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share (one rocprofv3 pass per counter group)"}
+import hashlib
+R = os.environ.get("GRAFT_REPO_ROOT", ".")
+lib = os.environ.get("AT_LIB_PATH") or os.path.join(R, "audiotools_amd", "lib", "libaudiotools_amd.so")
+out = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "box": "MI355X unique id " + uid, "stats_command": "bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-share", "command": "bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share (one rocprofv3 pass per counter group)"}
 st = glob.glob(O + "/stats/**/*kernel_stats.csv", recursive=True)
 if st:
     rows = list(csv.DictReader(open(st[0])))

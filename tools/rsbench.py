@@ -6,6 +6,8 @@ usage: python tools/rsbench.py [--batch 256] [--seconds 30] [--iters 20] [--roun
 import argparse
 import math
 import os
+
+os.environ.setdefault("AT_DEV_KNOBS", "1")      # A/B tool: the development build of the library (lib/libaudiotools_amd_dev.so) and its AT_* switches
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,5 @@
 #!/bin/bash
+export AT_DEV_KNOBS=1   # A/B script: development build of the library
 # A/B of the STFT kernels on one box: {scalar, SLP-packed} build x {generic, v2} kernel.
 # usage: tools/stftab.sh [batch]   (run on the GPU box; prints kbench lines)
 B=${1:-512}

@@ -15,6 +15,8 @@ usage: python tools/stftsweep.py [--batch 512] [--mel 1] --cfg 16:0:0,431:16:0,.
 """
 import argparse
 import os
+
+os.environ.setdefault("AT_DEV_KNOBS", "1")      # A/B tool: the development build of the library (lib/libaudiotools_amd_dev.so) and its AT_* switches
 import sys
 
 os.environ["AT_STFT_TUNE"] = "1"
