@@ -252,6 +252,82 @@ def stft_adjoint(grad_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop:
     return g
 
 
+def _fold_pad(out: torch.Tensor, T: int, left: int, right: int, mode: str) -> torch.Tensor:
+    """Gradient w.r.t. a signal padded by (left, right) samples in ``mode`` (torch.nn.functional.pad names: the outer padding
+    of match_stride, audio_signal.py:1192-1196) -> gradient w.r.t. the signal."""
+    g = out[..., left: left + T].clone()
+    if (left == 0 and right == 0) or mode == "constant":
+        return g
+    lo, hi = out[..., :left], out[..., left + T:]
+    if mode == "reflect":           # padded position left - 1 - j mirrors x[1 + j]; position left + T + j mirrors x[T - 2 - j]
+        if left:
+            g[..., 1: left + 1] += lo.flip(-1)
+        if right:
+            g[..., T - 1 - right: T - 1] += hi.flip(-1)
+    elif mode == "replicate":
+        if left:
+            g[..., 0] += lo.sum(-1)
+        if right:
+            g[..., T - 1] += hi.sum(-1)
+    elif mode == "circular":
+        if left:
+            g[..., T - left:] += lo
+        if right:
+            g[..., :right] += hi
+    else:
+        raise NotImplementedError(f"Unrecognised padding mode {mode}")
+    return g
+
+
+def stft_adjoint_general_supported(window: torch.Tensor, n_fft: int, hop: int) -> bool:
+    """Every transform size some forward kernel covers has a native adjoint as long as the inverse kernels take the
+    (window, hop) pair (torch.istft's NOLA condition)."""
+    return stft_native_supported(n_fft) and 0 < hop <= n_fft and _nola_ok_cached(window, n_fft, hop)
+
+
+def stft_adjoint_general(grad_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, T: int, pad: int = 0,
+                         right_pad: int = 0, padding_type: str = "reflect", match_stride: bool = False,
+                         _istft=None) -> torch.Tensor:
+    """Backward pass of ``stft_mel(audio (B, C, T), ..., pad, right_pad, padding_type, match_stride)`` for EVERY native
+    transform size: the run-time sizes (4096 / 8192, 400 / 1200 / 1920 ...) and ``match_stride`` (two frames dropped per
+    side, outer padding) included.  The adjoint of one frame's one-sided DFT is N irfft(Y) with Y = G / 2 on the interior
+    bins and Re G at DC / Nyquist, the adjoint of framing is window + overlap-add: N x envelope x istft(Y), i.e. the inverse
+    kernels with their envelope division undone.  The fused sizes take the dedicated adjoint kernel (at_stft_adjoint_f32:
+    no envelope round trip); dropped edge frames are zero frames, the centre reflection and the outer padding are folded
+    back onto the samples they copied."""
+    B, C, F, n_out = grad_bcfn.shape
+    frame_lo, n_expect = stft_frames(T, n_fft, hop, pad, right_pad, match_stride)
+    assert F == n_fft // 2 + 1 and n_out == n_expect, (grad_bcfn.shape, n_expect)
+    T2 = T + 2 * pad + right_pad
+    n_total = 1 + T2 // hop
+    drop_hi = n_total - frame_lo - n_out
+    half = n_fft // 2
+    if _istft is None and istft_fused_supported(n_fft, hop):
+        G = grad_bcfn if not (frame_lo or drop_hi) else torch.nn.functional.pad(grad_bcfn, (frame_lo, drop_hi))
+        g2 = stft_adjoint(G, window, n_fft, hop, T2)
+    else:
+        istft_fn = istft if _istft is None else _istft
+        Y = grad_bcfn * 0.5
+        Y[:, :, 0, :] = grad_bcfn[:, :, 0, :].real.to(Y.dtype)
+        Y[:, :, half, :] = grad_bcfn[:, :, half, :].real.to(Y.dtype)
+        # K zero frames in front move padded position 0 to output index K hop - half >= 0 of the centre-trimmed inverse;
+        # K behind keep the envelope of the last real frames what it is inside the range that is read
+        K = -(-half // hop)
+        lead, trail = K + frame_lo, drop_hi + K
+        n_all = lead + n_out + trail
+        full = T2 + n_fft                         # the centre-padded, outer-padded signal
+        length = full + K * hop - half
+        x = istft_fn(Y, window, n_fft, hop, length, lead=lead, trail=trail)
+        w2 = (window.to(x.dtype) ** 2)[None, None]
+        env = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, n_all, dtype=x.dtype, device=x.device), w2, stride=hop)[0, 0]
+        env = env[half: half + length]
+        if env.numel() < length:
+            env = torch.nn.functional.pad(env, (0, length - env.numel()))
+        x = torch.where(env > 1e-11, x * (env * float(n_fft)), torch.zeros_like(x))
+        g2 = _fold_reflect(x[..., K * hop - half:], T2, half)
+    return _fold_pad(g2, T, pad, pad + right_pad, padding_type)
+
+
 def stft_mel_adjoint_supported(n_fft: int, hop: int, n_mels: int) -> bool:
     return 64 <= n_fft <= 2048 and hop * 4 == n_fft and n_mels <= 8 * (n_fft // 32)
 

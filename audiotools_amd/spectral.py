@@ -48,6 +48,29 @@ class _NativeStft(torch.autograd.Function):
         return kernels.stft_adjoint(grad, window, n_fft, hop, T), None, None, None
 
 
+class _NativeStftGeneral(torch.autograd.Function):
+    """stft() under autograd for every other native transform: the run-time sizes (n_fft 4096 / 8192, 400 / 1200 /
+    1920 ...: the window lengths metrics/spectral.py:9-247 accepts) and ``match_stride`` (outer padding of any
+    ``padding_type``, two frames dropped per side).  Forward = the kernel the no-grad path runs; backward =
+    ``kernels.stft_adjoint_general`` (inverse kernels with the envelope division undone, or the dedicated adjoint kernel
+    for the fused sizes, plus the folds of the two paddings)."""
+
+    @staticmethod
+    def forward(ctx, audio, window, n_fft, hop, pad, right_pad, padding_type, match_stride):
+        ctx.save_for_backward(window)
+        ctx.cfg = (n_fft, hop, audio.shape[-1], pad, right_pad, padding_type, match_stride)
+        X, _ = kernels.stft_mel(audio.detach(), window, n_fft, hop, pad=pad, right_pad=right_pad,
+                                padding_type=padding_type, match_stride=match_stride)
+        return X
+
+    @staticmethod
+    def backward(ctx, grad):
+        (window,) = ctx.saved_tensors
+        n_fft, hop, T, pad, right_pad, padding_type, match_stride = ctx.cfg
+        g = kernels.stft_adjoint_general(grad, window, n_fft, hop, T, pad, right_pad, padding_type, match_stride)
+        return (g,) + (None,) * 7
+
+
 class _NativeStftMel(torch.autograd.Function):
     """mel_spectrogram() under autograd: ONE fused forward kernel (STFT + |X| + banded mel), and a
     backward that maps dL/dmel to dL/dX with the dense basis (``g_mag = g_mel @ basis``,
@@ -105,6 +128,16 @@ def _native_autograd_ok(audio: torch.Tensor, n_fft: int, hop: int, match_stride:
     return (audio.is_cuda and audio.dtype == torch.float32 and audio.requires_grad and torch.is_grad_enabled()
             and not match_stride and kernels.stft_fused_supported(n_fft) and kernels.istft_fused_supported(n_fft, hop)
             and audio.shape[-1] > n_fft // 2)
+
+
+def _native_autograd_general_ok(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, pad: int, right_pad: int,
+                                padding_type: str) -> bool:
+    """The same for the transforms ``_native_autograd_ok`` leaves out (run-time sizes, match_stride)."""
+    T2 = audio.shape[-1] + 2 * pad + right_pad
+    return (audio.is_cuda and audio.dtype == torch.float32 and audio.requires_grad and torch.is_grad_enabled()
+            and padding_type in kernels.PAD_MODES and T2 > n_fft // 2 + 1
+            and (padding_type != "reflect" or pad + right_pad < audio.shape[-1])
+            and kernels.stft_adjoint_general_supported(window, n_fft, hop))
 
 
 class SpectralMixin:
@@ -170,6 +203,8 @@ class SpectralMixin:
                                     padding_type=padding_type, match_stride=match_stride)
         elif _native_autograd_ok(audio, n_fft, hop, match_stride):
             X = _NativeStft.apply(audio, window, n_fft, hop)
+        elif _native_autograd_general_ok(audio, window, n_fft, hop, pad, right_pad, padding_type):
+            X = _NativeStftGeneral.apply(audio, window, n_fft, hop, pad, right_pad, padding_type, bool(match_stride))
         else:
             X = self._torch_stft(n_fft, hop, window, match_stride, padding_type, right_pad, pad)
         self.stft_data = X

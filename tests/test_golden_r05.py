@@ -32,7 +32,8 @@ def _near_frames_lowmag(x, cutoff):
 def _near_frames_gate(x, nz, eq, sr, nz_volume):
     """The same for SpectralGate (ml/layers/spectral_gate.py:93-127): signal dB against the per-bin threshold of the
     equalised, normalised noise clip, float64; a gate bit reaches 5 frames either side through the tent smoothing."""
-    noise = A.AudioSignal(nz.audio_data.clone(), nz.sample_rate).normalize(nz_volume).equalizer(eq)
+    # (prepare_batch moved the noise clip to the device under test in place: the yardstick is computed on the host)
+    noise = A.AudioSignal(nz.audio_data.detach().cpu().clone(), nz.sample_rate).normalize(nz_volume).equalizer(torch.as_tensor(eq).cpu())
     Xn = restate.stft(noise.audio_data.double(), N_FFT, HOP, "sqrt_hann")
     ndb = 20.0 * Xn.abs().clamp_min(1e-4).log10()
     thresh = ndb.mean(-1, keepdim=True) + 3.0 * ndb.std(-1, keepdim=True)
@@ -76,7 +77,7 @@ def test_threshold_transforms_against_reference_golden(name, device):
     ref = torch.from_numpy(d[name])
     assert float((ref - x).abs().max()) > 1e-3, "the fixture must hold transformed items"
     if name == "MaskLowMagnitudes":
-        near, spread = _near_frames_lowmag(x, kw[name]["db_cutoff"])
+        near, spread = _near_frames_lowmag(x, torch.as_tensor(kw[name]["db_cutoff"]).cpu())
     else:
         near, spread = _near_frames_gate(x, kw[name]["nz"], kw[name]["eq"], sr, t.nz_volume)
     n_bad, n_near = _assert_localized(y, ref, near, spread, name)

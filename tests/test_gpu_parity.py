@@ -764,6 +764,67 @@ def test_stft_autograd_native_adjoint(win, hop, T):
         assert "libaudiotools_amd.so" in f.read()
 
 
+@pytest.mark.parametrize("win,hop,T,ms,ptype", [(4096, 1024, 30000, False, None), (8192, 2048, 50000, False, None), (400, 100, 9000, False, None),
+                                                 (1200, 300, 16001, False, None), (1920, 480, 20000, False, None),
+                                                 (2048, 512, 22050 + 7, True, None), (512, 128, 16000, True, "constant"),
+                                                 (400, 100, 9001, True, None), (4096, 1024, 30000, True, "replicate"),
+                                                 (1024, 256, 12000, True, "circular"), (400, 160, 9000, False, None)])
+def test_stft_autograd_general_adjoint(win, hop, T, ms, ptype):
+    """the run-time transform sizes (4096 / 8192, the speech windows) and match_stride keep the HIP
+    kernels under autograd -- forward = the no-grad kernel, backward = kernels.stft_adjoint_general (inverse kernels with the
+    envelope division undone / at_stft_adjoint_f32, edge frames as zero frames, both paddings folded back).  grad_fn is
+    asserted native; the gradient is held against float64 torch on the CPU at 1e-4 per row (metrics/spectral.py:9-247,
+    tests/core/test_grad.py:44-66)."""
+    x = synth.audio_batch(2, 2, T, seed=win + T, gaps=False)
+    kw = dict(window_length=win, hop_length=hop, window_type="hann", match_stride=ms)
+    if ptype:
+        kw["padding_type"] = ptype
+
+    def loss_and_grad(dev, dtype):
+        xa = x.clone().to(dev, dtype).requires_grad_(True)
+        s = A.AudioSignal(xa, 44100)
+        if dtype == torch.float64:
+            s.audio_data = xa                      # (the constructor casts float64 input to float32)
+        X = s.stft(**kw)
+        name = type(X.grad_fn).__name__
+        wts = torch.randn(X.shape, generator=torch.Generator().manual_seed(5)).to(dev, dtype)
+        loss = (X.abs() * wts).sum() + (X.abs().clamp(1e-5).log10() * wts).mean() + (X.real * wts + X.imag * wts.flip(-1)).sum()
+        (gx,) = torch.autograd.grad(loss, xa)
+        return float(loss), gx, name, tuple(X.shape)
+
+    l_ref, g_ref, _, shp_ref = loss_and_grad("cpu", torch.float64)
+    l_got, g_got, name, shp = loss_and_grad("cuda", torch.float32)
+    assert shp == shp_ref
+    assert name in ("_NativeStftGeneralBackward", "_NativeStftBackward"), name        # not torch.stft's backward
+    assert abs(l_got - l_ref) <= 1e-4 * abs(l_ref)
+    assert rel_err(g_got.double(), g_ref) < REL, rel_err(g_got.double(), g_ref)
+
+
+def test_mel_autograd_general_sizes():
+    """mel_spectrogram under autograd at a run-time size and with match_stride: the STFT below the (torch) magnitude and
+    basis product is the native pair, the gradient matches float64."""
+    x = synth.audio_batch(2, 1, 16000, seed=77, gaps=False)
+    for kw in (dict(window_length=1200, hop_length=300), dict(window_length=2048, hop_length=512, match_stride=True)):
+        def run(dev, dtype):
+            xa = x.clone().to(dev, dtype).requires_grad_(True)
+            s = A.AudioSignal(xa, 24000)
+            if dtype == torch.float64:
+                s.audio_data = xa
+            if dtype == torch.float64:             # (the float32 basis does not multiply a float64 magnitude: by hand)
+                X = s.stft(**kw)
+                basis = torch.from_numpy(s.get_mel_filters(24000, kw["window_length"], 40)).double()
+                mel = (X.abs().transpose(2, -1) @ basis.T).transpose(-1, 2)
+            else:
+                mel = s.mel_spectrogram(40, **kw)
+            loss = mel.clamp(1e-5).log10().mean() + mel.sum() * 1e-3
+            (gx,) = torch.autograd.grad(loss, xa)
+            return gx, type(s.stft_data.grad_fn).__name__
+        g_ref, _ = run("cpu", torch.float64)
+        g_got, name = run("cuda", torch.float32)
+        assert "Native" in name, name
+        assert rel_err(g_got.double(), g_ref) < REL, (kw, rel_err(g_got.double(), g_ref))
+
+
 def test_c_abi_error_codes_and_degenerate_inputs():
     """The C ABI never throws: 0 = ok, -1 = bad argument, -2 = no kernel for the request; empty
     batches are no-ops; the Python layer turns codes into NativeError / the reference's errors."""
