@@ -277,16 +277,20 @@ __device__ __forceinline__ void build_pass_twiddles(float2* __restrict__ dst, co
 // lanes repeat that butterfly and store the same values to the same slots.  With predicated
 // iterations every butterfly was its own basic block and its LDS reads were not issued before the
 // previous butterfly had finished (the kernel ran at 46 % VALU and 26 % LDS utilisation).
-template <int R, int NB, int NT, class L>
+// WAVE = true (NT = 64): the tile belongs to ONE wave (the wave-per-row-pair form of the long convolution): the thread
+// index is the lane and "the workgroup meets" is a wave-level fence -- no s_barrier, the waves of a workgroup never wait
+// for each other.
+template <int R, int NB, int NT, class L, bool WAVE = false>
 __device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const float2* __restrict__ twp, int N, int NS,
                                              int total, const L lay) {
+  static_assert(!WAVE || NT == 64, "a wave-level pass has 64 threads");
   const int nb = N / R;
   const float inv_ns = 1.0f / (float)NS;
   float2 v[NB][MAX_RADIX];
   int o[NB], ob[NB];
   // opaque copy of the thread index: keeps the per-butterfly index arithmetic of every pass variant
   // from being hoisted out of the pass loop (that cost > 128 live registers and spills)
-  int tid = (int)threadIdx.x;
+  int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   asm volatile("" : "+v"(tid));
   const int last = total - 1;
   // the last iteration is skipped by the waves that lie entirely past the end (wave-uniform branch)
@@ -312,7 +316,7 @@ __device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const flo
 #pragma unroll
   for (int b = 0; b < NB - 1; ++b) dft_r<R>(v[b]);
   if (tail) dft_r<R>(v[NB - 1]);
-  __syncthreads();
+  if constexpr (WAVE) wave_sync(); else __syncthreads();
 #pragma unroll
   for (int b = 0; b < NB - 1; ++b) {
 #pragma unroll
@@ -322,23 +326,32 @@ __device__ __forceinline__ void pass_inplace(float2* __restrict__ buf, const flo
 #pragma unroll
     for (int q = 0; q < R; ++q) buf[lay.addr(ob[NB - 1], o[NB - 1] + NS * q)] = v[NB - 1][q];
   }
-  __syncthreads();
+  if constexpr (WAVE) wave_sync(); else __syncthreads();
 }
 
 // the variant for the iteration count of this launch (uniform): NB = ceil(total / NT)
-template <int R, int NT, class L>
+template <int R, int NT, class L, bool WAVE = false>
 __device__ __forceinline__ void pass_dispatch(float2* buf, const float2* tw, int N, int NS, int total, const L lay) {
-  constexpr int MAXB = (TILE_POINTS / R + NT - 1) / NT;
+  // (a wave-level tile holds at most WAVE_TILE_POINTS points: the variants past 8 butterflies per lane are never needed,
+  //  the host checks wave_pass_list_ok before it picks the wave form)
+  constexpr int MAXB = ((WAVE ? 2048 : TILE_POINTS) / R + NT - 1) / NT;
   const int nbi = (total + NT - 1) / NT;
-  if (nbi <= 1) pass_inplace<R, 1, NT>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 2 && nbi == 2) pass_inplace<R, (MAXB >= 2 ? 2 : 1), NT>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 3 && nbi == 3) pass_inplace<R, (MAXB >= 3 ? 3 : 1), NT>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 4 && nbi == 4) pass_inplace<R, (MAXB >= 4 ? 4 : 1), NT>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 6 && nbi <= 6) pass_inplace<R, (MAXB >= 6 ? 6 : 1), NT>(buf, tw, N, NS, total, lay);
-  else if (MAXB >= 8) pass_inplace<R, (MAXB >= 8 ? 8 : 1), NT>(buf, tw, N, NS, total, lay);
+  if (nbi <= 1) pass_inplace<R, 1, NT, L, WAVE>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 2 && nbi == 2) pass_inplace<R, (MAXB >= 2 ? 2 : 1), NT, L, WAVE>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 3 && nbi == 3) pass_inplace<R, (MAXB >= 3 ? 3 : 1), NT, L, WAVE>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 4 && nbi == 4) pass_inplace<R, (MAXB >= 4 ? 4 : 1), NT, L, WAVE>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 6 && nbi <= 6) pass_inplace<R, (MAXB >= 6 ? 6 : 1), NT, L, WAVE>(buf, tw, N, NS, total, lay);
+  else if (MAXB >= 8) pass_inplace<R, (MAXB >= 8 ? 8 : 1), NT, L, WAVE>(buf, tw, N, NS, total, lay);
 }
 
-template <int NT, class L>
+// the wave form runs at most 8 butterflies per lane and pass (pass_dispatch): batches * N / R <= 512 for every pass
+inline bool wave_pass_list_ok(const PassList& pl, int N, int batches) {
+  for (int p = 0; p < pl.n; ++p)
+    if ((N / pl.radix[p]) * batches > 8 * 64) return false;
+  return true;
+}
+
+template <int NT, class L, bool WAVE = false>
 __device__ __forceinline__ void run_passes(float2* buf, const float2* twb /* pass blocks */, int N, const PassList& pl,
                                            int batches, const L lay) {
   int off = 0;
@@ -347,15 +360,15 @@ __device__ __forceinline__ void run_passes(float2* buf, const float2* twb /* pas
     const int total = (N / R) * batches;
     const float2* tw = twb + off;
     switch (R) {
-      case 16: pass_dispatch<16, NT>(buf, tw, N, NS, total, lay); break;
-      case 25: pass_dispatch<25, NT>(buf, tw, N, NS, total, lay); break;
-      case 8: pass_dispatch<8, NT>(buf, tw, N, NS, total, lay); break;
-      case 9: pass_dispatch<9, NT>(buf, tw, N, NS, total, lay); break;
-      case 4: pass_dispatch<4, NT>(buf, tw, N, NS, total, lay); break;
-      case 2: pass_dispatch<2, NT>(buf, tw, N, NS, total, lay); break;
-      case 3: pass_dispatch<3, NT>(buf, tw, N, NS, total, lay); break;
-      case 5: pass_dispatch<5, NT>(buf, tw, N, NS, total, lay); break;
-      default: pass_dispatch<7, NT>(buf, tw, N, NS, total, lay); break;
+      case 16: pass_dispatch<16, NT, L, WAVE>(buf, tw, N, NS, total, lay); break;
+      case 25: pass_dispatch<25, NT, L, WAVE>(buf, tw, N, NS, total, lay); break;
+      case 8: pass_dispatch<8, NT, L, WAVE>(buf, tw, N, NS, total, lay); break;
+      case 9: pass_dispatch<9, NT, L, WAVE>(buf, tw, N, NS, total, lay); break;
+      case 4: pass_dispatch<4, NT, L, WAVE>(buf, tw, N, NS, total, lay); break;
+      case 2: pass_dispatch<2, NT, L, WAVE>(buf, tw, N, NS, total, lay); break;
+      case 3: pass_dispatch<3, NT, L, WAVE>(buf, tw, N, NS, total, lay); break;
+      case 5: pass_dispatch<5, NT, L, WAVE>(buf, tw, N, NS, total, lay); break;
+      default: pass_dispatch<7, NT, L, WAVE>(buf, tw, N, NS, total, lay); break;
     }
     if (NS > 1) off += NS * (R - 1);
   }

@@ -222,6 +222,7 @@ struct RowArgs {
   int C, Cir;
   int N1, N2, rt, npairs;
   float inv_m;
+  int64_t total_units;      // rows * npairs (the wave form: one wave per unit)
   PassList pl;
 };
 
@@ -378,6 +379,148 @@ __global__ __launch_bounds__(RTHREADS, ROW_WGS * RTHREADS / 256) void rowconv_ke
   body(std::integral_constant<int, ROW_LOADS>{});
 }
 
+#if AT_DEV_KNOBS
+// ---------------------------------------------------------------- the same, ONE WAVE per row pair (round 5; development build)
+// MEASURED, NOT SHIPPED (profiles/r05_notes.md section 3): at cfg4 on the N2 <= 1024 plan (N1 = 120, N2 = 1000) this kernel
+// takes 1.49 ms where rowconv_kernel takes 1.40 ms on the N2 = 2000 plan; with the column kernels 10 % faster at N1 = 120 the
+// whole convolution is 2.66-2.69 ms against 2.69-2.70 ms: a draw.  Counters: 9 720 VALU instructions per row pair and lane
+// (104 per complex point and transform), VALU active 42 % of the wave cycles x 2 waves per SIMD -- without the barriers the
+// row kernel is bound by the instruction count of the generic mixed-radix passes, not by latency any more.
+// rowconv_kernel's four waves move in lockstep between ~28 workgroup barriers and three workgroups share a CU: VALU, LDS and
+// HBM time add up (1.40 ms for 3.02 GB at cfg4 = 27 % of 8 TB/s, 39 % issue utilisation).  Here a row pair belongs to one
+// wave: its two rows live in the wave's own LDS slab, the mixed-radix passes are the same code with the lane as thread
+// index and a wave-level fence where the workgroup met (generic_fft.h, WAVE = true), so no wave ever waits for another one
+// and eight row pairs per CU are in eight different phases -- loads, passes, split step, stores overlap across waves instead
+// of inside one.  Rows of at most 1024 points (2 x N2 x 8 B per wave: two workgroups of four waves per CU); the arithmetic,
+// tables and index algebra are rowconv_kernel's, statement for statement.
+constexpr int WROW_N2 = 1024;                   // longest row of the wave form
+constexpr int WROW_WAVES = 4;                   // waves (row pairs) per workgroup
+constexpr int WLOADS = 2 * WROW_N2 / 64;        // points of a row pair per lane
+constexpr int WSPEC = WROW_N2 / 64;             // bins of one row per lane
+
+// PLAN = 0: run-time pass list (any eligible row length); PLAN = 1: N2 = 1000 = 25 * 5 * 8 with the pass list as literals
+// (cfg4's T = 240000 on the N2 <= 1024 plan): index arithmetic folds, and the kernel is 1/8 of the generic one's 128 KB of
+// code -- eight waves per CU in eight different phases have to share the instruction cache.
+template <int PLAN>
+__global__ __launch_bounds__(WROW_WAVES * 64, 2) void rowconv_wave_kernel(const RowArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float2 smem[];
+  const int N2 = PLAN == 1 ? 1000 : A.N2;
+  float2* tw = smem;                                            // [N2] per-pass twiddle blocks, shared by the workgroup
+  at::gfft::build_pass_twiddles<WROW_WAVES * 64>(tw, A.tw2, 1, N2, A.pl);
+  __syncthreads();                                              // the only workgroup barrier
+  const int lane = (int)(threadIdx.x & 63);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float2* buf = smem + N2 + wave * (2 * N2 + 2 * A.rt);         // [2][N2]
+  float2* rt = buf + 2 * N2;                                    // [2][rt]
+  const int64_t unit = (int64_t)blockIdx.x * WROW_WAVES + wave;
+  if (unit >= A.total_units) return;                            // wave-uniform
+  const int64_t xrow = unit / A.npairs;
+  const int p = (int)(unit - xrow * A.npairs);
+  const int k1a = p, k1b = (A.N1 - p) % A.N1;
+  const bool self = k1a == k1b;
+  const int nrow = self ? 1 : 2;
+  const int64_t b = xrow / A.C;
+  const int c = (int)(xrow - b * A.C);
+  const int64_t hrow = b * A.Cir + (A.Cir == 1 ? 0 : c);
+  const int64_t MM = (int64_t)A.N1 * N2;
+  float2* __restrict__ gx = A.ax + xrow * MM;
+  const float2* __restrict__ gh = A.ah + hrow * MM;
+  const int npts = nrow * N2;
+  const RowLayout lay{N2, 0};
+  const float2 wlo = A.sp_lo[k1a];
+  const int slot_b = self ? 0 : N2;
+  const float sc = (A.scale ? A.scale[hrow] : 1.0f) * A.inv_m;
+
+  for (int i = lane; i < nrow * A.rt; i += 64) {
+    const int s = i >= A.rt ? 1 : 0;
+    rt[i] = A.rowtw[(int64_t)(s ? k1b : k1a) * A.rt + (i - s * A.rt)];
+  }
+  at::wave_sync();
+
+  // rows of one signal -> twiddle w_M^{k1 n2} -> the wave's slab.  All loads of the pair are issued before the first
+  // product (fixed trip count, clamped indices: surplus iterations repeat the last point).
+  auto load_rows = [&](const float2* __restrict__ g) __attribute__((always_inline)) {
+    float2 r[WLOADS];
+    int tid = lane;
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      const int e = min(tid + 64 * i, npts - 1);
+      const int s = e >= N2 ? 1 : 0;
+      r[i] = g[__mul24(s ? k1b : k1a, N2) + (e - s * N2)];
+    }
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      const int e = min(tid + 64 * i, npts - 1);
+      const int s = e >= N2 ? 1 : 0;
+      const int n2 = e - s * N2;
+      const float2 w = cmulf(rt[s * A.rt + (n2 & 63)], rt[s * A.rt + 64 + (n2 >> 6)]);
+      buf[e] = cmulf(r[i], w);
+      if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    at::wave_sync();
+  };
+
+  float2 Xk[WSPEC], Xm[WSPEC];
+  for (int ph = 0; ph < 3; ++ph) {
+    int tid = lane;                           // opaque per phase: nothing below is hoisted out of the loop
+    asm volatile("" : "+v"(tid));
+    if (ph < 2) load_rows(ph == 0 ? reinterpret_cast<const float2*>(gx) : gh);
+    if constexpr (PLAN == 1) {
+      // butterflies per lane for a row pair: 80 / 64 -> 2, 400 / 64 -> 7, 250 / 64 -> 4 (a self-paired row: half of them,
+      // the surplus lanes repeat the last butterfly); twiddle blocks: radix 5 behind 25 at 0, radix 8 behind 125 at 100
+      at::gfft::pass_inplace<25, 2, 64, RowLayout, true>(buf, tw, 1000, 1, nrow * 40, lay);
+      at::gfft::pass_inplace<5, 7, 64, RowLayout, true>(buf, tw, 1000, 25, nrow * 200, lay);
+      at::gfft::pass_inplace<8, 4, 64, RowLayout, true>(buf, tw + 100, 1000, 125, nrow * 125, lay);
+    } else {
+      run_passes<64, RowLayout, true>(buf, tw, N2, A.pl, nrow, lay);
+    }
+    if (ph == 2) break;
+#pragma unroll
+    for (int i = 0; i < WSPEC; ++i) {
+      const int k2 = tid + 64 * i;
+      const int k2m = k1a == 0 ? (k2 == 0 ? 0 : N2 - k2) : N2 - 1 - k2;
+      if (k2 < N2 && (!self || k2 <= k2m)) {
+        const float2 zk = buf[k2], zm = buf[slot_b + k2m];
+        const bool dc = k1a == 0 && k2 == 0;            // DC and Nyquist, both real, packed in Z[0]
+        const float2 w = cmulf(wlo, A.sp_hi[k2]);
+        float2 sk, sm;
+        if (dc) { sk = make_float2(zk.x + zk.y, 0.f); sm = make_float2(zk.x - zk.y, 0.f); }
+        else real_split(zk, zm, w, sk, sm);
+        if (ph == 0) { Xk[i] = sk; Xm[i] = sm; }
+        else {
+          float2 ok, om;
+          if (dc) {
+            const float y0 = Xk[i].x * sk.x * sc, ym = Xm[i].x * sm.x * sc;
+            ok = make_float2(0.5f * (y0 + ym), 0.5f * (y0 - ym));
+            om = ok;
+          } else {
+            float2 yk = cmulf(Xk[i], sk), ym = cmulf(Xm[i], sm);
+            yk.x *= sc; yk.y *= sc; ym.x *= sc; ym.y *= sc;
+            real_merge(yk, ym, w, ok, om);
+          }
+          buf[k2] = make_float2(ok.x, -ok.y);
+          if (!(self && k2 == k2m)) buf[slot_b + k2m] = make_float2(om.x, -om.y);
+        }
+      }
+    }
+    at::wave_sync();
+  }
+  int tid2 = lane;
+  asm volatile("" : "+v"(tid2));
+#pragma unroll
+  for (int i = 0; i < WLOADS; ++i) {
+    const int e = min(tid2 + 64 * i, npts - 1);
+    const int s = e >= N2 ? 1 : 0;
+    const int n2 = e - s * N2;
+    const float2 w = cmulf(rt[s * A.rt + (n2 & 63)], rt[s * A.rt + 64 + (n2 >> 6)]);
+    gx[__mul24(s ? k1b : k1a, N2) + n2] = cmulf(buf[e], w);
+    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+#endif  // AT_DEV_KNOBS
+
 inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
 
 }  // namespace
@@ -494,7 +637,22 @@ int run_longconv(const float* x, const IrSource& ir, const float* scale, int64_t
   ra.ax = ax; ra.ah = ah; ra.scale = scale; ra.tw2 = tb + o.tw2; ra.rowtw = tb + o.rowtw; ra.sp_lo = tb + o.sp_lo;
   ra.sp_hi = tb + o.sp_hi; ra.C = (int)C; ra.Cir = (int)Cir; ra.N1 = P.N1; ra.N2 = P.N2; ra.rt = o.rt;
   ra.npairs = P.N1 / 2 + 1; ra.inv_m = 1.0f / (float)(T / 2); ra.pl = P.p2;
-  hipLaunchKernelGGL(rowconv_kernel, dim3((unsigned)(rows_x * ra.npairs)), dim3(RTHREADS), row_lds, st, ra);
+  ra.total_units = rows_x * ra.npairs;
+#if AT_DEV_KNOBS
+  static const int wave_form = at::env_int_once("AT_ROWCONV_WAVE", 0);      // development A/B: 1 = one wave per row pair (rows <= 1024)
+  if (wave_form && P.N2 <= WROW_N2 && at::gfft::wave_pass_list_ok(P.p2, P.N2, 2)) {
+    const size_t wlds = ((size_t)P.N2 + (size_t)WROW_WAVES * (2 * P.N2 + 2 * o.rt)) * sizeof(float2);
+    const bool fixed1 = P.N2 == 1000 && P.p2.n == 3 && P.p2.radix[0] == 25 && P.p2.radix[1] == 5 && P.p2.radix[2] == 8;
+    const void* kfn = fixed1 ? reinterpret_cast<const void*>(rowconv_wave_kernel<1>) : reinterpret_cast<const void*>(rowconv_wave_kernel<0>);
+    if ((e = at::allow_big_lds(kfn)) != AT_OK) return e;
+    const int64_t wgs = (ra.total_units + WROW_WAVES - 1) / WROW_WAVES;
+    if (fixed1) hipLaunchKernelGGL(rowconv_wave_kernel<1>, dim3((unsigned)wgs), dim3(WROW_WAVES * 64), wlds, st, ra);
+    else hipLaunchKernelGGL(rowconv_wave_kernel<0>, dim3((unsigned)wgs), dim3(WROW_WAVES * 64), wlds, st, ra);
+  } else
+#endif
+  {
+    hipLaunchKernelGGL(rowconv_kernel, dim3((unsigned)(rows_x * ra.npairs)), dim3(RTHREADS), row_lds, st, ra);
+  }
   AT_LAUNCH_CHECK();
 
   ca.src = ax; ca.dst = ax; ca.rows = rows_x;
