@@ -41,6 +41,7 @@ ap.add_argument("--variants", action="store_true", help="(dev build) twin withou
 ap.add_argument("--pool", type=int, default=0, help="carve N extra sets out of ONE hipMalloc of N x the set size")
 ap.add_argument("--spans", action="store_true", help="(dev build) span schedules: phase-shifted rounds, row-interleaved spans")
 ap.add_argument("--affinity", action="store_true", help="(dev build) one XCD at a time on each eighth of the spectrum buffer")
+ap.add_argument("--spacing", action="store_true", help="the twin on the first R rows of every set, R = 1024 ... 512: the spacing of the eight XCD spans changes with R")
 ap.add_argument("--tag", default="")
 args = ap.parse_args()
 
@@ -199,6 +200,17 @@ if args.variants:
             t1 = timeit(bs.twin)
             print(f"variant on the {lab} set: {name:28s} {t1:.3f} ms", flush=True)
     os.environ.pop("AT_STFT_FLAGS", None)
+
+if args.spacing:
+    print("spacing sweep: twin on the first R rows of each set (8 spans of R / 8 rows = R x 0.8836 MB apart); us per row", flush=True)
+    Rs = [1024, 1016, 1008, 1000, 992, 976, 960, 944, 928, 912, 896, 864, 832, 800, 768, 704, 640, 576, 512]
+    print("      R: " + " ".join(f"{r:6d}" for r in Rs), flush=True)
+    for i, bs in enumerate(sets):
+        vals = []
+        for R in Rs:
+            t_ = timeit(lambda: launch(lib.at_stft_mel_floor_f32, bs.px, bs.ps, bs.pm, rows=R), iters=8)
+            vals.append(1e3 * t_ / R)
+        print(f"  set {i}: " + " ".join(f"{v:6.3f}" for v in vals), flush=True)
 
 if args.affinity:
     assert os.environ.get("AT_STFT_TUNE") == "1", "start the process with AT_STFT_TUNE=1"
