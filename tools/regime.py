@@ -212,6 +212,18 @@ if args.spacing:
             vals.append(1e3 * t_ / R)
         print(f"  set {i}: " + " ".join(f"{v:6.3f}" for v in vals), flush=True)
 
+if args.spacing:
+    for Rw in (512, 256):
+        offs = list(range(0, rows - Rw + 1, 64))
+        print(f"window sweep: twin on rows [a, a + {Rw}) of each set; us per row;  a = " + " ".join(f"{a:5d}" for a in offs), flush=True)
+        for i, bs in enumerate(sets):
+            vals = []
+            for a in offs:
+                px, ps, pm = bs.px + a * T * 4, bs.ps + a * N * F * 8, bs.pm + a * N * n_mels * 4
+                t_ = timeit(lambda: launch(lib.at_stft_mel_floor_f32, px, ps, pm, rows=Rw), iters=8)
+                vals.append(1e3 * t_ / Rw)
+            print(f"  set {i}:                                                       " + " ".join(f"{v:5.3f}" for v in vals), flush=True)
+
 if args.affinity:
     assert os.environ.get("AT_STFT_TUNE") == "1", "start the process with AT_STFT_TUNE=1"
     NSL = 8
