@@ -351,6 +351,152 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
   }
 }
 
+// The same with the ROW IN REGISTERS (round 5): mono impulse responses of up to RT * NV float4 -- a 2 s RIR at 48 kHz is
+// 96 000 samples = 47 float4 per thread -- are read ONCE; the arg-max, the energies and the output all come from the
+// registers (the three-sweep kernel above moved 1.61 GB for the 0.79 GB of one read + one write at cfg4: its second and
+// third sweeps missed L2).  Every thread holds exactly the elements the sweeps of alter_drr_kernel hand it, in the same
+// order, and the block reductions are the same functions: the results are bit-identical.
+template <int NV>
+__global__ __launch_bounds__(RT, 2) void alter_drr_regs_kernel(const float* __restrict__ x, int64_t B, int64_t T, int t0,
+                                                               const float* __restrict__ drr /* (B) */, float* __restrict__ out,
+                                                               float* __restrict__ vmax, int64_t* __restrict__ imax) {
+  __shared__ MaxIdx shm[RT / 64];
+  __shared__ float shf[RT / 64];
+  const int T4 = (int)(T / 4);
+  const int tid = (int)threadIdx.x;
+  const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);      // first float4 slot of this wave in every k-iteration
+  // k-iterations: [0, kfull) hold a float4 for every lane of this wave, iteration kfull (if < per) only for some lanes,
+  // everything behind it for none -- all three are wave-uniform, so the sweeps below carry lane masks in ONE iteration
+  const int dfull = T4 - wbase - 64;
+  const int kfull = dfull >= 0 ? min(NV, dfull / RT + 1) : 0;
+  const int kpart = (kfull < NV && wbase + RT * kfull < T4) ? 1 : 0;
+  for (int64_t row = blockIdx.x; row < B; row += gridDim.x) {
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(x + row * T);
+    float4 r[NV];
+    int t0_ = tid;                                       // opaque per sweep: the per-element indices are recomputed here, not
+    asm volatile("" : "+v"(t0_));                        // hoisted out of the row loop and kept alive next to the row itself
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = t0_ + RT * k;
+      r[k] = p4[i < T4 ? i : T4 - 1];                    // clamped, unconditional: all loads in flight at once
+    }
+    // sweep 1 (registers): signed arg-max, 32-bit indices (T < 2^31)
+    float bv = -INFINITY;
+    int bi = 0;
+    int t1 = tid;
+    asm volatile("" : "+v"(t1));
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (k < kfull + kpart) {                           // wave-uniform
+        const int i = t1 + RT * k;
+        const bool ok = k < kfull || i < T4;
+        const float e[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool take = ok && e[u] > bv;
+          bv = take ? e[u] : bv;
+          bi = take ? 4 * i + u : bi;
+        }
+      }
+    }
+    const MaxIdx m = block_argmax(MaxIdx{bv, (int64_t)bi}, shm);
+    const int e_lo = (int)m.i - t0, e_hi = (int)m.i + t0;           // early span = window (mono: channel 0 is this row)
+    const unsigned e_span = 2u * (unsigned)t0;                      // early  <=>  (unsigned)(n - e_lo) <= e_span
+    // does iteration k of THIS wave touch the early span at all?  (wave-uniform; true for one or two iterations of one or
+    // two waves: everywhere else an element is "late" and the sweeps take their three-instruction path)
+    auto touches = [&](int k) { const int lo = 4 * (wbase + RT * k); return lo <= e_hi && lo + 255 >= e_lo; };
+    // sweep 2 (registers): energies and peaks
+    float a_sum = 0.f, late_sq = 0.f, mx_late = 0.f, mx_ew = 0.f;
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (k < kfull + kpart) {
+        const int i = t2 + RT * k;
+        const bool ok = k < kfull || i < T4;
+        const float e[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
+        if (!touches(k)) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float v = ok ? e[u] : 0.f;             // (a surplus element adds +0 to a sum and max(., 0) to a peak: neutral)
+            late_sq += v * v;
+            mx_late = fmaxf(mx_late, fabsf(v));
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool early = (unsigned)(4 * i + u - e_lo) <= e_span;
+            const float v = ok ? e[u] : 0.f;
+            const float av = fabsf(v), sq = v * v;
+            a_sum += early ? sq : 0.f;
+            late_sq += early ? 0.f : sq;
+            mx_ew = fmaxf(mx_ew, early ? av : 0.f);
+            mx_late = fmaxf(mx_late, early ? 0.f : av);
+          }
+        }
+      }
+    }
+    a_sum = block_sum(a_sum, shf);
+    const float c_sum = 0.f;                              // early-but-outside-the-window is empty for a mono row
+    late_sq = block_sum(late_sq, shf);
+    mx_late = block_max(mx_late, shf);
+    mx_ew = block_max(mx_ew, shf);
+    const float mx_enw = 0.f;
+    const float cc = c_sum - powf(10.f, drr[row] / 10.f) * late_sq;
+    const float disc = sqrtf(0.f * 0.f - 4.f * a_sum * cc);
+    const float r1 = (-0.f - disc) / (2.f * a_sum), r2 = (-0.f + disc) / (2.f * a_sum);
+    float alpha = (r1 != r1 || r2 != r2) ? NAN : fmaxf(r1, r2);
+    const float min_alpha = mx_late / fmaxf(mx_ew, mx_enw);
+    alpha = (alpha != alpha || min_alpha != min_alpha) ? NAN : fmaxf(alpha, min_alpha);
+    const float peak = fmaxf(fmaxf(fabsf(alpha * mx_ew), mx_enw), mx_late);
+    const float gain = (alpha == alpha && peak > 1.0f) ? 1.0f / peak : 1.0f;
+    // what alpha * w * e + (1 - w) * e contributes to a late element (w = 0, e = 0): zero, or NaN when alpha is not finite
+    // (a non-finite alpha poisons the whole row, as in torch)
+    const float late_term = alpha * 0.f * 0.f + 1.f * 0.f;
+    // sweep 3 (registers -> out)
+    float4* __restrict__ o4 = reinterpret_cast<float4*>(out + row * T);
+    float av_best = -1.0f;
+    int ai = 0;
+    int t3 = tid;
+    asm volatile("" : "+v"(t3));
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (k < kfull + kpart) {
+        const int i = t3 + RT * k;
+        const bool ok = k < kfull || i < T4;
+        const float e[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
+        float o[4];
+        if (!touches(k)) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) o[u] = (late_term + e[u]) * gain;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool early = (unsigned)(4 * i + u - e_lo) <= e_span;
+            const float ev = early ? e[u] : 0.f, l = early ? 0.f : e[u], w = early ? 1.f : 0.f;
+            o[u] = (alpha * w * ev + (1.f - w) * ev + l) * gain;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float a = fabsf(o[u]);
+          const bool take = ok && takes_over(a, av_best);
+          av_best = take ? a : av_best;
+          ai = take ? 4 * i + u : ai;
+        }
+        if (ok) o4[i] = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    if (vmax) {
+      const MaxIdx am = block_argmax(MaxIdx{av_best, (int64_t)ai}, shm);
+      if (tid == 0) {
+        vmax[row] = am.v;
+        if (imax) imax[row] = am.i;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -393,7 +539,18 @@ int at_alter_drr_peak_f32(const float* x, int64_t B, int64_t C, int64_t T, int t
   if (C > 1 && x == out) return AT_ERR_INVALID;  // channel 0 is re-read by the other channels
   const int64_t rows = B * C;
   const int64_t blocks = rows < 65536 ? rows : 65536;
-  hipLaunchKernelGGL(alter_drr_kernel, dim3((unsigned)blocks), dim3(RT), 0, reinterpret_cast<hipStream_t>(stream), x, B,
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // mono rows that fit the register file of one workgroup: one read, one write
+  const bool aligned = (T % 4) == 0 && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+  if (C == 1 && aligned && T / 4 <= (int64_t)RT * 48 && T < (1LL << 31)) {
+    const int64_t per = (T / 4 + RT - 1) / RT;
+    if (per <= 16) hipLaunchKernelGGL(alter_drr_regs_kernel<16>, dim3((unsigned)blocks), dim3(RT), 0, st, x, B, T, t0, drr, out, vmax, imax);
+    else if (per <= 32) hipLaunchKernelGGL(alter_drr_regs_kernel<32>, dim3((unsigned)blocks), dim3(RT), 0, st, x, B, T, t0, drr, out, vmax, imax);
+    else hipLaunchKernelGGL(alter_drr_regs_kernel<48>, dim3((unsigned)blocks), dim3(RT), 0, st, x, B, T, t0, drr, out, vmax, imax);
+    AT_LAUNCH_CHECK();
+    return AT_OK;
+  }
+  hipLaunchKernelGGL(alter_drr_kernel, dim3((unsigned)blocks), dim3(RT), 0, st, x, B,
                      (int)C, T, t0, drr, out, vmax, imax);
   AT_LAUNCH_CHECK();
   return AT_OK;

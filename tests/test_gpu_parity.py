@@ -1878,6 +1878,45 @@ def test_tap_design_kernels_match_torch_formulation():
         assert rel_err(tq[:, :Lq], ref_t) < 1e-6 and not tq[:, Lq:].any()
 
 
+@pytest.mark.parametrize("T", [96000, 40000, 8192, 2048, 512, 8])
+def test_alter_drr_register_resident_kernel(T):
+    """Round 5: mono impulse responses of up to 98 304 aligned samples are read ONCE (alter_drr_regs_kernel: the row in the
+    registers of one workgroup; csrc/irtools.hip) instead of three times.  Against the torch formulation on the CPU (pinned
+    to the unmodified reference in tests/test_transforms.py): peaks at the first / last sample, on wave and iteration
+    boundaries of the kernel's element assignment, an all-negative row, a tie, a NaN row; the reported peak equals absmax's;
+    in place."""
+    from audiotools_amd import kernels
+    sr = 48000
+    g = torch.Generator().manual_seed(T)
+    B = 9
+    ir = torch.randn(B, 1, T, generator=g) * torch.exp(-torch.arange(T) / (0.2 * T + 1))
+    for b, pos in enumerate((0, T - 1, min(255, T - 1), min(256, T - 1), min(2047, T - 1), min(2048, T - 1), T // 2)):
+        ir[b, 0, pos] = ir[b].abs().max() * 1.5
+    ir[7] = -ir[7].abs() - 0.01                         # every sample negative: the signed arg-max is the least negative one
+    if T >= 512:
+        ir[8, 0, 100] = 3.0
+        ir[8, 0, 300] = 3.0                              # tie: the first index wins
+    drr = torch.tensor([0.0, 3.0, 6.0, 10.0, 15.0, 20.0, 25.0, 30.0, 12.0])
+    ref = A.AudioSignal(ir.clone(), sr).alter_drr(drr).audio_data
+    sig = A.AudioSignal(ir.clone(), sr).to("cuda")
+    got = sig.alter_drr(drr.cuda()).audio_data.cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    assert rel_err(torch.nan_to_num(got), torch.nan_to_num(ref)) < 1e-5
+    t0 = int(sr * 0.0025)
+    x = ir.cuda()
+    out, vmax, imax = kernels.alter_drr(x, t0, drr.cuda(), want_peak=True)
+    pv, pi = kernels.absmax(out, want_index=True)
+    same = lambda a, b: bool(((a == b) | (a.isnan() & b.isnan())).all())
+    assert same(vmax, pv) and torch.equal(imax, pi)
+    assert same(out.cpu(), got)
+    if T >= 4:
+        xn = x.clone()
+        xn[3, 0, T // 3] = float("nan")                  # a NaN sample: torch's max propagates it, the row becomes NaN
+        refn = A.AudioSignal(xn.cpu(), sr).alter_drr(drr).audio_data
+        gotn = kernels.alter_drr(xn, t0, drr.cuda()).cpu()
+        assert torch.equal(torch.isnan(gotn), torch.isnan(refn))
+
+
 def test_alter_drr_reports_the_peak_absmax_would():
     """at_alter_drr_peak_f32: the output pass of alter_drr also yields max |out| and its first position per row -- what
     apply_ir's convolution asks at_absmax_f32 for next -- for mono and multi-channel impulse responses, a row whose DRR
