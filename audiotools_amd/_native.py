@@ -191,9 +191,9 @@ def lib():
         if _lib is not None:
             return _lib
         if not os.path.exists(LIB_PATH):
-            raise NativeError(
-                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
-                f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+            how = ("`python -m audiotools_amd._native --dev` (the development build AT_DEV_KNOBS=1 asks for)" if LIB_PATH == DEV_LIB_PATH
+                   else "`python -c 'import __graft_entry__ as g; g.build()'`")
+            raise NativeError(f"{LIB_PATH} not found: build it with {how} (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         try:
             handle = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
