@@ -59,10 +59,114 @@ def stft_fused_supported(n_fft: int) -> bool:
     return bool(_native.lib().at_stft_fused_supported(int(n_fft)))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Placement-aware output buffers (round 5).  The time of the fused STFT kernel follows WHERE its spectrum buffer lies
+# physically: the same binary writes the same 7.2 GB in 1.95 ms into one allocation and in 2.12-2.19 ms into the next one of the
+# same process (DRAM bank-level parallelism behind GB-scale address bits; profiles/r05_notes.md section 1) -- deterministic per
+# allocation, invisible from the virtual address, not reachable by any schedule of the kernel.  MI355X has 288 GB of HBM: for
+# large outputs the first call of a shape allocates a few candidate buffer sets, times the REAL kernel into each (every
+# candidate holds this call's valid result), keeps the fastest ones in a small pool and recycles them for later calls of
+# that shape.  Only the SPECTRUM buffer is pooled: exchanging buffers between a slow and a fast set showed that neither the
+# signal's nor the mel output's placement matters (r05_notes.md 1.1).  Semantics are those of a fresh allocation: a pooled
+# buffer is handed out again only when no tensor of the caller references its storage any more (the C++ storage use
+# count), otherwise the call falls back to torch.empty.
+class _PlacedOutputs:
+    CANDIDATES = 8              # buffer sets timed at calibration (about two in five allocations are fast: with eight, at least
+                                # two fast ones turn up in ~90 % of the processes, with five in ~65 %)
+    KEEP = 3                    # ... of which this many stay in the pool (mel_spectrogram alternates two while stft_data holds one)
+    MIN_BYTES = 256 << 20       # outputs below this size are not worth it
+    MAX_POOL_BYTES = 48 << 30   # all shapes together; the least recently used shape is dropped beyond it
+    enabled = True
+
+    def __init__(self):
+        self.shapes = {}        # key -> {"slots": [(ms, stft_buf)], "bytes": int, "tick": int} or None (not worth it / no room)
+        self.tick = 0
+
+    @staticmethod
+    def _free(t):
+        # 2 = the pool's tensor + the temporary storage object of this query; every view / saved tensor / numpy export adds one
+        return t is None or torch._C._storage_Use_Count(t.untyped_storage()._cdata) <= 2
+
+    def acquire(self, key, nbytes, alloc, launch):
+        """(stft_buf, launched) for this call: a pooled spectrum buffer when the shape has a calibrated pool and one of its
+        buffers is free; at the first call of a shape, calibration (then `launched` is True: the buffer already holds this
+        call's result); otherwise None (plain allocation)."""
+        if not self.enabled or nbytes < self.MIN_BYTES or torch.cuda.is_current_stream_capturing():
+            return None
+        self.tick += 1
+        ent = self.shapes.get(key, False)
+        if ent is None:
+            return None
+        if ent is False:
+            return self._calibrate(key, nbytes, alloc, launch)
+        ent["tick"] = self.tick
+        for _ms, sb in ent["slots"]:
+            if self._free(sb):
+                return sb, False
+        return None
+
+    def _calibrate(self, key, nbytes, alloc, launch):
+        dev = key[0]
+        free_b, _total = torch.cuda.mem_get_info(dev)
+        if free_b < (self.CANDIDATES + 2) * nbytes or self.KEEP * nbytes > self.MAX_POOL_BYTES:
+            self.shapes[key] = None                # no room for the candidates, or a shape the pool is not meant to hold
+            return None
+        while self.shapes and sum(e["bytes"] for e in self.shapes.values() if e) + self.KEEP * nbytes > self.MAX_POOL_BYTES:
+            live = [(e["tick"], k) for k, e in self.shapes.items() if e]
+            if not live:
+                break
+            del self.shapes[min(live)[1]]
+        cands = [alloc() for _ in range(self.CANDIDATES)]
+        for sb in cands:                           # first touch of every buffer
+            launch(sb)
+        evs = []
+        for _round in range(2):                    # two timed launches per buffer, interleaved over them; the smaller one counts
+            for sb in cands:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                launch(sb)
+                e1.record()
+                evs.append((e0, e1))
+        torch.cuda.synchronize(dev)                # once per shape and process: calibration, not the transform path
+        n = len(cands)
+        timed = sorted((min(evs[i][0].elapsed_time(evs[i][1]), evs[n + i][0].elapsed_time(evs[n + i][1])), i) for i in range(n))
+        slots = [(ms, cands[i]) for ms, i in timed[: self.KEEP]]
+        self.shapes[key] = {"slots": slots, "bytes": self.KEEP * nbytes, "tick": self.tick,
+                            "calibration_ms": [ms for ms, _ in timed]}
+        return slots[0][1], True
+
+    def report(self):
+        return [{"shape": [list(k[1]), list(k[2]) if k[2] else None], "calibration_ms": e["calibration_ms"],
+                 "kept_ms": [ms for ms, _ in e["slots"]]} for k, e in self.shapes.items() if e]
+
+
+_placed_outputs = _PlacedOutputs()
+
+
+def output_placement(enabled: bool = None, candidates: int = None, keep: int = None, min_bytes: int = None):
+    """Configure / query the placement-aware pool of large STFT outputs (see _PlacedOutputs).  Returns its report: per
+    calibrated shape the kernel times measured on the candidate buffer sets and on the ones that were kept.  Disabling
+    drops the pooled buffers."""
+    if enabled is not None:
+        _PlacedOutputs.enabled = bool(enabled)
+        if not enabled:
+            _placed_outputs.shapes.clear()
+    if candidates is not None:
+        _PlacedOutputs.CANDIDATES = max(int(candidates), 1)
+    if keep is not None:
+        _PlacedOutputs.KEEP = max(int(keep), 1)
+    if min_bytes is not None:
+        _PlacedOutputs.MIN_BYTES = int(min_bytes)
+    return _placed_outputs.report()
+
+
 def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *, pad: int = 0,
              right_pad: int = 0, padding_type: str = "reflect", match_stride: bool = False,
-             want_stft: bool = True, mel=None, frame_range=None):
+             want_stft: bool = True, mel=None, frame_range=None, out=None):
     """Fused STFT (+ mel).  ``audio`` (B, C, T) float32 HIP tensor.
+
+    ``out``: optional ``(stft_buf, mel_buf)`` -- caller-provided contiguous output buffers of the physical shapes
+    (B, C, N, F) complex64 and (B, C, N, n_mels) float32 (``mel_buf`` None without ``mel``) instead of fresh allocations.
 
     ``mel`` is ``None`` or a tuple ``(unit_info, unit_w, n_mels)`` of
     device tables from :func:`tables.mel_units`.
@@ -86,20 +190,45 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
     tw = tables.stft_twiddles(n_fft, dev)
     if not want_stft:
         raise NotImplementedError("the fused kernel always produces stft_data")
-    stft_buf = torch.empty((B, C, n_out, F), dtype=torch.complex64, device=dev)
-    mel_buf = None
     info = w = None
     n_units = n_mels = 0
     if mel is not None:
         info, w, n_mels = mel
         # fused sizes: unit tables (n_units rows of 2 ints); generic sizes: banded tables (n_units = number of 16-bin chunks)
         n_units = int(info.shape[0]) if stft_fused_supported(n_fft) else int(w.shape[0])
-        mel_buf = torch.empty((B, C, n_out, n_mels), dtype=torch.float32, device=dev)
-    code = _native.lib().at_stft_mel_f32(
-        _native.ptr(audio), B * C, T, _native.ptr(window), _native.ptr(tw), n_fft, hop, pad, right_pad,
-        PAD_MODES[padding_type], frame_lo, n_out, _native.ptr(stft_buf), _native.ptr(info), _native.ptr(w),
-        n_units, n_mels, _native.ptr(mel_buf), _native.current_stream(dev))
-    _native.check(code, "at_stft_mel_f32")
+    shape_s, shape_m = (B, C, n_out, F), ((B, C, n_out, n_mels) if mel is not None else None)
+
+    def alloc():
+        return torch.empty(shape_s, dtype=torch.complex64, device=dev)
+
+    def launch(sb, mb):
+        code = _native.lib().at_stft_mel_f32(
+            _native.ptr(audio), B * C, T, _native.ptr(window), _native.ptr(tw), n_fft, hop, pad, right_pad,
+            PAD_MODES[padding_type], frame_lo, n_out, _native.ptr(sb), _native.ptr(info), _native.ptr(w),
+            n_units, n_mels, _native.ptr(mb), _native.current_stream(dev))
+        _native.check(code, "at_stft_mel_f32")
+
+    launched = False
+    if out is not None:
+        stft_buf = out[0]
+        assert (stft_buf.shape == shape_s and stft_buf.dtype == torch.complex64 and stft_buf.is_contiguous()
+                and stft_buf.device == dev), "out[0]: contiguous complex64 (B, C, N, F) on the audio's device"
+        mel_buf = out[1] if mel is not None else None
+        if mel is not None:
+            assert (mel_buf.shape == shape_m and mel_buf.dtype == torch.float32 and mel_buf.is_contiguous()
+                    and mel_buf.device == dev), "out[1]: contiguous float32 (B, C, N, n_mels) on the audio's device"
+    else:
+        mel_buf = torch.empty(shape_m, dtype=torch.float32, device=dev) if shape_m else None
+        nbytes = B * C * n_out * F * 8
+        key = (dev, shape_s, shape_m, torch.cuda.current_stream(dev).cuda_stream)
+        # (every calibration launch writes the same mel values into the one mel buffer of this call)
+        got = _placed_outputs.acquire(key, nbytes, alloc, lambda sb: launch(sb, mel_buf)) if nbytes >= _PlacedOutputs.MIN_BYTES else None
+        if got is not None:
+            stft_buf, launched = got
+        else:
+            stft_buf = alloc()
+    if not launched:
+        launch(stft_buf, mel_buf)
     stft = stft_buf.transpose(2, 3) if stft_buf is not None else None
     mel_spec = mel_buf.transpose(2, 3) if mel_buf is not None else None
     return stft, mel_spec

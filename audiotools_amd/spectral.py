@@ -189,6 +189,21 @@ class SpectralMixin:
         X = X.reshape(self.batch_size, self.num_channels, X.shape[1], X.shape[2])
         return X[..., 2:-2] if match_stride else X
 
+    def _release_stft_data(self):
+        """Drop the spectrum a native stft() / mel_spectrogram() is about to replace (and any edit pending on it) and return
+        its shape.  The call WILL assign a new one; releasing the old tensor first lets its storage be reused for the new
+        result when nobody else holds it -- what the caching allocator does for a temporary, one call earlier."""
+        old = self._stft_data
+        self._pending_edit = None
+        self._stft_data = None
+        return None if old is None else tuple(old.shape)
+
+    @staticmethod
+    def _warn_if_shape_changed(old_shape, new):
+        if old_shape is not None and old_shape != tuple(new.shape):
+            import warnings
+            warnings.warn("stft_data changed shape")       # (audio_signal.py:942-943; the setter no longer sees the old tensor)
+
     def stft(self, window_length: int = None, hop_length: int = None, window_type: str = None,
              match_stride: bool = None, padding_type: str = None):
         """Short-time Fourier transform -> complex64 (B, C, F, N); also stored
@@ -199,8 +214,12 @@ class SpectralMixin:
         window = self.get_window(wtype, n_fft, str(audio.device))
         right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
         if kernels.is_native(audio) and kernels.stft_native_supported(n_fft):
+            # the spectrum this call replaces is released BEFORE the kernel runs: when nothing else references it, the
+            # placement-aware pool (kernels._PlacedOutputs) can hand its buffer -- the fastest one it knows -- out again
+            old_shape = self._release_stft_data()
             X, _ = kernels.stft_mel(audio, window, n_fft, hop, pad=pad, right_pad=right_pad,
                                     padding_type=padding_type, match_stride=match_stride)
+            self._warn_if_shape_changed(old_shape, X)
         elif _native_autograd_ok(audio, n_fft, hop, match_stride):
             X = _NativeStft.apply(audio, window, n_fft, hop)
         elif _native_autograd_general_ok(audio, window, n_fft, hop, pad, right_pad, padding_type):
@@ -290,9 +309,11 @@ class SpectralMixin:
             window = self.get_window(wtype, n_fft, str(dev))
             right_pad, pad = self.compute_stft_padding(n_fft, hop, match_stride)
             try:
+                old_shape = self._release_stft_data()        # (released before the kernel runs: see stft())
                 X, mel = kernels.stft_mel(audio, window, n_fft, hop, pad=pad, right_pad=right_pad,
                                           padding_type=padding_type, match_stride=match_stride,
                                           mel=(info, w, n_mels))
+                self._warn_if_shape_changed(old_shape, X)
                 self.stft_data = X
                 return mel
             except _native.NativeUnsupported:

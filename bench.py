@@ -433,6 +433,7 @@ def main():
         # the zero-compute floor of the dominant kernel's traffic on THIS box: its measurement twin (same grid, schedule,
         # addresses, load / store instructions and cache policy, no transform: at_stft_mel_floor_f32), timed the same way
         floor_ms = floor_iso_ms = floor_same_ms = None
+        placement = None
         try:
             if rank != 0:
                 raise StopIteration
@@ -478,6 +479,30 @@ def main():
                 oe[1].record()
                 torch.cuda.synchronize()
                 floor_same_ms = oe[0].elapsed_time(oe[1]) / args.steps
+            # Placement (profiles/r05_notes.md section 1; kernels._PlacedOutputs): the library times the real kernel into eight
+            # candidate output sets at the first call of a large shape and recycles the fastest three, so the kernel of record
+            # above ran on pooled buffers.  What the same binary does on a PLAIN allocation of this process -- the buffers
+            # torch.empty hands out, as every round before this one measured it -- is timed here next to it.
+            placement = None
+            try:
+                placement = {"pool": K.output_placement()}
+                for _ in range(3):
+                    K.stft_mel(x, win, n_fft, hop, mel=(units[0], units[1], N_MELS), out=(fl_stft, fl_mel))
+                pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                pe[0].record()
+                for _ in range(args.steps):
+                    K.stft_mel(x, win, n_fft, hop, mel=(units[0], units[1], N_MELS), out=(fl_stft, fl_mel))
+                pe[1].record()
+                torch.cuda.synchronize()
+                k_plain = pe[0].elapsed_time(pe[1]) / args.steps
+                placement.update({"kernel_ms_plain_allocation": k_plain,
+                                  "frac_plain_allocation": stft_bytes / (k_plain * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "twin_ms_plain_allocation": floor_ms,
+                                  "note": "pool: kernel times the library measured on its candidate output sets at the first "
+                                          "call and on the three it kept (kernels.output_placement()); *_plain_allocation: the same "
+                                          "kernel on a fresh torch.empty allocation of this process (the twin's fresh buffers)"})
+            except Exception as e:  # pragma: no cover
+                placement = {"error": f"{type(e).__name__}: {e}"}
             del fl_stft, fl_mel
         except StopIteration:
             pass
@@ -510,6 +535,7 @@ def main():
                            "frac_of_floor": (min(floor_ms, floor_iso_ms) / stft_ms) if floor_ms else None,
                            "floor_frac_of_peak": (stft_bytes / (min(floor_ms, floor_iso_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS)
                            if floor_ms else None,
+                           "placement": placement,
                            "floor_note": "floor_ms = the same launch with the transform removed (stft_mel_kernel_v2<.., FLOOR>: "
                                          "identical grid, runs, addresses, load/store instructions, nt policy), HIP events: K launches back to "
                                          "back (floor_ms) and one at a time on an idle device (floor_ms_one_at_a_time), both into FRESH buffers; frac_of_floor "

@@ -825,6 +825,85 @@ def test_mel_autograd_general_sizes():
         assert rel_err(g_got.double(), g_ref) < REL, (kw, rel_err(g_got.double(), g_ref))
 
 
+def test_stft_mel_into_caller_buffers():
+    """kernels.stft_mel(out=(stft_buf, mel_buf)): the same numbers into caller-provided buffers (fused and tiled sizes);
+    a buffer of the wrong shape is refused."""
+    from audiotools_amd import kernels, tables
+    x = synth.audio_batch(3, 2, 30000, seed=11, gaps=False).cuda()
+    for n_fft, hop, sr in ((2048, 512, 44100), (512, 128, 16000), (4096, 1024, 96000)):
+        win = tables.window("hann", n_fft, x.device)
+        mel = (tables.mel_units(sr, n_fft, 40, 0.0, None, x.device) + (40,)) if kernels.stft_fused_supported(n_fft) else \
+            (tables.mel_bands(sr, n_fft, 40, 0.0, None, x.device) + (40,))
+        X0, M0 = kernels.stft_mel(x, win, n_fft, hop, mel=mel)
+        N, F = X0.shape[-1], X0.shape[-2]
+        sb = torch.full((3, 2, N, F), float("nan"), dtype=torch.complex64, device="cuda")
+        mb = torch.full((3, 2, N, 40), float("nan"), device="cuda")
+        X1, M1 = kernels.stft_mel(x, win, n_fft, hop, mel=mel, out=(sb, mb))
+        assert X1.data_ptr() == sb.data_ptr() and M1.data_ptr() == mb.data_ptr()
+        assert torch.equal(X0, X1) and torch.equal(M0, M1)
+        with pytest.raises(AssertionError):
+            kernels.stft_mel(x, win, n_fft, hop, mel=mel, out=(sb[:, :, :-1], mb))
+
+
+def test_placement_aware_output_pool_semantics():
+    """kernels._PlacedOutputs (round 5): large STFT outputs come from a small pool of buffer sets chosen by timing the real
+    kernel at the first call of a shape.  The semantics stay those of a fresh allocation: a result is never overwritten while
+    ANY tensor references its storage (views, stft_data of a signal, saved autograd tensors), a released buffer is reused,
+    more simultaneous results than the pool holds fall back to plain allocations, and the numbers do not depend on the pool."""
+    from audiotools_amd import kernels, tables
+    rep0 = kernels.output_placement(enabled=True, min_bytes=1 << 20)          # a small threshold so that a test-sized batch takes the pool
+    try:
+        x = synth.audio_batch(8, 2, 88200, seed=21, gaps=False).cuda()
+        win = tables.window("hann", 2048, x.device)
+        mel = tables.mel_units(44100, 2048, 80, 0.0, None, x.device) + (80,)
+        kernels.output_placement(enabled=False)
+        Xref, Mref = kernels.stft_mel(x, win, 2048, 512, mel=mel)
+        kernels.output_placement(enabled=True)
+        X1, M1 = kernels.stft_mel(x, win, 2048, 512, mel=mel)                  # calibration: CANDIDATES sets timed, KEEP kept
+        rep = kernels.output_placement()
+        assert len(rep) == 1 and len(rep[0]["calibration_ms"]) == kernels._PlacedOutputs.CANDIDATES and len(rep[0]["kept_ms"]) == 3
+        assert rep[0]["kept_ms"] == sorted(rep[0]["calibration_ms"])[:3]
+        assert torch.equal(X1, Xref) and torch.equal(M1, Mref)
+        held = [(X1, M1)]
+        ptrs = {X1.data_ptr()}
+        for _ in range(4):                                                     # five results alive at once: three pooled, two plain
+            X, M = kernels.stft_mel(x * 0.5, win, 2048, 512, mel=mel)
+            assert X.data_ptr() not in ptrs
+            ptrs.add(X.data_ptr())
+            held.append((X, M))
+        assert torch.equal(held[0][0], Xref) and torch.equal(held[0][1], Mref)  # the first result is untouched
+        assert torch.equal(held[1][0], held[4][0])
+        p_first = held[0][0].data_ptr()
+        view_only = torch.view_as_real(held[0][0])                             # a VIEW keeps the storage alive ...
+        del held[0]
+        del X1, M1
+        Xn, _ = kernels.stft_mel(x * 0.25, win, 2048, 512, mel=mel)
+        assert Xn.data_ptr() != p_first and torch.equal(torch.view_as_complex(view_only), Xref)
+        del view_only, Xn                                                      # ... and once it is gone the pooled set is handed out again
+        pooled = {kernels.stft_mel(x, win, 2048, 512, mel=mel)[0].data_ptr() for _ in range(3)}
+        assert len(pooled) == 1                                                # released at once, reused at once: one (the fastest free) set
+        # a signal keeps its stft_data: two results alternate, both from the pool, neither overwritten while it is stft_data
+        sig = A.AudioSignal(x, 44100)
+        m_a = sig.mel_spectrogram(80).clone()
+        s_a = sig.stft_data
+        m_b = sig.mel_spectrogram(80)
+        assert sig.stft_data.data_ptr() != s_a.data_ptr() and torch.equal(s_a, Xref) and torch.equal(m_a, m_b)
+        # ... and a signal nobody else looks into gets the SAME (fastest free) spectrum buffer call after call: stft() /
+        # mel_spectrogram() release the spectrum they are about to replace before the kernel runs
+        del s_a, m_b
+        sig2 = A.AudioSignal(x, 44100)
+        sig2.mel_spectrogram(80)
+        p2 = sig2.stft_data.data_ptr()
+        for _ in range(3):
+            m2 = sig2.mel_spectrogram(80)
+            assert sig2.stft_data.data_ptr() == p2 and torch.equal(sig2.stft_data, Xref) and torch.equal(m2, Mref)
+        with pytest.warns(UserWarning, match="stft_data changed shape"):       # the reference's warning survives the early release
+            sig2.stft(512, 128)
+    finally:
+        kernels.output_placement(enabled=True, min_bytes=256 << 20)
+        kernels._placed_outputs.shapes.clear()
+
+
 def test_c_abi_error_codes_and_degenerate_inputs():
     """The C ABI never throws: 0 = ok, -1 = bad argument, -2 = no kernel for the request; empty
     batches are no-ops; the Python layer turns codes into NativeError / the reference's errors."""
