@@ -98,7 +98,11 @@ class _PlacedOutputs:
         if ent is None:
             return None
         if ent is False:
-            return self._calibrate(key, nbytes, alloc, launch)
+            try:
+                return self._calibrate(key, nbytes, alloc, launch)
+            except torch.cuda.OutOfMemoryError:        # somebody else took the memory between the check and the allocations
+                self.shapes[key] = None
+                return None
         ent["tick"] = self.tick
         for _ms, sb in ent["slots"]:
             if self._free(sb):
@@ -136,8 +140,8 @@ class _PlacedOutputs:
         return slots[0][1], True
 
     def report(self):
-        return [{"shape": [list(k[1]), list(k[2]) if k[2] else None], "calibration_ms": e["calibration_ms"],
-                 "kept_ms": [ms for ms, _ in e["slots"]]} for k, e in self.shapes.items() if e]
+        return [{"shape": list(k[1]), "calibration_ms": e["calibration_ms"], "kept_ms": [ms for ms, _ in e["slots"]]}
+                for k, e in self.shapes.items() if e]
 
 
 _placed_outputs = _PlacedOutputs()
@@ -220,7 +224,7 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
     else:
         mel_buf = torch.empty(shape_m, dtype=torch.float32, device=dev) if shape_m else None
         nbytes = B * C * n_out * F * 8
-        key = (dev, shape_s, shape_m, torch.cuda.current_stream(dev).cuda_stream)
+        key = (dev, shape_s, torch.cuda.current_stream(dev).cuda_stream)      # (with or without the mel stage: one pool per spectrum shape)
         # (every calibration launch writes the same mel values into the one mel buffer of this call)
         got = _placed_outputs.acquire(key, nbytes, alloc, lambda sb: launch(sb, mel_buf)) if nbytes >= _PlacedOutputs.MIN_BYTES else None
         if got is not None:
