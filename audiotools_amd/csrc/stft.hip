@@ -40,6 +40,9 @@
 #ifndef AT_STFT_WPS
 #define AT_STFT_WPS 2           // resident waves per SIMD the register budget allows
 #endif
+#ifndef AT_STFT_WPS_SMALL
+#define AT_STFT_WPS_SMALL 2     // the same for n_fft <= 512 (their 152-164 registers would allow 3)
+#endif
 #ifndef AT_STFT_PIPE
 #define AT_STFT_PIPE 1           // A/B build: 0 = the groups of the n_fft <= 1024 kernels load behind their predecessor's stores
 #endif
@@ -109,7 +112,7 @@ template <int M>
 __host__ __device__ constexpr int lds_fixed_floats(int nw) { return nw * 2 * WAVE_LDS_SLOTS + 2 * M + M + 16 * 36; }
 
 template <int M, int NW, bool VEC2, int NR /* mel rounds of 64 units; 0 = no mel */>
-__global__ __launch_bounds__(NW * 64, AT_STFT_WPS) void stft_mel_kernel(const StftArgs A) {
+__global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WPS)) void stft_mel_kernel(const StftArgs A) {
   constexpr bool MEL = NR > 0;
   using P = Plan<M>;
   constexpr int L = P::L, FW = P::FW, N = 2 * M;
@@ -1035,7 +1038,8 @@ int launch_mw(const StftArgs& A, int n_cu, hipStream_t stream) {
   // persistent grid: as many blocks as are co-resident (LDS-limited; the kernel needs ~200 VGPRs,
   // i.e. 2 waves/SIMD = 8 waves/CU), times #CUs
   int per_cu = (int)((160 * 1024) / bytes);
-  const int by_waves = (4 * AT_STFT_WPS) / NW > 0 ? (4 * AT_STFT_WPS) / NW : 1;
+  constexpr int WPS = M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WPS;
+  const int by_waves = (4 * WPS) / NW > 0 ? (4 * WPS) / NW : 1;
   if (per_cu > by_waves) per_cu = by_waves;
   if (per_cu < 1) per_cu = 1;
   const int max_blocks = n_cu * per_cu;

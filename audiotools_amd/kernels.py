@@ -140,8 +140,8 @@ class _PlacedOutputs:
         return slots[0][1], True
 
     def report(self):
-        return [{"shape": list(k[1]), "calibration_ms": e["calibration_ms"], "kept_ms": [ms for ms, _ in e["slots"]]}
-                for k, e in self.shapes.items() if e]
+        return [{"op": k[3] if len(k) > 3 else "stft", "shape": list(k[1]), "calibration_ms": e["calibration_ms"],
+                 "kept_ms": [ms for ms, _ in e["slots"]]} for k, e in self.shapes.items() if e]
 
 
 _placed_outputs = _PlacedOutputs()
@@ -341,20 +341,40 @@ def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, l
     need = int(lib.at_istft_workspace_bytes(B * C, n_frames, n_fft, hop))
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     tw = tables.stft_twiddles(n_fft, dev)
-    out = torch.empty((B, C, length), dtype=torch.float32, device=dev)
-    if edit is not None:
-        code = lib.at_istft_edit_f32(_native.ptr(torch.view_as_real(X)), B * C, N, _native.ptr(window), _native.ptr(tw), n_fft, hop,
-                                     lead, n_frames, length, _native.ptr(out), _native.ptr(ws), need, int(edit["kind"]), C,
-                                     _native.ptr(edit.get("lo")), _native.ptr(edit.get("hi")), _native.ptr(edit.get("shift")),
-                                     _native.ptr(edit.get("cut")), _native.ptr(edit.get("maxpow")),
-                                     float(edit.get("fill_re", 0.0)), float(edit.get("fill_im", 0.0)),
-                                     float(edit.get("top_db", 0.0)), int(edit.get("use_top", 0)), float(edit.get("val", 0.0)),
-                                     _native.current_stream(dev))
-        _native.check(code, "at_istft_edit_f32")
-        return out
-    code = lib.at_istft_f32(_native.ptr(torch.view_as_real(X)), B * C, N, _native.ptr(window), _native.ptr(tw), n_fft, hop,
-                            lead, n_frames, length, _native.ptr(out), _native.ptr(ws), need, _native.current_stream(dev))
-    _native.check(code, "at_istft_f32")
+    Xr = torch.view_as_real(X)
+
+    def alloc():
+        return torch.empty((B, C, length), dtype=torch.float32, device=dev)
+
+    def launch(out):
+        if edit is not None:
+            code = lib.at_istft_edit_f32(_native.ptr(Xr), B * C, N, _native.ptr(window), _native.ptr(tw), n_fft, hop,
+                                         lead, n_frames, length, _native.ptr(out), _native.ptr(ws), need, int(edit["kind"]), C,
+                                         _native.ptr(edit.get("lo")), _native.ptr(edit.get("hi")), _native.ptr(edit.get("shift")),
+                                         _native.ptr(edit.get("cut")), _native.ptr(edit.get("maxpow")),
+                                         float(edit.get("fill_re", 0.0)), float(edit.get("fill_im", 0.0)),
+                                         float(edit.get("top_db", 0.0)), int(edit.get("use_top", 0)), float(edit.get("val", 0.0)),
+                                         _native.current_stream(dev))
+            _native.check(code, "at_istft_edit_f32")
+        else:
+            code = lib.at_istft_f32(_native.ptr(Xr), B * C, N, _native.ptr(window), _native.ptr(tw), n_fft, hop,
+                                    lead, n_frames, length, _native.ptr(out), _native.ptr(ws), need, _native.current_stream(dev))
+            _native.check(code, "at_istft_f32")
+
+    # the inverse follows the placement of its SIGNAL buffer (11 % between allocations at B = 512, tools/placement_survey.py):
+    # the same pool as the forward transform's spectrum, fresh-allocation semantics (_PlacedOutputs)
+    nbytes = B * C * length * 4
+    got = None
+    if nbytes >= _PlacedOutputs.MIN_BYTES:
+        key = (dev, (B, C, length), torch.cuda.current_stream(dev).cuda_stream, "istft", n_fft, hop, N)
+        got = _placed_outputs.acquire(key, nbytes, alloc, launch)
+    if got is not None:
+        out, launched = got
+        out = out.detach()        # the caller's own tensor object on the pooled storage: the pool tells by the storage's use count
+    else:                         # whether a result is still held (the forward transform hands out a transposed view for the same reason)
+        out, launched = alloc(), False
+    if not launched:
+        launch(out)
     return out
 
 

@@ -899,6 +899,21 @@ def test_placement_aware_output_pool_semantics():
             assert sig2.stft_data.data_ptr() == p2 and torch.equal(sig2.stft_data, Xref) and torch.equal(m2, Mref)
         with pytest.warns(UserWarning, match="stft_data changed shape"):       # the reference's warning survives the early release
             sig2.stft(512, 128)
+        # the inverse takes its signal buffer from the same pool (its own key): same numbers, nothing overwritten while held
+        kernels._placed_outputs.shapes.clear()
+        kernels.output_placement(enabled=False)
+        y_ref = kernels.istft(Xref, win, 2048, 512, x.shape[-1])
+        kernels.output_placement(enabled=True)
+        y1 = kernels.istft(Xref, win, 2048, 512, x.shape[-1])
+        rep = kernels.output_placement()
+        assert [r["op"] for r in rep] == ["istft"] and len(rep[0]["calibration_ms"]) == kernels._PlacedOutputs.CANDIDATES
+        y2 = kernels.istft(Xref * 0.5, win, 2048, 512, x.shape[-1])
+        assert y2.data_ptr() != y1.data_ptr()
+        assert torch.equal(y1, y_ref), float((y1 - y_ref).abs().max())
+        assert torch.allclose(y2, 0.5 * y_ref, atol=1e-6), float((y2 - 0.5 * y_ref).abs().max())
+        p1 = y1.data_ptr()
+        del y1
+        assert kernels.istft(Xref, win, 2048, 512, x.shape[-1]).data_ptr() == p1
     finally:
         kernels.output_placement(enabled=True, min_bytes=256 << 20)
         kernels._placed_outputs.shapes.clear()

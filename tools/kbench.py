@@ -70,3 +70,5 @@ for what in args.what.split(","):
         timeit(lambda: y.fill_(1.0), y.numel() * 4, "fill")
         z = torch.empty_like(x)
         timeit(lambda: z.copy_(x), 2 * x.numel() * 4, "copy")
+for r in kernels.output_placement():       # the placement pool's calibrations (kernel ms per candidate buffer)
+    print("pool", r["op"], r["shape"], " ".join(f"{t:.3f}" for t in r["calibration_ms"]))
