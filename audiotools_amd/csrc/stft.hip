@@ -43,6 +43,15 @@
 #ifndef AT_STFT_WPS_SMALL
 #define AT_STFT_WPS_SMALL 2     // the same for n_fft <= 512 (their 152-164 registers would allow 3)
 #endif
+#ifndef AT_STFT_RUNSTORE
+#define AT_STFT_RUNSTORE 1      // 0 = A/B build: the several-frames-per-wave kernels store FW segments per instruction instead of 512-byte runs from the slab
+#endif
+#ifndef AT_STFT_MELREG
+#define AT_STFT_MELREG 1        // 0 = A/B build: unit descriptors (and two rounds' weights) of the several-frames-per-wave kernels re-read from LDS per frame
+#endif
+#ifndef AT_STFT_MELUNROLL
+#define AT_STFT_MELUNROLL 1     // A/B build: unroll factor of the per-frame mel loop of those kernels (2: within 1 %)
+#endif
 #ifndef AT_STFT_PIPE
 #define AT_STFT_PIPE 1           // A/B build: 0 = the groups of the n_fft <= 1024 kernels load behind their predecessor's stores
 #endif
@@ -111,6 +120,16 @@ constexpr int MELW_ROW = 20;  // floats per padded LDS row of 16 unit weights
 template <int M>
 __host__ __device__ constexpr int lds_fixed_floats(int nw) { return nw * 2 * WAVE_LDS_SLOTS + 2 * M + M + 16 * 36; }
 
+// 512-byte-run stores (AT_STFT_RUNSTORE): every size with several frames per wave; with the mel stage only where the extra
+// magnitude region (NW x FW x (M/16 + 1) x MAG_ROW floats, 21-25 KB) still leaves two workgroups per CU: n_fft 128 ... 512
+// with two rounds of units (80 mel bands: 73-75 KB per workgroup).  n_fft 1024 with mel measured no gain (s24).
+template <int M, int NR>
+__host__ __device__ constexpr bool runstore_for() { return AT_STFT_RUNSTORE && M <= 512 && (NR == 0 || (NR == 2 && M >= 64 && M <= 256)); }
+template <int M, int NR>
+__host__ __device__ constexpr int runstore_mag_floats(int nw) {
+  return (runstore_for<M, NR>() && NR > 0) ? nw * (64 / (M / 16)) * (M / 16 + 1) * MAG_ROW : 0;
+}
+
 template <int M, int NW, bool VEC2, int NR /* mel rounds of 64 units; 0 = no mel */>
 __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WPS)) void stft_mel_kernel(const StftArgs A) {
   constexpr bool MEL = NR > 0;
@@ -130,6 +149,7 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
   float* s_tw2 = s_win + N + M;
   float* s_melw = s_tw2 + 16 * 36;
   int2* s_uinfo = reinterpret_cast<int2*>(s_melw + A.n_units * MELW_ROW);
+  [[maybe_unused]] float* s_mag = reinterpret_cast<float*>(s_uinfo + A.n_units);   // RUNSTORE with mel: NW x FW x MAG_ROWS x MAG_ROW
 
   // ---- block-shared tables -> LDS (once per persistent block)
   // the window is stored HALVED: the factor 1/2 of the split step (X = (Z + conj Z')/2 ...) is exact
@@ -174,6 +194,24 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
       tw3b[b] = A.tw[(j % NS) * (N / (NS * P::R3))];
     }
   }
+  // Several frames per wave: the mel stage runs FW times per group with the same units in every lane -- their descriptors
+  // (and, for two rounds, their sixteen weights each) stay in registers instead of being re-read from LDS per frame.
+  constexpr bool MELDESC = MEL && FW > 1 && AT_STFT_MELREG;
+  constexpr bool MELREG = MELDESC && NR <= 2 && M <= 256;    // (n_fft 1024: 24 bytes of scratch per lane with them)
+  [[maybe_unused]] int mu_off[MELDESC ? NR : 1], mu_fl[MELDESC ? NR : 1];
+  [[maybe_unused]] float4 mu_w[MELREG ? NR : 1][4];
+  if constexpr (MELDESC) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int2 ui = s_uinfo[r * 64 + lane];
+      mu_off[r] = ui.x;
+      mu_fl[r] = ui.y;
+      if constexpr (MELREG) {
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) mu_w[r][i4] = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW)[i4];
+      }
+    }
+  }
   const int Ti = (int)A.T;
   const int n_out = (int)A.n_out;
   const int gpr = A.groups_per_row;
@@ -209,6 +247,7 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
   // other waves stretches the load latency, profiles/r04_notes.md 12) and therefore ahead of this group's stores
   // (vmcnt retires in order: the samples are waited for with the stores still in flight).
   constexpr bool PIPE = FW > 1 && AT_STFT_PIPE;
+  constexpr bool RUNSTORE = runstore_for<M, NR>();
   float2 nxt16[PIPE ? 16 : 1];
 
   // ---- one frame group: window, FFT, split, stores (+ mel).  `a` holds the raw samples.
@@ -314,7 +353,68 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
     }
 
     // |X| of frame slot fs: rows of 16 bins padded to MAG_ROW floats
-    float* magbuf = reinterpret_cast<float*>(wbuf) + fs * (MAG_ROWS * MAG_ROW);
+    float* magbase = (RUNSTORE && MEL) ? s_mag + wave * (FW * MAG_ROWS * MAG_ROW) : reinterpret_cast<float*>(wbuf);
+    float* magbuf = magbase + fs * (MAG_ROWS * MAG_ROW);
+    if constexpr (RUNSTORE) {
+      // Several frames per wave: the FW frames of the group are consecutive rows of the output, (M + 1) FW contiguous float2.
+      // Every lane drops its bins into the wave's slab (frame slot fs at the FFT's own stride 17 L: conflict-free), then the
+      // wave streams the slab out as 512-byte runs -- 17 store instructions whose 64 lanes write consecutive addresses,
+      // instead of 17 instructions of FW segments of 8 L bytes each (n_fft 512: 0.90 -> 0.78 ms, 256: 0.52 -> 0.42, 128:
+      // 0.60 -> 0.42, 1024: 1.14 -> 1.10; profiles/r05_notes.md 8).  With the mel stage the magnitudes go to a region of
+      // their own (the slab is busy with X).
+      float2* sx = wbuf + fs * P::SLOTS;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = t + L * q;
+        float2 xa, xb;
+        if (q == 0 && t == 0) {   // k == 0: DC and Nyquist (Z is computed from the halved window)
+          xa = make_float2(2.f * (zk[0].x + zk[0].y), 0.f);
+          xb = make_float2(2.f * (zk[0].x - zk[0].y), 0.f);
+        } else {
+          const float2 twp = s_twp[k];
+          const float sr = zk[q].x + zm[q].x, si = zk[q].y - zm[q].y;
+          const float dr = zk[q].x - zm[q].x, di = zk[q].y + zm[q].y;
+          const float c = twp.x, s = -twp.y;
+          const float pp = fmaf(s, dr, -c * di);
+          const float qq = fmaf(s, di, c * dr);
+          xa = make_float2(sr - pp, si - qq);
+          xb = make_float2(sr + pp, -si - qq);
+        }
+        sx[k] = xa;
+        sx[M - k] = xb;
+        if constexpr (MEL) {
+          magbuf[k + 4 * (k >> 4)] = cabs_fast(xa);
+          magbuf[(M - k) + 4 * ((M - k) >> 4)] = cabs_fast(xb);
+        }
+      }
+      if (t == 0) {
+        const float2 xh = make_float2(2.f * zh.x, -2.f * zh.y);
+        sx[M / 2] = xh;
+        if constexpr (MEL) magbuf[M / 2 + 4 * ((M / 2) >> 4)] = cabs_fast(xh);
+      }
+      wave_sync();
+      constexpr int TOT = FW * (M + 1);
+      constexpr int NST = (TOT + 63) / 64;
+      const int f0 = gb * FW;
+      float2* __restrict__ obase = A.out + ((int64_t)row * n_out + f0) * (M + 1);
+      if (f0 + FW <= n_out) {               // wave-uniform: every slot a frame of its own -> unconditional stores
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+          const int idx = min(i * 64 + lane, TOT - 1);      // (only the last instruction clamps: duplicates of the last bin)
+          const int f = idx / (M + 1);
+          obase[idx] = wbuf[f * P::SLOTS + (idx - f * (M + 1))];
+        }
+      } else {                              // last group of a row: only the frames that exist
+        const int tot = (n_out - f0) * (M + 1);
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+          const int idx = i * 64 + lane;
+          const int f = idx / (M + 1);
+          if (idx < tot) obase[idx] = wbuf[f * P::SLOTS + (idx - f * (M + 1))];
+        }
+      }
+      if constexpr (!MEL) wave_sync();      // every read of the slab is done (the mel stage below ends with the same)
+    } else {
     // Lane t computes the pair X[k], X[M-k] for k = t + L q.  X[k] is stored directly
     // (addresses ascend with the lane).  The partner X[M-k] DEscends with the lane, and a
     // store instruction whose lanes write descending addresses is ~10 % slower on this memory
@@ -355,6 +455,7 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
       if (STORE_OK(xh.x)) orow[M / 2] = xh;
       if constexpr (MEL) magbuf[M / 2 + 4 * ((M / 2) >> 4)] = cabs_fast(xh);
     }
+    }
     if constexpr (MEL) {
       // The last row holds only the Nyquist bin; a unit on it multiplies its other 15 columns by
       // zero weights, and those columns alias FFT-slab slots that may never have been written
@@ -364,11 +465,11 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
 
     if constexpr (MEL) {
       wave_sync();
-#pragma unroll 1
+#pragma unroll AT_STFT_MELUNROLL
       for (int fsl = 0; fsl < FW; ++fsl) {
         const int fo2 = gb * FW + fsl;
         if (fo2 >= n_out) break;  // wave-uniform
-        const float* mg = reinterpret_cast<float*>(wbuf) + fsl * (MAG_ROWS * MAG_ROW);
+        const float* mg = magbase + fsl * (MAG_ROWS * MAG_ROW);
         float* mrow = A.mel + ((int64_t)row * n_out + fo2) * A.n_mels;
         // two rounds at a time: enough independent work to cover the LDS latency, while the
         // scheduling barrier keeps the other rounds' 32 loaded registers each from piling up
@@ -379,14 +480,22 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int r = r0 + j;
-            const int2 ui = s_uinfo[r * 64 + lane];
-            u_fl[j] = ui.y;
-            const float4* mq = reinterpret_cast<const float4*>(mg + ui.x);
+            int u_off;
+            if constexpr (MELDESC) {
+              u_off = mu_off[r];
+              u_fl[j] = mu_fl[r];
+            } else {
+              const int2 ui = s_uinfo[r * 64 + lane];
+              u_off = ui.x;
+              u_fl[j] = ui.y;
+            }
+            const float4* mq = reinterpret_cast<const float4*>(mg + u_off);
             const float4* wq = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW);
             float v = 0.f;
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
-              const float4 w = wq[i4];
+              float4 w;
+              if constexpr (MELREG) w = mu_w[r][i4]; else w = wq[i4];
               const float4 m = mq[i4];
               v = fmaf(w.x, m.x, v);
               v = fmaf(w.y, m.y, v);
@@ -1024,15 +1133,16 @@ int launch_one(const StftArgs& A, size_t lds_bytes, int max_blocks, hipStream_t 
   // run of 16 a small batch (54 frame groups per wave at B=64) leaves some waves with 4 runs and
   // others with 3 -- the launch then lasts 64/54 of its balanced time.
   StftArgs B = A;
-  B.run = balanced_run(A.total_groups, blocks, NW);
+  // (n_fft 1024: runs of 64 groups measured 2 % faster than 16 in two rounds, the smaller sizes alike or slower: s23)
+  B.run = balanced_run(A.total_groups, blocks, NW, M >= 512 ? 4 * AT_STFT_RUN : AT_STFT_RUN);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, stream, B);
   AT_LAUNCH_CHECK();
   return AT_OK;
 }
 
-template <int M, int NW, bool VEC2>
-int launch_mw(const StftArgs& A, int n_cu, hipStream_t stream) {
-  size_t fl = lds_fixed_floats<M>(NW) + (size_t)A.n_units * (MELW_ROW + 2);
+template <int M, int NW, bool VEC2, int NR>
+int launch_nr(const StftArgs& A, int n_cu, hipStream_t stream) {
+  size_t fl = lds_fixed_floats<M>(NW) + (size_t)A.n_units * (MELW_ROW + 2) + runstore_mag_floats<M, NR>(NW);
   const size_t bytes = fl * 4;
   if (bytes > 160 * 1024) return AT_ERR_UNSUPPORTED;
   // persistent grid: as many blocks as are co-resident (LDS-limited; the kernel needs ~200 VGPRs,
@@ -1042,12 +1152,16 @@ int launch_mw(const StftArgs& A, int n_cu, hipStream_t stream) {
   const int by_waves = (4 * WPS) / NW > 0 ? (4 * WPS) / NW : 1;
   if (per_cu > by_waves) per_cu = by_waves;
   if (per_cu < 1) per_cu = 1;
-  const int max_blocks = n_cu * per_cu;
+  return launch_one<M, NW, VEC2, NR>(A, bytes, n_cu * per_cu, stream);
+}
+
+template <int M, int NW, bool VEC2>
+int launch_mw(const StftArgs& A, int n_cu, hipStream_t stream) {
   switch (A.n_units / 64) {
-    case 0: return launch_one<M, NW, VEC2, 0>(A, bytes, max_blocks, stream);
-    case 2: return launch_one<M, NW, VEC2, 2>(A, bytes, max_blocks, stream);
-    case 4: return launch_one<M, NW, VEC2, 4>(A, bytes, max_blocks, stream);
-    case 6: return launch_one<M, NW, VEC2, 6>(A, bytes, max_blocks, stream);
+    case 0: return launch_nr<M, NW, VEC2, 0>(A, n_cu, stream);
+    case 2: return launch_nr<M, NW, VEC2, 2>(A, n_cu, stream);
+    case 4: return launch_nr<M, NW, VEC2, 4>(A, n_cu, stream);
+    case 6: return launch_nr<M, NW, VEC2, 6>(A, n_cu, stream);
   }
   return AT_ERR_UNSUPPORTED;
 }

@@ -67,6 +67,43 @@ def test_stft_vs_oracle(n_fft, hop, wt):
     assert rel_err(X, ref) < REL
 
 
+@pytest.mark.parametrize("n_fft", [32, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("with_mel", [False, True])
+def test_stft_run_stores_ragged_groups(n_fft, with_mel):
+    """The wave kernels with several frames per wave (n_fft <= 1024) write a group of FW = 2048 / n_fft consecutive frames as
+    one stream of 512-byte runs out of LDS (round 5).  Frame counts around the group size -- 1, FW - 1, FW, FW + 1, several
+    groups + a ragged tail -- against torch.stft in float64, for three rows, with guard bands in front of and behind the
+    caller-provided output buffers: a group must never write past the frames that exist."""
+    from audiotools_amd import kernels, tables
+    if with_mel and n_fft == 32:
+        pytest.skip("the fused mel stage needs at least one 16-bin row per band group: n_fft >= 64")
+    FW = 2048 // n_fft
+    hop = n_fft // 4
+    sr, n_mels = 16000, {32: 5, 64: 10, 128: 20, 256: 40, 512: 80, 1024: 80}[n_fft]
+    dev = torch.device("cuda")
+    win = tables.window("hann", n_fft, dev)
+    mel = (tables.mel_units(sr, n_fft, n_mels, 0.0, None, dev) + (n_mels,)) if with_mel else None
+    for n_frames in sorted({1, 2, max(FW - 1, 1), FW, FW + 1, 3 * FW + max(FW - 1, 1), 5 * FW}):
+        T = max((n_frames - 1) * hop + (1 if n_frames > 1 else 0), n_fft // 2 + 1)       # 1 + T // hop frames; reflect padding needs T > n_fft / 2
+        N = 1 + T // hop
+        x = synth.audio_batch(3, 1, T, seed=n_fft + n_frames, gaps=False)
+        F = n_fft // 2 + 1
+        G = 1000
+        big = torch.full((G + 3 * N * F + G,), 7.0 + 3.0j, dtype=torch.complex64, device=dev)
+        sb = big[G:G + 3 * N * F].view(3, 1, N, F)
+        bigm = torch.full((G + 3 * N * n_mels + G,), -5.0, device=dev)
+        mb = bigm[G:G + 3 * N * n_mels].view(3, 1, N, n_mels) if with_mel else None
+        X, Mm = kernels.stft_mel(x.to(dev), win, n_fft, hop, mel=mel, out=(sb, mb))
+        ref = restate.stft(x.double(), n_fft, hop, "hann")
+        assert X.shape == ref.shape, (n_frames, X.shape, ref.shape)
+        assert rel_err(X, ref) < REL, (n_fft, n_frames)
+        assert bool((big[:G] == 7.0 + 3.0j).all()) and bool((big[-G:] == 7.0 + 3.0j).all()), (n_fft, n_frames, "spectrum guard")
+        if with_mel:
+            refm = restate.mel_spectrogram(ref.to(torch.complex64), sr, n_mels)
+            assert rel_err(Mm, refm) < REL, (n_fft, n_frames)
+            assert bool((bigm[:G] == -5.0).all()) and bool((bigm[-G:] == -5.0).all()), (n_fft, n_frames, "mel guard")
+
+
 @pytest.mark.parametrize("T", [16000, 16001, 15999, 4098])
 def test_stft_odd_lengths_and_alignment(T):
     x = synth.audio_batch(2, 3, T, seed=T, gaps=False)
