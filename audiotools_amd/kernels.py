@@ -71,8 +71,9 @@ def stft_fused_supported(n_fft: int) -> bool:
 # buffer is handed out again only when no tensor of the caller references its storage any more (the C++ storage use
 # count), otherwise the call falls back to torch.empty.
 class _PlacedOutputs:
-    CANDIDATES = 8              # buffer sets timed at calibration (about two in five allocations are fast: with eight, at least
-                                # two fast ones turn up in ~90 % of the processes, with five in ~65 %)
+    CANDIDATES = 12             # buffers timed at calibration (fewer when the free memory does not hold them).  The times of one
+                                # process spread over about 12 %; the fastest of eight was 1.864-1.940 ms in nine processes
+                                # (profiles/r05_notes.md 5): four more draws for ~30 ms more calibration, once per shape
     KEEP = 3                    # ... of which this many stay in the pool (mel_spectrogram alternates two while stft_data holds one)
     MIN_BYTES = 256 << 20       # outputs below this size are not worth it
     MAX_POOL_BYTES = 48 << 30   # all shapes together; the least recently used shape is dropped beyond it
@@ -112,15 +113,16 @@ class _PlacedOutputs:
     def _calibrate(self, key, nbytes, alloc, launch):
         dev = key[0]
         free_b, _total = torch.cuda.mem_get_info(dev)
-        if free_b < (self.CANDIDATES + 2) * nbytes or self.KEEP * nbytes > self.MAX_POOL_BYTES:
-            self.shapes[key] = None                # no room for the candidates, or a shape the pool is not meant to hold
+        n_cand = min(self.CANDIDATES, int(free_b // nbytes) - 2)       # as many candidates as fit next to two more results
+        if n_cand < 2 or self.KEEP * nbytes > self.MAX_POOL_BYTES:
+            self.shapes[key] = None                # no room for candidates, or a shape the pool is not meant to hold
             return None
         while self.shapes and sum(e["bytes"] for e in self.shapes.values() if e) + self.KEEP * nbytes > self.MAX_POOL_BYTES:
             live = [(e["tick"], k) for k, e in self.shapes.items() if e]
             if not live:
                 break
             del self.shapes[min(live)[1]]
-        cands = [alloc() for _ in range(self.CANDIDATES)]
+        cands = [alloc() for _ in range(n_cand)]
         for sb in cands:                           # first touch of every buffer
             launch(sb)
         evs = []
