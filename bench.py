@@ -302,6 +302,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the north-star step from a captured HIP graph instead of eager launches")
+    ap.add_argument("--no-probes", action="store_true",
+                    help="skip the floor twin and the plain-allocation probe behind the timed region (the --stats pass of "
+                         "tools/profile_round.sh: its per-kernel average should hold the timed launches, not the probes')")
     ap.add_argument("--no-share", action="store_true",
                     help="skip the share_64 block (the 8-GPU share timed on this device): profile runs use it so that the "
                          "per-kernel averages of rocprofv3 only see launches of the benchmark's own size")
@@ -443,7 +446,7 @@ def main():
         floor_ms = floor_iso_ms = floor_same_ms = None
         placement = None
         try:
-            if rank != 0:
+            if rank != 0 or args.no_probes:
                 raise StopIteration
             from audiotools_amd import kernels as K, tables as TB
             win = TB.window("hann", n_fft, device)
@@ -455,11 +458,12 @@ def main():
                     K.stft_mel_floor(x, win, n_fft, hop, fl_stft, (units[0], units[1], N_MELS), fl_mel)
                 fe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                 fe[0].record()
-                for _ in range(args.steps):
+                n_probe = max(5, min(args.steps, 20))          # launches per probe
+                for _ in range(n_probe):
                     K.stft_mel_floor(x, win, n_fft, hop, fl_stft, (units[0], units[1], N_MELS), fl_mel)
                 fe[1].record()
                 torch.cuda.synchronize()
-                floor_ms = fe[0].elapsed_time(fe[1]) / args.steps
+                floor_ms = fe[0].elapsed_time(fe[1]) / n_probe
                 # ... and one launch at a time with the device idle before each (what a kernel trace sees): on some boxes the
                 # twin runs faster this way than back to back (1.73 against 2.09 ms, profiles/r04_notes.md), the real kernel
                 # does not; the smaller of the two is the floor the kernel is held against
@@ -482,11 +486,11 @@ def main():
                     K.stft_mel_floor(x, win, n_fft, hop, own_stft, (units[0], units[1], N_MELS), own_mel)
                 oe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                 oe[0].record()
-                for _ in range(args.steps):
+                for _ in range(n_probe):
                     K.stft_mel_floor(x, win, n_fft, hop, own_stft, (units[0], units[1], N_MELS), own_mel)
                 oe[1].record()
                 torch.cuda.synchronize()
-                floor_same_ms = oe[0].elapsed_time(oe[1]) / args.steps
+                floor_same_ms = oe[0].elapsed_time(oe[1]) / n_probe
             # Placement (profiles/r05_notes.md section 1; kernels._PlacedOutputs): the library times the real kernel into eight
             # candidate output sets at the first call of a large shape and recycles the fastest three, so the kernel of record
             # above ran on pooled buffers.  What the same binary does on a PLAIN allocation of this process -- the buffers
@@ -498,11 +502,12 @@ def main():
                     K.stft_mel(x, win, n_fft, hop, mel=(units[0], units[1], N_MELS), out=(fl_stft, fl_mel))
                 pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                 pe[0].record()
-                for _ in range(args.steps):
+                n_probe = max(5, min(args.steps, 20))
+                for _ in range(n_probe):
                     K.stft_mel(x, win, n_fft, hop, mel=(units[0], units[1], N_MELS), out=(fl_stft, fl_mel))
                 pe[1].record()
                 torch.cuda.synchronize()
-                k_plain = pe[0].elapsed_time(pe[1]) / args.steps
+                k_plain = pe[0].elapsed_time(pe[1]) / n_probe
                 placement.update({"kernel_ms_plain_allocation": k_plain,
                                   "frac_plain_allocation": stft_bytes / (k_plain * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "twin_ms_plain_allocation": floor_ms,

@@ -8,9 +8,11 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share $*"
 # 1. kernel trace + stats for the bench command
-# (more steps than the counter passes: the first launches after start-up run 20-40 % slow while clocks ramp, and the
-#  per-kernel AVERAGE of this file is what bench.py's roofline.avg_launch_ms is checked against)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-share $* > $O/bench_stats.log 2>&1
+# (many more steps than the counter passes: the per-kernel AVERAGE of this file is what bench.py's roofline.avg_launch_ms is
+#  checked against, and it also holds the launches outside the timed loop -- the first ones after start-up while clocks
+#  ramp, the ~36 calibration launches of the output placement pool into candidate buffers that are then dropped, the
+#  plain-allocation probe of roofline.placement: 200 timed steps keep them below a quarter of the calls)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-share --no-probes $* > $O/bench_stats.log 2>&1
 # 2. HBM traffic counters, each in its own pass (guide: FETCH_SIZE 3 TCC slots, WRITE_SIZE 2)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o bench -- $CMD > $O/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o bench -- $CMD > $O/pmc_write.log 2>&1
@@ -28,7 +30,7 @@ except Exception:
 import hashlib
 R = os.environ.get("GRAFT_REPO_ROOT", ".")
 lib = os.environ.get("AT_LIB_PATH") or os.path.join(R, "audiotools_amd", "lib", "libaudiotools_amd.so")
-out = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "box": "MI355X unique id " + uid, "stats_command": "bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-share", "command": "bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share (one rocprofv3 pass per counter group)"}
+out = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "box": "MI355X unique id " + uid, "stats_command": "bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-share --no-probes", "command": "bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-share (one rocprofv3 pass per counter group)"}
 st = glob.glob(O + "/stats/**/*kernel_stats.csv", recursive=True)
 if st:
     rows = list(csv.DictReader(open(st[0])))
