@@ -7,6 +7,7 @@ function here computes anything on the host beyond shapes.
 """
 import functools
 import math
+import threading
 import os
 
 import numpy as np
@@ -82,6 +83,7 @@ class _PlacedOutputs:
     def __init__(self):
         self.shapes = {}        # key -> {"slots": [(ms, stft_buf)], "bytes": int, "tick": int} or None (not worth it / no room)
         self.tick = 0
+        self.lock = threading.RLock()      # two host threads calling the same shape: one calibrates, the other waits for the pool
 
     @staticmethod
     def _free(t):
@@ -94,21 +96,22 @@ class _PlacedOutputs:
         call's result); otherwise None (plain allocation)."""
         if not self.enabled or nbytes < self.MIN_BYTES or torch.cuda.is_current_stream_capturing():
             return None
-        self.tick += 1
-        ent = self.shapes.get(key, False)
-        if ent is None:
-            return None
-        if ent is False:
-            try:
-                return self._calibrate(key, nbytes, alloc, launch)
-            except torch.cuda.OutOfMemoryError:        # somebody else took the memory between the check and the allocations
-                self.shapes[key] = None
+        with self.lock:
+            self.tick += 1
+            ent = self.shapes.get(key, False)
+            if ent is None:
                 return None
-        ent["tick"] = self.tick
-        for _ms, sb in ent["slots"]:
-            if self._free(sb):
-                return sb, False
-        return None
+            if ent is False:
+                try:
+                    return self._calibrate(key, nbytes, alloc, launch)
+                except torch.cuda.OutOfMemoryError:    # somebody else took the memory between the check and the allocations
+                    self.shapes[key] = None
+                    return None
+            ent["tick"] = self.tick
+            for _ms, sb in ent["slots"]:
+                if self._free(sb):
+                    return sb, False
+            return None
 
     def _calibrate(self, key, nbytes, alloc, launch):
         dev = key[0]

@@ -603,3 +603,85 @@ def test_long_fir_as_one_circular_convolution(monkeypatch):
         shared = kernels._fir_long(x, tp[:1], 1, L, False, None)
         ref0 = torch.nn.functional.conv1d(xp.reshape(-1, 1, xp.shape[-1]), taps[0].double()[None, None]).reshape(B, C, T)
         assert (shared.double() - ref0).abs().max() < 2e-5 * ref0.abs().max()
+
+
+def test_placed_outputs_pool_logic_on_cpu(monkeypatch):
+    """kernels._PlacedOutputs without a GPU: the device queries and events are stand-ins (every "launch" takes as long as the
+    candidate's index), the bookkeeping is the real one -- calibration keeps the fastest KEEP, as many candidates as the
+    free memory holds, a buffer is handed out again only when nothing references its storage (a view, a detached alias
+    and the pool's own tensor object are three different cases: the last one is invisible to the storage use count, which
+    is why callers always get an alias), the least recently used shape is dropped beyond MAX_POOL_BYTES."""
+    import torch
+    from audiotools_amd import kernels
+
+    clock = {"now": 0.0}
+
+    class FakeEvent:
+        def __init__(self, enable_timing=True):
+            self.t = None
+
+        def record(self):
+            self.t = clock["now"]
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    free = {"bytes": 100 * 4096}
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (free["bytes"], 1 << 40))
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    pool = kernels._PlacedOutputs()
+    monkeypatch.setattr(kernels._PlacedOutputs, "MIN_BYTES", 1024)
+    made = []
+
+    def alloc():
+        t = torch.empty(1024, dtype=torch.float32)
+        made.append(t)
+        return t
+
+    def launch(t):                       # candidate i "takes" 10 - i ms (the last allocations are the fastest), and writes its result
+        i = next(k for k, m in enumerate(made) if m is t)
+        clock["now"] += 10.0 - i
+        t.fill_(7.0)
+
+    key = ("cpu", (1024,), 0, "fake")
+    got = pool.acquire(key, 4096, alloc, launch)
+    assert got is not None and got[1] is True                      # calibrated: the buffer already holds the result
+    rep = pool.report()
+    assert rep[0]["op"] == "fake" and len(rep[0]["calibration_ms"]) == kernels._PlacedOutputs.CANDIDATES == len(made)
+    assert rep[0]["kept_ms"] == sorted(rep[0]["calibration_ms"])[:3]
+    fastest = made[-1]
+    assert got[0] is fastest and float(got[0][0]) == 7.0
+    # the pool's OWN tensor object does not count as a holder: the launchers hand out an alias (detach / transposed view)
+    held = got[0].detach()
+    nxt = pool.acquire(key, 4096, alloc, launch)
+    assert nxt[1] is False and nxt[0] is made[-2], "the fastest buffer is held: the next fastest is handed out"
+    view = nxt[0].view(32, 32)                                     # a view holds the storage just the same
+    third = pool.acquire(key, 4096, alloc, launch)
+    assert third[0] is made[-3]
+    alias3 = third[0].detach()
+    assert pool.acquire(key, 4096, alloc, launch) is None, "all three held: plain allocation"
+    del held
+    assert pool.acquire(key, 4096, alloc, launch)[0] is fastest    # released -> reused at once
+    del view, alias3
+    # as many candidates as the free memory holds next to two more results; fewer than two: no pool for the shape
+    free["bytes"] = 7 * 4096
+    made.clear()
+    assert pool.acquire(("cpu", (1024,), 0, "tight"), 4096, alloc, launch) is not None and len(made) == 5
+    free["bytes"] = 3 * 4096
+    assert pool.acquire(("cpu", (1024,), 0, "none"), 4096, alloc, launch) is None
+    assert pool.acquire(("cpu", (1024,), 0, "none"), 4096, alloc, launch) is None     # remembered
+    # least recently used shape dropped beyond MAX_POOL_BYTES
+    free["bytes"] = 100 * 4096
+    monkeypatch.setattr(kernels._PlacedOutputs, "MAX_POOL_BYTES", 2 * 3 * 4096)
+    made.clear()
+    pool.acquire(key, 4096, alloc, launch)                                           # touch "fake": "tight" is now the oldest
+    made.clear()
+    assert pool.acquire(("cpu", (1024,), 0, "third"), 4096, alloc, launch) is not None
+    ops = sorted(r["op"] for r in pool.report())
+    assert ops == ["fake", "third"], ops
+    # below the threshold, or disabled: never
+    assert pool.acquire(("cpu", (8,), 0, "small"), 512, alloc, launch) is None
+    monkeypatch.setattr(kernels._PlacedOutputs, "enabled", False)
+    assert pool.acquire(key, 4096, alloc, launch) is None
