@@ -46,6 +46,15 @@
 #ifndef AT_STFT_RUNSTORE
 #define AT_STFT_RUNSTORE 1      // 0 = A/B build: the several-frames-per-wave kernels store FW segments per instruction instead of 512-byte runs from the slab
 #endif
+#ifndef AT_STFT_RUNSTORE_NT
+#define AT_STFT_RUNSTORE_NT 1   // those runs as non-temporal stores (0 = A/B build).  With 512-byte runs `nt` pays as it does in the v2 kernel: n_fft 512
+                                // 0.81-0.87 -> 0.70 ms, 1024 @ 44.1 kHz 2.06 -> 1.93, 256: 0.42-0.47 -> 0.39 (s33); on the old 128-byte segments it had
+                                // cost 25 % (they lost the L2's write combining, r04_notes.md 12)
+#endif
+#ifndef AT_STFT_SEG_NT
+#define AT_STFT_SEG_NT 1        // the 256-byte segments of n_fft 1024 + mel (the one several-frames-per-wave case left on the old store path) non-temporal:
+                                // 2.59 -> 2.50 ms at 44.1 kHz, 1.27 -> 1.24 at 22 kHz (s34); 0 = A/B build
+#endif
 #ifndef AT_STFT_MELREG
 #define AT_STFT_MELREG 1        // 0 = A/B build: unit descriptors (and two rounds' weights) of the several-frames-per-wave kernels re-read from LDS per frame
 #endif
@@ -100,6 +109,8 @@ struct StftArgs {
 };
 
 using at::fetch_padded;
+template <int POL>
+__device__ __forceinline__ void st2(float2* p, float2 v);   // (defined with the v2 kernel below: bit 0 of POL = non-temporal)
 
 // ---- mel "unit" tables (built by at_mel_units_host) --------------------------------------
 // The Slaney filterbank is banded: band m is non-zero on a short run of bins.  Bins are cut
@@ -248,6 +259,7 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
   // (vmcnt retires in order: the samples are waited for with the stores still in flight).
   constexpr bool PIPE = FW > 1 && AT_STFT_PIPE;
   constexpr bool RUNSTORE = runstore_for<M, NR>();
+  constexpr int SEG_NT = (AT_STFT_SEG_NT && M == 512 && FW > 1) ? 1 : 0;
   float2 nxt16[PIPE ? 16 : 1];
 
   // ---- one frame group: window, FFT, split, stores (+ mel).  `a` holds the raw samples.
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
         for (int i = 0; i < NST; ++i) {
           const int idx = min(i * 64 + lane, TOT - 1);      // (only the last instruction clamps: duplicates of the last bin)
           const int f = idx / (M + 1);
-          obase[idx] = wbuf[f * P::SLOTS + (idx - f * (M + 1))];
+          st2<AT_STFT_RUNSTORE_NT>(obase + idx, wbuf[f * P::SLOTS + (idx - f * (M + 1))]);
         }
       } else {                              // last group of a row: only the frames that exist
         const int tot = (n_out - f0) * (M + 1);
@@ -439,7 +451,7 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
         xa = make_float2(sr - pp, si - qq);          // the 1/2 is in the window table
         xb = make_float2(sr + pp, -si - qq);
       }
-      if (STORE_OK(xa.x)) orow[k] = xa;
+      if (STORE_OK(xa.x)) st2<SEG_NT>(orow + k, xa);
       if constexpr (MEL) magbuf[k + 4 * (k >> 4)] = cabs_fast(xa);
       xbs[q] = make_float2(__shfl(xb.x, rev_lane, 64), __shfl(xb.y, rev_lane, 64));
     }
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, (M <= 256 ? AT_STFT_WPS_SMALL : AT_STFT_WP
 #pragma unroll
     for (int q = 7; q >= 0; --q) {
       const int kb = (M - L * q - L + 1) + t;   // lane L-1 of q == 0 holds the Nyquist bin M
-      if (STORE_OK(xbs[q].x)) orow[kb] = xbs[q];
+      if (STORE_OK(xbs[q].x)) st2<SEG_NT>(orow + kb, xbs[q]);
       if constexpr (MEL) magbuf[kb + 4 * (kb >> 4)] = cabs_fast(xbs[q]);
     }
     if (t == 0) {  // k == M/2: X = conj(Z[M/2])
