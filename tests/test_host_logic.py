@@ -685,3 +685,47 @@ def test_placed_outputs_pool_logic_on_cpu(monkeypatch):
     assert pool.acquire(("cpu", (8,), 0, "small"), 512, alloc, launch) is None
     monkeypatch.setattr(kernels._PlacedOutputs, "enabled", False)
     assert pool.acquire(key, 4096, alloc, launch) is None
+
+
+@pytest.mark.parametrize("M", [16, 32, 64, 128, 256, 512])
+def test_run_store_index_algebra(M):
+    """Lane-level model of the 512-byte-run stores of the several-frames-per-wave STFT kernels (csrc/stft.hip, RUNSTORE):
+    the split step's lanes (frame slot fs = lane / L, t = lane % L) drop bins k = t + L q and M - k (q < 8; lane t = 0 also
+    M / 2) into the slab at fs * 17 L + bin; the wave then reads the slab back by the LINEAR output index idx = 64 i + lane
+    (frame idx / (M + 1), bin idx % (M + 1)) in 17 instructions.  Every (frame, bin) must be written exactly once, fit the
+    1088-slot slab, be read back at its own output offset, and a ragged last group must store exactly the frames that exist."""
+    L = M // 16
+    FW = 64 // L
+    SLOTS = 17 * L
+    slab = {}
+    for lane in range(64):
+        fs, t = lane // L, lane % L
+        for q in range(8):
+            k = t + L * q
+            for b in (k, M - k):
+                slot = fs * SLOTS + b
+                assert slot not in slab and slot < 1088
+                slab[slot] = (fs, b)
+        if t == 0:
+            slot = fs * SLOTS + M // 2
+            assert slot not in slab
+            slab[slot] = (fs, M // 2)
+    TOT = FW * (M + 1)
+    NST = (TOT + 63) // 64
+    assert len(slab) == TOT and NST == 17
+    for live in range(1, FW + 1):                       # frames of the group that exist
+        tot = live * (M + 1)
+        stored = {}
+        for i in range(NST):
+            for lane in range(64):
+                if live == FW:
+                    idx = min(i * 64 + lane, TOT - 1)   # full group: unconditional stores, the last instruction clamps
+                elif i * 64 + lane < tot:
+                    idx = i * 64 + lane
+                else:
+                    continue
+                f = idx // (M + 1)
+                k = idx - f * (M + 1)
+                assert slab[f * SLOTS + k] == (f, k)
+                stored[idx] = (f, k)                    # (duplicates of the clamped lanes carry the same value)
+        assert sorted(stored) == list(range(tot))
