@@ -78,7 +78,7 @@ class _PlacedOutputs:
     KEEP = 3                    # ... of which this many stay in the pool (mel_spectrogram alternates two while stft_data holds one)
     MIN_BYTES = 256 << 20       # outputs below this size are not worth it
     MAX_POOL_BYTES = 48 << 30   # all shapes together; the least recently used shape is dropped beyond it
-    enabled = True
+    enabled = hasattr(torch._C, "_storage_Use_Count")      # (a private torch API: without it nothing is pooled)
 
     def __init__(self):
         self.shapes = {}        # key -> {"slots": [(ms, stft_buf)], "bytes": int, "tick": int} or None (not worth it / no room)
