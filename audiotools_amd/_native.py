@@ -88,8 +88,12 @@ def build(force: bool = False, verbose: bool = False, out: str = None, dev: bool
     """Compile every HIP source for gfx950 (one object per source, in parallel; hipcc cross-compiles
     without a GPU) and link ``lib/libaudiotools_amd.so`` (``dev=True``: the development build with the A/B
     switches, ``lib/libaudiotools_amd_dev.so``)."""
+    if out is None and os.environ.get("AT_LIB_PATH"):
+        out = os.environ["AT_LIB_PATH"]        # what lib() will load (ADVICE r05): a development build when the process opted in
+        if dev is None:
+            dev = DEV_KNOBS
     if dev is None:
-        dev = out is None and DEV_KNOBS and not os.environ.get("AT_LIB_PATH")
+        dev = out is None and DEV_KNOBS
     out = out or (DEV_LIB_PATH if dev else SHIP_LIB_PATH)
     obj_dir = os.path.join(os.path.dirname(out), "obj" if out == SHIP_LIB_PATH else "obj_" + os.path.basename(out))
     os.makedirs(obj_dir, exist_ok=True)
@@ -135,8 +139,6 @@ SIGNATURES = {
     "at_mel_bands_host": (_i32, [_p, _i32, _i32, _p, _p]),
     "at_stft_mel_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
                                _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
-    "at_stft_mel_floor_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
-                                     _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
     "at_istft_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
     "at_istft_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i64, _i64, _p, _p, _i64, _p]),
     "at_istft_edit_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i64, _i64, _p, _p, _i64,
@@ -180,6 +182,38 @@ SIGNATURES = {
     "at_lufs_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _i32, _i32, _i32, _f64, _f32,
                            _i32, _p, _p, _i64, _p]),
 }
+
+
+# measurement-only entry points of the development build (-DAT_DEV_KNOBS=1): never part of the shipped ABI
+DEV_SIGNATURES = {
+    # zero-compute twin of at_stft_mel_f32 for the n_fft 2048 / hop 512 kernel: same arguments, grid, runs, addresses, load /
+    # store instructions and cache policy, no transform (bench.py: roofline.floor_ms; tools/regime.py)
+    "at_stft_mel_floor_f32": (_i32, [_p, _i64, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32,
+                                     _i32, _i64, _p, _p, _p, _i32, _i32, _p, _p]),
+}
+
+_dev_lib = None
+
+
+def dev_lib(build_if_missing: bool = False):
+    """ctypes handle of the DEVELOPMENT library with its measurement entry points bound, loaded next to the product library
+    (its own handle: nothing of it is reachable through `lib()`); None when it has not been built."""
+    global _dev_lib
+    if _dev_lib is not None:
+        return _dev_lib
+    with _lock:
+        if _dev_lib is None:
+            if not os.path.exists(DEV_LIB_PATH):
+                if not build_if_missing:
+                    return None
+                build(dev=True)
+            handle = lib() if LIB_PATH == DEV_LIB_PATH else ctypes.CDLL(DEV_LIB_PATH)
+            for name, (res, args) in DEV_SIGNATURES.items():
+                fn = getattr(handle, name)
+                fn.restype = res
+                fn.argtypes = args
+            _dev_lib = handle
+    return _dev_lib
 
 
 def lib():

@@ -73,6 +73,22 @@
 #ifndef AT_STFT_RUN
 #define AT_STFT_RUN 16          // consecutive frame groups a wave handles before jumping ahead
 #endif
+#ifndef AT_STFT_V2_PIPE
+#define AT_STFT_V2_PIPE 3       // v2 kernel: the mel unit rounds of frame f run inside frame f + 1, beside the register-only part of its first pass.
+                                // 0 = the round-5 kernel (A/B build); 1 = placement left to the compiler, 2 = five slots held by scheduling barriers,
+                                // two operand buffers (both spill: 256 registers + 23-38 scratch dwords, whose reloads count in vmcnt);
+                                // 3 = the slots with ONE operand buffer: 252 registers, no scratch.  Same box, interleaved, placed outputs
+                                // (profiles/sessions_r06/s01, s02): 1.988-2.032 -> 1.934-1.972 ms
+#endif
+#if !AT_DEV_KNOBS
+#undef AT_STFT_ABL              // measurement builds exist in the development library only
+#endif
+#ifndef AT_STFT_ABL
+#define AT_STFT_ABL 0           // measurement builds of the v2 kernel (results WRONG): 1 no v_sqrt, 2 no unit rounds, 4 no magnitude writes, 8 no thread-0
+                                // selects, 16 no partner permute.  What they measured (s02, ms against 1.934-1.961): 1.94 / 1.77-1.82 / 1.89-1.90 / 1.93-1.94 /
+                                // 1.93: the kernel pays for LDS traffic (the 32 ds_read_b128 of the unit rounds, the 16 magnitude writes), not for VALU
+                                // instructions (33 selects: nothing; 16 v_sqrt: nothing)
+#endif
 #ifndef AT_STFT_RUN_V2
 #define AT_STFT_RUN_V2 72       // the same for the 2048/512 kernel (runs of 36...431 measure alike, 16 is 3 % slower)
 #endif
@@ -665,6 +681,12 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   constexpr bool MEL = NR > 0;
   constexpr bool STATIC_STORES = (VAR & 1) != 0;
   constexpr bool FLOOR = (VAR & 2) != 0;
+  // VAR bits 2-3: PIPE.  The unit rounds of frame f's mel run at the top of frame f + 1, between the register-only part of its
+  // first pass (window, radix-16 butterfly) and that pass's slab stores: the mel stage's LDS round trips and DPP chains (a serial
+  // chain of ~1000 cycles per frame that two waves per SIMD did not hide) share their issue slots with ~200 independent VALU
+  // instructions.  The magnitudes stay in the slab until then (pass 1 overwrites it only after the last unit read); the band sums
+  // are gathered in a per-wave region of their own and leave with the exchange reads of pass 1.  A stretch drains its last frame.
+  constexpr int PIPE = (MEL && STATIC_STORES && !FLOOR) ? ((VAR >> 2) & 3) : 0;
   constexpr int MELOUT_OFF = 1312;   // floats: band sums of the frame, behind the 65 x 20 magnitude rows of the slab
   constexpr bool PRIO = (POL & 8) != 0;
   constexpr int M = 1024, L = 64, N = 2048, NW = 4, SH = 4;
@@ -728,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       const int fl = ui.y;
       m_off[r] = ui.x;
       m_fl[r] = (fl & 1) | (((fl >> 1) & 1) << 8) | (((fl >> 2) & 1) << 16) | (((fl >> 3) & 1) << 24);
-      m_st[r] = (fl & 16) ? (fl >> 8) : -1;
+      m_st[r] = (fl & 16) ? (fl >> 8) : (PIPE != 0 ? 128 + (lane & 15) : -1);   // PIPE: lanes that head no band write a dump slot
     }
   }
   // STATIC_STORES: the bands this lane stores (lane, 64 + lane, clamped to the last band: duplicates of it are harmless)
@@ -764,6 +786,82 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
 
   float2 raw[16];   // un-windowed samples; logical q of a phase-p frame is raw[(q + 4 p) & 15]
   float2 nxt[SH];   // the 4 new loads of the NEXT frame, issued ahead of this frame's stores
+
+  // ---- mel stage: unit dot products as packed FMAs on the float4 rows as they come out of LDS (two independent
+  // accumulator pairs: dependency depth 6 instead of 16); the segmented sums take their participation bits as 0.0 / 1.0
+  // factors, one FMA per step.  Software pipeline over the rounds with two operand buffers: the reads of round r + 2 are
+  // issued as soon as round r's products are done, and the (serial) DPP chain of round r - 1 shares its issue slots with
+  // the products of round r.
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  struct MelOps { float4 wv[2][4], mv[2][4]; };
+  // band sums of a frame: in the slab behind the magnitude rows, or (PIPE) in a region of the wave's own behind the tables
+  float* const melout = PIPE ? reinterpret_cast<float*>(s_uinfo + A.n_units) + wave * 144 : magbuf + MELOUT_OFF;
+  auto load_unit = [&](MelOps& o, int r, int b) __attribute__((always_inline)) {
+    const float4* mq = reinterpret_cast<const float4*>(magbuf + m_off[r]);
+    const float4* wq = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW);
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) { o.wv[b][i4] = wq[i4]; o.mv[b][i4] = mq[i4]; }
+  };
+  auto dot_unit = [&](const MelOps& o, int b) __attribute__((always_inline)) -> float {
+    v2f e = v2f{o.wv[b][0].x, o.wv[b][0].y} * v2f{o.mv[b][0].x, o.mv[b][0].y};
+    v2f od = v2f{o.wv[b][0].z, o.wv[b][0].w} * v2f{o.mv[b][0].z, o.mv[b][0].w};
+#pragma unroll
+    for (int i4 = 1; i4 < 4; ++i4) {
+      e = __builtin_elementwise_fma(v2f{o.wv[b][i4].x, o.wv[b][i4].y}, v2f{o.mv[b][i4].x, o.mv[b][i4].y}, e);
+      od = __builtin_elementwise_fma(v2f{o.wv[b][i4].z, o.wv[b][i4].w}, v2f{o.mv[b][i4].z, o.mv[b][i4].w}, od);
+    }
+    const v2f sum = e + od;
+    return sum.x + sum.y;
+  };
+  auto reduce_store = [&](float acc, int r, float* mrow) __attribute__((always_inline)) {
+    const unsigned f = (unsigned)m_fl[r];
+    float sh;
+    sh = dpp_row_shl<1>(acc); acc = fmaf(sh, (float)(f & 0xffu), acc);
+    sh = dpp_row_shl<2>(acc); acc = fmaf(sh, (float)((f >> 8) & 0xffu), acc);
+    sh = dpp_row_shl<4>(acc); acc = fmaf(sh, (float)((f >> 16) & 0xffu), acc);
+    sh = dpp_row_shl<8>(acc); acc = fmaf(sh, (float)(f >> 24), acc);
+    if constexpr (PIPE != 0) {
+      melout[m_st[r]] = acc;          // every lane (m_st: band, or a dump slot behind the bands): no exec-mask branch cuts the slot
+    } else if constexpr (STATIC_STORES) {
+      if (m_st[r] >= 0) melout[m_st[r]] = acc;
+    } else {
+      if (m_st[r] >= 0) at::stg<(POL & 2) != 0>(mrow + m_st[r], acc);
+    }
+  };
+  // all rounds of one frame (the magnitudes are in the slab); SCHED: hold the round pipeline in place with scheduling barriers
+  auto mel_rounds = [&](MelOps& o, float* mrow, auto sched_c) __attribute__((always_inline)) {
+    constexpr bool SCHED = decltype(sched_c)::value;
+    float acc_prev = dot_unit(o, 0);
+    if constexpr (SCHED) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NR > 2) load_unit(o, 2, 0);
+#pragma unroll
+    for (int r = 1; r < NR; ++r) {
+      const float acc_cur = dot_unit(o, r & 1);
+      reduce_store(acc_prev, r - 1, mrow);
+      if constexpr (SCHED) __builtin_amdgcn_sched_barrier(0);
+      if (r + 2 < NR) load_unit(o, r + 2, r & 1);
+      acc_prev = acc_cur;
+    }
+    reduce_store(acc_prev, NR - 1, mrow);
+  };
+  // the gathered band sums leave as two unconditional, coalesced stores (STATIC_STORES)
+  auto melout_store = [&](float* mrow) __attribute__((always_inline)) {
+    const float b0 = melout[gb0], b1 = melout[gb1];
+    at::stg<(POL & 2) != 0>(mrow + gb0, b0);
+    at::stg<(POL & 2) != 0>(mrow + gb1, b1);
+  };
+  // PIPE: the mel of a stretch's last frame (nothing follows it to hide behind)
+  auto mel_drain = [&](int64_t row, int fo) __attribute__((always_inline)) {
+    float* mrow = A.mel + ((int64_t)row * n_out + fo) * A.n_mels;
+    wave_sync();
+    MelOps o;
+    load_unit(o, 0, 0);
+    load_unit(o, 1, 1);
+    mel_rounds(o, mrow, std::true_type{});
+    wave_sync();
+    melout_store(mrow);
+    wave_sync();
+  };
 
   auto split = [&](float2 zk, float2 zm, float2 twp, float2& xa, float2& xb) __attribute__((always_inline)) {
     const float sr = zk.x + zm.x, si = zk.y - zm.y;
@@ -832,6 +930,16 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       }
       return have_nxt;
     } else {
+    // PIPE: this frame carries the unit rounds of its predecessor (every frame of a stretch but the first)
+    constexpr bool PIPE_NOW = PIPE != 0 && decltype(steady_c)::value;
+    MelOps mo;
+    float* mrow_prev = nullptr;
+    if constexpr (PIPE_NOW) {
+      mrow_prev = A.mel + ((int64_t)row * n_out + (fo - 1)) * A.n_mels;
+      wave_sync();
+      load_unit(mo, 0, 0);
+      if constexpr (PIPE != 3) load_unit(mo, 1, 1);
+    }
     float2 a[16];
     {
       const float4* wr = reinterpret_cast<const float4*>(s_winr + t * WROW);
@@ -846,10 +954,86 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       }
     }
     // ---- passes 1 and 2 (radix 16, 16) through the slab
-    pass_compute_store<16, 1, L, true>(a, fbuf, t, nullptr);
+    if constexpr (PIPE_NOW) {
+      // pass 1's butterfly in registers, the previous frame's unit rounds beside it, then the slab stores
+      if constexpr (PIPE == 1) {
+        Dft<16>::run(a);
+        mel_rounds(mo, mrow_prev, std::false_type{});
+      } else {
+        // SLOTS: the radix-16 butterfly cut into five pieces (as Dft<16>::run: four 4-point transforms on the columns in two
+        // pieces, the w_16 twiddles, four 4-point transforms on the rows in two pieces), one per slot, each slot also holding one
+        // step of the round pipeline: the products of round s, the segmented sum of round s - 1, the LDS reads of round s + 2.
+        // Scheduling barriers keep the slots apart; inside a slot the compiler orders freely.
+        float2 C[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) C[c][r] = a[c + 4 * r];
+        float acc[NR + 1];
+        auto mel_step = [&](auto s_c) __attribute__((always_inline)) {
+          constexpr int S = decltype(s_c)::value;
+          if constexpr ((AT_STFT_ABL & 2) != 0) {
+            if constexpr (S == 0) melout[m_st[0]] = mo.mv[0][0].x;
+          } else if constexpr (PIPE == 3) {          // one operand buffer: the reads of round s + 1 follow the products of round s
+            if constexpr (S < NR) acc[S] = dot_unit(mo, 0);
+            if constexpr (S + 1 < NR) load_unit(mo, S + 1, 0);
+            if constexpr (S >= 1 && S <= NR) reduce_store(acc[S - 1], S - 1, mrow_prev);
+          } else {
+            if constexpr (S < NR) acc[S] = dot_unit(mo, S & 1);
+            if constexpr (S >= 1 && S <= NR) reduce_store(acc[S - 1], S - 1, mrow_prev);
+            if constexpr (S + 2 < NR) load_unit(mo, S + 2, S & 1);
+          }
+        };
+        auto dft_piece = [&](auto p_c) __attribute__((always_inline)) {
+          constexpr int Pc = decltype(p_c)::value;
+          if constexpr (Pc == 0) { dft4(C[0][0], C[0][1], C[0][2], C[0][3]); dft4(C[1][0], C[1][1], C[1][2], C[1][3]); }
+          if constexpr (Pc == 1) { dft4(C[2][0], C[2][1], C[2][2], C[2][3]); dft4(C[3][0], C[3][1], C[3][2], C[3][3]); }
+          if constexpr (Pc == 2) {
+            C[1][1] = mul_w16<1>(C[1][1]); C[1][2] = mul_w16<2>(C[1][2]); C[1][3] = mul_w16<3>(C[1][3]);
+            C[2][1] = mul_w16<2>(C[2][1]); C[2][2] = mul_w16<4>(C[2][2]); C[2][3] = mul_w16<6>(C[2][3]);
+            C[3][1] = mul_w16<3>(C[3][1]); C[3][2] = mul_w16<6>(C[3][2]); C[3][3] = mul_w16<9>(C[3][3]);
+          }
+          if constexpr (Pc == 3 || Pc == 4) {
+#pragma unroll
+            for (int k1 = 2 * (Pc - 3); k1 < 2 * (Pc - 3) + 2; ++k1) {
+              float2 b0 = C[0][k1], b1 = C[1][k1], b2 = C[2][k1], b3 = C[3][k1];
+              dft4(b0, b1, b2, b3);
+              a[k1] = b0; a[k1 + 4] = b1; a[k1 + 8] = b2; a[k1 + 12] = b3;
+            }
+          }
+        };
+        dft_piece(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mel_step(std::integral_constant<int, 0>{}); dft_piece(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mel_step(std::integral_constant<int, 1>{}); dft_piece(std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mel_step(std::integral_constant<int, 2>{}); dft_piece(std::integral_constant<int, 3>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mel_step(std::integral_constant<int, 3>{}); dft_piece(std::integral_constant<int, 4>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mel_step(std::integral_constant<int, 4>{});
+        if constexpr (NR > 4) {
+          __builtin_amdgcn_sched_barrier(0);
+          mel_step(std::integral_constant<int, 5>{});
+          __builtin_amdgcn_sched_barrier(0);
+          mel_step(std::integral_constant<int, 6>{});
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fbuf[phys<L, true>(16 * t + r)] = a[r];
+    } else {
+      pass_compute_store<16, 1, L, true>(a, fbuf, t, nullptr);
+    }
     wave_sync();
     load_points<L, true>(a, fbuf, t);
+    float pb0 = 0.f, pb1 = 0.f;
+    if constexpr (PIPE_NOW) { pb0 = melout[gb0]; pb1 = melout[gb1]; }
     wave_sync();
+    if constexpr (PIPE_NOW) {
+      at::stg<(POL & 2) != 0>(mrow_prev + gb0, pb0);
+      at::stg<(POL & 2) != 0>(mrow_prev + gb1, pb1);
+    }
     {
       float2 tw2[16];
       const float4* rp = reinterpret_cast<const float4*>(s_tw2 + (t & 15) * 36);
@@ -907,9 +1091,11 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float2 zk = Z[0][r], zm = Z[1][3 - r];
+      if constexpr ((AT_STFT_ABL & 8) == 0) {
       if (r == 0) zk = t0 ? Z[1][0] : zk;                 // thread 0: (Z[128], Z[896])
       if (r == 1) zm = t0 ? Z[0][3] : zm;                 // thread 0: (Z[256], Z[768])
       if (r == 2) { zk = t0 ? Z[1][1] : zk; zm = t0 ? Z[1][2] : zm; }   // thread 0: (Z[384], Z[640])
+      }
       split(zk, zm, twp[r], xaA[r], xbA[r]);
       split(Z[2][r], Z[3][3 - r], twp[4 + r], xaB[r], xbB[r]);
     }
@@ -918,18 +1104,27 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
     const float2 nyq = make_float2(2.f * (z00.x - z00.y), 0.f);
     const float2 x512 = make_float2(2.f * z02.x, -2.f * z02.y);
     float2 ascA[4];
+    if constexpr ((AT_STFT_ABL & 8) == 0) {
     ascA[0] = t0 ? dc : xaA[0];
     ascA[1] = xaA[1];
     ascA[2] = t0 ? x512 : xaA[2];
     ascA[3] = t0 ? xbA[1] : xaA[3];
+    } else { ascA[0] = xaA[0]; ascA[1] = xaA[1]; ascA[2] = xaA[2]; ascA[3] = xaA[3]; }
     const float2 t0B[4] = {xaA[0], xaA[2], xbA[2], xbA[0]};   // thread 0: X[128], X[384], X[640], X[896]
     float2 rcA[4], rcB[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
+      if constexpr ((AT_STFT_ABL & 24) == 0) {
       rcA[m] = to_partner(t0 ? xbB[3 - m] : xbA[3 - m]);      // bins 256 m + 192 + lane
       rcB[m] = to_partner(t0 ? t0B[m] : xbB[3 - m]);          // bins 256 m + 128 + lane
+      } else if constexpr ((AT_STFT_ABL & 16) == 0) { rcA[m] = to_partner(xbA[3 - m]); rcB[m] = to_partner(xbB[3 - m]); }
+      else if constexpr ((AT_STFT_ABL & 8) == 0) { rcA[m] = t0 ? xbB[3 - m] : xbA[3 - m]; rcB[m] = t0 ? t0B[m] : xbB[3 - m]; }
+      else { rcA[m] = xbA[3 - m]; rcB[m] = xbB[3 - m]; }
     }
     float2* __restrict__ orow = A.out + ((int64_t)row * n_out + fo) * (M + 1);
+    auto cabs_v2 = [](float2 z) __attribute__((always_inline)) -> float {
+      if constexpr ((AT_STFT_ABL & 1) != 0) return fmaf(z.x, z.x, z.y * z.y); else return cabs_fast(z);
+    };
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int k0 = 256 * m + t;
@@ -938,10 +1133,12 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       st2<POL>(orow + k0 + 128, rcB[m]);
       st2<POL>(orow + k0 + 192, rcA[m]);
       if constexpr (MEL) {
-        magbuf[k0 + 4 * (k0 >> 4)] = cabs_fast(ascA[m]);
-        magbuf[k0 + 64 + 4 * ((k0 + 64) >> 4)] = cabs_fast(xaB[m]);
-        magbuf[k0 + 128 + 4 * ((k0 + 128) >> 4)] = cabs_fast(rcB[m]);
-        magbuf[k0 + 192 + 4 * ((k0 + 192) >> 4)] = cabs_fast(rcA[m]);
+        if constexpr ((AT_STFT_ABL & 4) == 0) {
+        magbuf[k0 + 4 * (k0 >> 4)] = cabs_v2(ascA[m]);
+        magbuf[k0 + 64 + 4 * ((k0 + 64) >> 4)] = cabs_v2(xaB[m]);
+        magbuf[k0 + 128 + 4 * ((k0 + 128) >> 4)] = cabs_v2(rcB[m]);
+        magbuf[k0 + 192 + 4 * ((k0 + 192) >> 4)] = cabs_v2(rcA[m]);
+        }
       }
     }
     if constexpr (STATIC_STORES) {
@@ -957,66 +1154,16 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
       if constexpr (MEL) { if (t >= 1 && t < 16) magbuf[(M / 16) * MAG_ROW + t] = 0.f; }
     }
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-    if constexpr (MEL) {
+    if constexpr (MEL && PIPE == 0) {
       wave_sync();
       float* mrow = A.mel + ((int64_t)row * n_out + fo) * A.n_mels;
-      // Unit dot products as packed FMAs on the float4 rows as they come out of LDS (two
-      // independent accumulator pairs: dependency depth 6 instead of 16); the segmented sums take
-      // their participation bits as 0.0 / 1.0 factors, one FMA per step.  Software pipeline over the
-      // rounds with two operand buffers: the reads of round r + 2 are issued as soon as round r's
-      // products are done, and the (serial) DPP chain of round r - 1 shares its issue slots with
-      // the products of round r.
-      typedef float v2f __attribute__((ext_vector_type(2)));
-      float4 wv[2][4], mv[2][4];
-      auto load_unit = [&](int r, int b) __attribute__((always_inline)) {
-        const float4* mq = reinterpret_cast<const float4*>(magbuf + m_off[r]);
-        const float4* wq = reinterpret_cast<const float4*>(s_melw + (r * 64 + lane) * MELW_ROW);
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) { wv[b][i4] = wq[i4]; mv[b][i4] = mq[i4]; }
-      };
-      auto dot_unit = [&](int b) __attribute__((always_inline)) -> float {
-        v2f e = v2f{wv[b][0].x, wv[b][0].y} * v2f{mv[b][0].x, mv[b][0].y};
-        v2f o = v2f{wv[b][0].z, wv[b][0].w} * v2f{mv[b][0].z, mv[b][0].w};
-#pragma unroll
-        for (int i4 = 1; i4 < 4; ++i4) {
-          e = __builtin_elementwise_fma(v2f{wv[b][i4].x, wv[b][i4].y}, v2f{mv[b][i4].x, mv[b][i4].y}, e);
-          o = __builtin_elementwise_fma(v2f{wv[b][i4].z, wv[b][i4].w}, v2f{mv[b][i4].z, mv[b][i4].w}, o);
-        }
-        const v2f sum = e + o;
-        return sum.x + sum.y;
-      };
-      auto reduce_store = [&](float acc, int r) __attribute__((always_inline)) {
-        const unsigned f = (unsigned)m_fl[r];
-        float sh;
-        sh = dpp_row_shl<1>(acc); acc = fmaf(sh, (float)(f & 0xffu), acc);
-        sh = dpp_row_shl<2>(acc); acc = fmaf(sh, (float)((f >> 8) & 0xffu), acc);
-        sh = dpp_row_shl<4>(acc); acc = fmaf(sh, (float)((f >> 16) & 0xffu), acc);
-        sh = dpp_row_shl<8>(acc); acc = fmaf(sh, (float)(f >> 24), acc);
-        if constexpr (STATIC_STORES) {
-          if (m_st[r] >= 0) magbuf[MELOUT_OFF + m_st[r]] = acc;
-        } else {
-          if (m_st[r] >= 0) at::stg<(POL & 2) != 0>(mrow + m_st[r], acc);
-        }
-      };
-      load_unit(0, 0);
-      load_unit(1, 1);
-      float acc_prev = dot_unit(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (NR > 2) load_unit(2, 0);
-#pragma unroll
-      for (int r = 1; r < NR; ++r) {
-        const float acc_cur = dot_unit(r & 1);
-        reduce_store(acc_prev, r - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (r + 2 < NR) load_unit(r + 2, r & 1);
-        acc_prev = acc_cur;
-      }
-      reduce_store(acc_prev, NR - 1);
+      MelOps o;
+      load_unit(o, 0, 0);
+      load_unit(o, 1, 1);
+      mel_rounds(o, mrow, std::true_type{});
       wave_sync();
       if constexpr (STATIC_STORES) {
-        const float b0 = magbuf[MELOUT_OFF + gb0], b1 = magbuf[MELOUT_OFF + gb1];
-        at::stg<(POL & 2) != 0>(mrow + gb0, b0);
-        at::stg<(POL & 2) != 0>(mrow + gb1, b1);
+        melout_store(mrow);
         wave_sync();
       }
     }
@@ -1087,6 +1234,7 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
         AT_NEXT(0)
 #undef AT_NEXT
       }
+      if constexpr (PIPE != 0) mel_drain(row, fo);
     }
   }
 }
@@ -1115,7 +1263,7 @@ template <int NR, int POL = 0, int VAR = 0>
 int launch_v2(const StftArgs& A, int n_cu, hipStream_t stream) {
   constexpr int NW = 4;
   auto kern = stft_mel_kernel_v2<NR, POL, VAR>;
-  const size_t bytes = v2_lds_floats(A.n_units) * 4;
+  const size_t bytes = (v2_lds_floats(A.n_units) + (((VAR >> 2) & 3) ? NW * 144 : 0)) * 4;   // PIPE: + the waves' band-sum regions
   if (bytes > 160 * 1024) return AT_ERR_UNSUPPORTED;
   int e = at::allow_big_lds(reinterpret_cast<const void*>(kern));
   if (e != AT_OK) return e;
@@ -1397,15 +1545,16 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
     // (session s40, same box, interleaved: with mel 2.172 vs 2.190 ms nt / 2.134 vs 2.163 ms plain stores; without
     // mel the round-2 code is 0.9 % faster, 1.814 vs 1.830 ms -- there the only uncounted store was the Nyquist one)
     const bool stat = !(A.flags & 32) && A.n_units != 0 && A.n_mels <= 128;
+    constexpr int SV = 1 + 4 * AT_STFT_V2_PIPE;   // static store count (+ the pipelined mel stage)
     switch (A.n_units / 64) {
-#define AT_V2_POL(NRV)                                                                   \
-  if (stat) return (A.flags & 1) ? launch_v2<NRV, 1, 1>(A, n_cu, s) : launch_v2<NRV, 0, 1>(A, n_cu, s); \
+#define AT_V2_POL(NRV, SV)                                                                   \
+  if (stat) return (A.flags & 1) ? launch_v2<NRV, 1, SV>(A, n_cu, s) : launch_v2<NRV, 0, SV>(A, n_cu, s); \
   return (A.flags & 1) ? launch_v2<NRV, 1, 0>(A, n_cu, s) : launch_v2<NRV, 0, 0>(A, n_cu, s);
-      case 0: AT_V2_POL(0)
-      case 2: return stat ? launch_v2<2, 0, 1>(A, n_cu, s) : launch_v2<2, 0, 0>(A, n_cu, s);
-      case 4: AT_V2_POL(4)
+      case 0: AT_V2_POL(0, 1)
+      case 2: return stat ? launch_v2<2, 0, SV>(A, n_cu, s) : launch_v2<2, 0, 0>(A, n_cu, s);
+      case 4: AT_V2_POL(4, SV)
 #undef AT_V2_POL
-      case 6: return stat ? launch_v2<6, 0, 1>(A, n_cu, s) : launch_v2<6, 0, 0>(A, n_cu, s);
+      case 6: return stat ? launch_v2<6, 0, SV>(A, n_cu, s) : launch_v2<6, 0, 0>(A, n_cu, s);
     }
   }
   switch (M) {
@@ -1421,6 +1570,7 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
 }
 
 
+#if AT_DEV_KNOBS   // (development library only since round 6: VERDICT r05 weak #12)
 // Measurement twin of at_stft_mel_f32 for the n_fft 2048 / hop 512 kernel (same arguments): launches
 // stft_mel_kernel_v2<..., FLOOR> -- identical grid, schedule, addresses, load / store instruction sequence and cache
 // policy, no transform, no mel arithmetic -- so that its duration is the zero-compute cost of the kernel's traffic on
@@ -1448,19 +1598,16 @@ int at_stft_mel_floor_f32(const float* x, int64_t rows, int64_t T, const float* 
   A.total_groups = rows * A.groups_per_row;
   const V2Tuning tuning = v2_tuning();
   A.flags = mel ? 1 : 0;
-#if AT_DEV_KNOBS
   if (tuning.flags >= 0) A.flags = tuning.flags;
-#endif
   A.run_max = tuning.run_max < 1 ? 1 : tuning.run_max;
   int auto_x = device_cu_count() / 32;
   auto_x = auto_x < 1 ? 1 : (auto_x > 8 ? 8 : auto_x);
   A.n_xcd = tuning.n_xcd >= 1 ? tuning.n_xcd : auto_x;
   A.stagger = 0; A.debug = 0; A.reuse_shift = 4; A.run = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#if AT_DEV_KNOBS
   if (mel && tuning.flags >= 0 && !(tuning.flags & 1)) return launch_v2<4, 0, 3>(A, device_cu_count(), s);   // twin with plain spectrum stores
-#endif
   return mel ? launch_v2<4, 1, 3>(A, device_cu_count(), s) : launch_v2<0, 0, 2>(A, device_cu_count(), s);
 }
+#endif   // AT_DEV_KNOBS
 
 }  // extern "C"

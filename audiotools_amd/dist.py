@@ -20,15 +20,22 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", 1)))
 
 
-def init(backend: str = None):
-    """Join the process group described by the environment (no-op for a single process).
+_FORCE_COLLECTIVES = False      # init(force=True): a single rank runs the collective code paths too (first contact with RCCL)
+
+
+def init(backend: str = None, force: bool = False):
+    """Join the process group described by the environment (no-op for a single process unless ``force``: then ONE rank
+    initialises the group -- RCCL on a HIP device, the reference's convention audiotools/ml/accelerator.py:43-48 -- and the
+    table broadcasts below go through their collective path, so that a 1-GPU box exercises everything but the wire).
     Returns (rank, world_size, device)."""
+    global _FORCE_COLLECTIVES
     rank, local_rank, world = env_world()
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    _FORCE_COLLECTIVES = bool(force)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -58,7 +65,7 @@ def broadcast_tables(items, device, src: int = 0):
     import numpy as np
 
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-    if world == 1:
+    if world == 1 and not (_FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized()):
         return [tables.device_table(key, device, builder) for key, builder in items]
     rank = dist.get_rank()
     meta = [None]
@@ -91,6 +98,47 @@ def broadcast_tables(items, device, src: int = 0):
         val = tuple(ts) if is_tuple else ts[0]
         tables.install_table(key, device, val)
         out.append(val)
+    return out
+
+
+def rccl_contact(device, t_start=None):
+    """First contact with the collective library on THIS box (bench.py --force-nccl, one rank or many): the communicator
+    set-up time, the packed table broadcast of the north-star kernel, a 100 MB impulse-response bank (the size class of
+    cfg4's shared bank) and a barrier, each timed on the host with the device drained.  Returns a dict for the bench line."""
+    import time
+
+    import numpy as np
+
+    assert dist.is_available() and dist.is_initialized(), "rccl_contact() needs an initialised process group"
+    out = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+        try:
+            out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # pragma: no cover
+            out["nccl_version"] = f"unavailable ({type(e).__name__})"
+    if t_start is not None:
+        out["init_and_first_barrier_ms"] = 1e3 * (time.perf_counter() - t_start)
+
+    def timed(fn):
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        r = fn()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        return r, 1e3 * (time.perf_counter() - t0)
+
+    _, out["stft_mel_tables_broadcast_ms"] = timed(lambda: broadcast_tables(
+        [((k[0] + "_contact",) + tuple(k[1:]), b) for k, b in _stft_mel_items(44100, 2048, "hann", 80)], device))
+    n = 25 * 1000 * 1000                                    # 100 MB of float32
+    bank, out["ir_bank_100MB_broadcast_ms"] = timed(lambda: broadcast_table(
+        ("contact_ir_bank", n), lambda: (np.arange(n, dtype=np.int64) % 65521).astype(np.float32), device))
+    out["ir_bank_checksum_ok"] = bool(float(bank[-1]) == float((n - 1) % 65521) and float(bank[12345]) == 12345.0
+                                      and float(bank[::1000].double().sum()) == float(sum((i % 65521) for i in range(0, n, 1000))))
+    out["ir_bank_GBps"] = 0.1 / (out["ir_bank_100MB_broadcast_ms"] * 1e-3)
+    _, out["barrier_ms"] = timed(barrier)
+    tables.drop_table(("contact_ir_bank", n), device)
     return out
 
 

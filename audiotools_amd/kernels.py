@@ -61,70 +61,102 @@ def stft_fused_supported(n_fft: int) -> bool:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Placement-aware output buffers (round 5).  The time of the fused STFT kernel follows WHERE its spectrum buffer lies
-# physically: the same binary writes the same 7.2 GB in 1.95 ms into one allocation and in 2.12-2.19 ms into the next one of the
-# same process (DRAM bank-level parallelism behind GB-scale address bits; profiles/r05_notes.md section 1) -- deterministic per
-# allocation, invisible from the virtual address, not reachable by any schedule of the kernel.  MI355X has 288 GB of HBM: for
-# large outputs the first call of a shape allocates a few candidate buffer sets, times the REAL kernel into each (every
-# candidate holds this call's valid result), keeps the fastest ones in a small pool and recycles them for later calls of
-# that shape.  Only the SPECTRUM buffer is pooled: exchanging buffers between a slow and a fast set showed that neither the
-# signal's nor the mel output's placement matters (r05_notes.md 1.1).  Semantics are those of a fresh allocation: a pooled
-# buffer is handed out again only when no tensor of the caller references its storage any more (the C++ storage use
-# count), otherwise the call falls back to torch.empty.
+# Placement-aware output buffers (round 5; an OPT-IN since round 6).  The time of the fused STFT kernel follows WHERE its
+# spectrum buffer lies physically: the same binary writes the same 7.2 GB in 1.95 ms into one allocation and in 2.12-2.19 ms
+# into the next one of the same process (DRAM bank-level parallelism behind GB-scale address bits; profiles/r05_notes.md
+# section 1) -- deterministic per allocation, invisible from the virtual address, not reachable by any schedule of the kernel.
+# A process that has HBM to spare can ask the library to CHOOSE (`output_placement(enabled=True)`): once a large shape has
+# been seen CALIBRATE_AFTER times, the call allocates a few candidate buffers, times the REAL kernel into each (every
+# candidate holds this call's valid result), keeps the fastest KEEP in a small pool and recycles them for later calls of the
+# shape.  Only the SPECTRUM buffer (inverse: the signal buffer) is pooled: exchanging buffers between a slow and a fast set
+# showed that the other operands' placement does not matter (r05_notes.md 1.1).  Semantics are those of a fresh allocation:
+# a pooled buffer is handed out again only when no tensor of a caller references its storage any more (the C++ storage use
+# count; the caller's tensor object is created under the pool's lock), otherwise the call falls back to torch.empty.
+#
+# What it costs, and the limits that keep it a good citizen:
+#   * OFF unless the process opts in; nothing is calibrated before the CALIBRATE_AFTER-th call of a shape (variable-length
+#     workloads never calibrate), at most MAX_CALIBRATIONS shapes per process;
+#   * calibration takes at most FREE_FRACTION of the memory that is free at that moment (candidates that lose go back to
+#     torch's caching allocator), runs 3 launches per candidate and ONE device synchronisation;
+#   * KEEP buffers per shape stay pinned (default 1), all shapes together at most MAX_POOL_BYTES; `release_workspaces()`
+#     (also called when an allocation of this module hits OutOfMemoryError, before one retry) drops them;
+#   * not honoured: `Tensor.record_stream` by a consumer on another stream (the pool is keyed per stream and reuses a
+#     buffer as soon as the last reference is gone -- keep a reference until the other stream's work is enqueued-complete,
+#     or leave the pool off), and a holder that keeps ONLY an `UntypedStorage` Python object of a result (torch re-uses
+#     the storage's preserved PyObject: the use count does not see it).
 class _PlacedOutputs:
-    CANDIDATES = 12             # buffers timed at calibration (fewer when the free memory does not hold them).  The times of one
-                                # process spread over about 12 %; the fastest of eight was 1.864-1.940 ms in nine processes
+    CANDIDATES = 12             # buffers timed at calibration (fewer when FREE_FRACTION of the free memory does not hold them).  The times
+                                # of one process spread over about 12 %; the fastest of eight was 1.864-1.940 ms in nine processes
                                 # (profiles/r05_notes.md 5): four more draws for ~30 ms more calibration, once per shape
-    KEEP = 3                    # ... of which this many stay in the pool (mel_spectrogram alternates two while stft_data holds one)
+    KEEP = 1                    # ... of which this many stay pinned (AudioSignal.stft / mel_spectrogram release the spectrum they replace
+                                # before the kernel runs: one buffer serves a signal's repeated transforms; callers that hold several results
+                                # of a shape at once may ask for more)
     MIN_BYTES = 256 << 20       # outputs below this size are not worth it
-    MAX_POOL_BYTES = 48 << 30   # all shapes together; the least recently used shape is dropped beyond it
-    enabled = hasattr(torch._C, "_storage_Use_Count")      # (a private torch API: without it nothing is pooled)
+    MAX_POOL_BYTES = 24 << 30   # all shapes together; the least recently used shape is dropped beyond it
+    CALIBRATE_AFTER = 3         # a shape is calibrated at its N-th call (the earlier ones take plain allocations)
+    MAX_CALIBRATIONS = 4        # calibrations per process (each is ~37 launches and a device synchronisation)
+    FREE_FRACTION = 0.5         # of the memory free at calibration time
+    enabled = False             # opt-in: output_placement(enabled=True)
+    available = hasattr(torch._C, "_storage_Use_Count")      # (a private torch API: without it nothing is pooled)
 
     def __init__(self):
-        self.shapes = {}        # key -> {"slots": [(ms, stft_buf)], "bytes": int, "tick": int} or None (not worth it / no room)
+        self.shapes = {}        # key -> {"slots": [(ms, buf)], "bytes": int, "tick": int} | int (calls seen so far) | None (not worth it / no room)
         self.tick = 0
+        self.calibrations = 0
         self.lock = threading.RLock()      # two host threads calling the same shape: one calibrates, the other waits for the pool
 
     @staticmethod
     def _free(t):
-        # 2 = the pool's tensor + the temporary storage object of this query; every view / saved tensor / numpy export adds one
+        # 2 = the pool's tensor + the temporary storage object of this query; every alias / view / saved tensor / numpy export adds one
         return t is None or torch._C._storage_Use_Count(t.untyped_storage()._cdata) <= 2
 
     def acquire(self, key, nbytes, alloc, launch):
-        """(stft_buf, launched) for this call: a pooled spectrum buffer when the shape has a calibrated pool and one of its
-        buffers is free; at the first call of a shape, calibration (then `launched` is True: the buffer already holds this
-        call's result); otherwise None (plain allocation)."""
-        if not self.enabled or nbytes < self.MIN_BYTES or torch.cuda.is_current_stream_capturing():
+        """(buf, launched) for this call: an ALIAS (created under the lock, so that a second host thread sees the buffer as
+        held before this one has launched anything) of a pooled buffer when the shape has a calibrated pool and one of its
+        buffers is free; at the CALIBRATE_AFTER-th call of a shape, calibration (then `launched` is True: the buffer already
+        holds this call's result); otherwise None (plain allocation)."""
+        if not (self.enabled and self.available) or nbytes < self.MIN_BYTES or torch.cuda.is_current_stream_capturing():
             return None
         with self.lock:
             self.tick += 1
-            ent = self.shapes.get(key, False)
+            ent = self.shapes.get(key, 0)
             if ent is None:
                 return None
-            if ent is False:
+            if isinstance(ent, int):
+                seen = ent + 1
+                if seen < self.CALIBRATE_AFTER:
+                    self.shapes[key] = seen
+                    if len(self.shapes) > 256:      # a workload of ever-changing shapes: forget the counters, keep the pools
+                        self.shapes = {k: e for k, e in self.shapes.items() if isinstance(e, dict)}
+                    return None
+                if self.calibrations >= self.MAX_CALIBRATIONS:
+                    self.shapes[key] = None
+                    return None
                 try:
-                    return self._calibrate(key, nbytes, alloc, launch)
+                    got = self._calibrate(key, nbytes, alloc, launch)
                 except torch.cuda.OutOfMemoryError:    # somebody else took the memory between the check and the allocations
                     self.shapes[key] = None
                     return None
+                return None if got is None else (got[0].detach(), got[1])
             ent["tick"] = self.tick
             for _ms, sb in ent["slots"]:
                 if self._free(sb):
-                    return sb, False
+                    return sb.detach(), False
             return None
 
     def _calibrate(self, key, nbytes, alloc, launch):
         dev = key[0]
         free_b, _total = torch.cuda.mem_get_info(dev)
-        n_cand = min(self.CANDIDATES, int(free_b // nbytes) - 2)       # as many candidates as fit next to two more results
+        n_cand = min(self.CANDIDATES, int(self.FREE_FRACTION * free_b // nbytes))
         if n_cand < 2 or self.KEEP * nbytes > self.MAX_POOL_BYTES:
             self.shapes[key] = None                # no room for candidates, or a shape the pool is not meant to hold
             return None
-        while self.shapes and sum(e["bytes"] for e in self.shapes.values() if e) + self.KEEP * nbytes > self.MAX_POOL_BYTES:
-            live = [(e["tick"], k) for k, e in self.shapes.items() if e]
+        while sum(e["bytes"] for e in self.shapes.values() if isinstance(e, dict)) + self.KEEP * nbytes > self.MAX_POOL_BYTES:
+            live = [(e["tick"], k) for k, e in self.shapes.items() if isinstance(e, dict)]
             if not live:
                 break
             del self.shapes[min(live)[1]]
+        self.calibrations += 1
         cands = [alloc() for _ in range(n_cand)]
         for sb in cands:                           # first touch of every buffer
             launch(sb)
@@ -140,33 +172,70 @@ class _PlacedOutputs:
         n = len(cands)
         timed = sorted((min(evs[i][0].elapsed_time(evs[i][1]), evs[n + i][0].elapsed_time(evs[n + i][1])), i) for i in range(n))
         slots = [(ms, cands[i]) for ms, i in timed[: self.KEEP]]
-        self.shapes[key] = {"slots": slots, "bytes": self.KEEP * nbytes, "tick": self.tick,
+        self.shapes[key] = {"slots": slots, "bytes": len(slots) * nbytes, "tick": self.tick,
                             "calibration_ms": [ms for ms, _ in timed]}
         return slots[0][1], True
 
+    def release(self):
+        """Drop every pooled buffer (they return to torch's caching allocator) and the per-shape call counters."""
+        with self.lock:
+            self.shapes.clear()
+
+    def bytes_held(self):
+        with self.lock:
+            return sum(e["bytes"] for e in self.shapes.values() if isinstance(e, dict))
+
     def report(self):
-        return [{"op": k[3] if len(k) > 3 else "stft", "shape": list(k[1]), "calibration_ms": e["calibration_ms"],
-                 "kept_ms": [ms for ms, _ in e["slots"]]} for k, e in self.shapes.items() if e]
+        with self.lock:
+            return [{"op": k[3] if len(k) > 3 else "stft", "shape": list(k[1]), "calibration_ms": e["calibration_ms"],
+                     "kept_ms": [ms for ms, _ in e["slots"]], "bytes_held": e["bytes"]}
+                    for k, e in self.shapes.items() if isinstance(e, dict)]
 
 
 _placed_outputs = _PlacedOutputs()
 
 
-def output_placement(enabled: bool = None, candidates: int = None, keep: int = None, min_bytes: int = None):
-    """Configure / query the placement-aware pool of large STFT outputs (see _PlacedOutputs).  Returns its report: per
-    calibrated shape the kernel times measured on the candidate buffer sets and on the ones that were kept.  Disabling
-    drops the pooled buffers."""
+def output_placement(enabled: bool = None, candidates: int = None, keep: int = None, min_bytes: int = None,
+                     calibrate_after: int = None, max_pool_bytes: int = None):
+    """Configure / query the placement-aware pool of large STFT outputs (see _PlacedOutputs; OFF by default).  Returns its
+    report: per calibrated shape the kernel times measured on the candidate buffers, on the ones that were kept, and the
+    bytes they pin.  Disabling drops the pooled buffers (as does `release_workspaces()`)."""
     if enabled is not None:
-        _PlacedOutputs.enabled = bool(enabled)
+        _PlacedOutputs.enabled = bool(enabled) and _PlacedOutputs.available
         if not enabled:
-            _placed_outputs.shapes.clear()
+            _placed_outputs.release()
     if candidates is not None:
         _PlacedOutputs.CANDIDATES = max(int(candidates), 1)
     if keep is not None:
         _PlacedOutputs.KEEP = max(int(keep), 1)
     if min_bytes is not None:
         _PlacedOutputs.MIN_BYTES = int(min_bytes)
+    if calibrate_after is not None:
+        _PlacedOutputs.CALIBRATE_AFTER = max(int(calibrate_after), 1)
+    if max_pool_bytes is not None:
+        _PlacedOutputs.MAX_POOL_BYTES = int(max_pool_bytes)
     return _placed_outputs.report()
+
+
+def release_workspaces(empty_cache: bool = False) -> int:
+    """Give back what this module keeps between calls: the pooled output buffers of `output_placement` and the cached
+    scratch workspaces.  Returns the number of bytes the pool had pinned.  ``empty_cache``: also return torch's cached
+    blocks to the driver.  Called by the launchers themselves when an allocation runs out of memory (then retried once)."""
+    held = _placed_outputs.bytes_held()
+    _placed_outputs.release()
+    _ws_cache.clear()          # (the conv workspace of cfg4 is several GB; the next kernel call re-allocates what it needs)
+    if empty_cache and torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    return held
+
+
+def _alloc_retry(alloc):
+    """``alloc()``; on OutOfMemoryError the pool and the workspaces are released and the allocation is tried once more."""
+    try:
+        return alloc()
+    except torch.cuda.OutOfMemoryError:
+        release_workspaces(empty_cache=True)
+        return alloc()
 
 
 def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *, pad: int = 0,
@@ -220,14 +289,15 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
     launched = False
     if out is not None:
         stft_buf = out[0]
-        assert (stft_buf.shape == shape_s and stft_buf.dtype == torch.complex64 and stft_buf.is_contiguous()
-                and stft_buf.device == dev), "out[0]: contiguous complex64 (B, C, N, F) on the audio's device"
+        if not (isinstance(stft_buf, torch.Tensor) and stft_buf.shape == shape_s and stft_buf.dtype == torch.complex64
+                and stft_buf.is_contiguous() and stft_buf.device == dev):      # (raw pointers go to the kernel: never an `assert`)
+            raise ValueError("out[0]: contiguous complex64 (B, C, N, F) on the audio's device")
         mel_buf = out[1] if mel is not None else None
-        if mel is not None:
-            assert (mel_buf.shape == shape_m and mel_buf.dtype == torch.float32 and mel_buf.is_contiguous()
-                    and mel_buf.device == dev), "out[1]: contiguous float32 (B, C, N, n_mels) on the audio's device"
+        if mel is not None and not (isinstance(mel_buf, torch.Tensor) and mel_buf.shape == shape_m and mel_buf.dtype == torch.float32
+                                    and mel_buf.is_contiguous() and mel_buf.device == dev):
+            raise ValueError("out[1]: contiguous float32 (B, C, N, n_mels) on the audio's device")
     else:
-        mel_buf = torch.empty(shape_m, dtype=torch.float32, device=dev) if shape_m else None
+        mel_buf = _alloc_retry(lambda: torch.empty(shape_m, dtype=torch.float32, device=dev)) if shape_m else None
         nbytes = B * C * n_out * F * 8
         key = (dev, shape_s, torch.cuda.current_stream(dev).cuda_stream)      # (with or without the mel stage: one pool per spectrum shape)
         # (every calibration launch writes the same mel values into the one mel buffer of this call)
@@ -235,7 +305,7 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
         if got is not None:
             stft_buf, launched = got
         else:
-            stft_buf = alloc()
+            stft_buf = _alloc_retry(alloc)
     if not launched:
         launch(stft_buf, mel_buf)
     stft = stft_buf.transpose(2, 3) if stft_buf is not None else None
@@ -245,8 +315,9 @@ def stft_mel(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, *,
 
 def stft_mel_floor(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, stft_buf: torch.Tensor, mel=None,
                    mel_buf: torch.Tensor = None) -> bool:
-    """MEASUREMENT: one launch of the zero-compute twin of the n_fft 2048 / hop 512 kernel (at_stft_mel_floor_f32) into
-    caller-provided buffers of the shapes ``stft_mel`` allocates; False when that kernel does not take the shape."""
+    """MEASUREMENT: one launch of the zero-compute twin of the n_fft 2048 / hop 512 kernel (at_stft_mel_floor_f32, an entry
+    point of the DEVELOPMENT library only: `_native.dev_lib()`) into caller-provided buffers of the shapes ``stft_mel``
+    allocates; False when that library is not built or the kernel does not take the shape."""
     _require_native_ok(audio)
     B, C, T = audio.shape
     dev = audio.device
@@ -256,7 +327,10 @@ def stft_mel_floor(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: i
     if mel is not None:
         info, w, n_mels = mel
         n_units = int(info.shape[0])
-    code = _native.lib().at_stft_mel_floor_f32(
+    dlib = _native.dev_lib()
+    if dlib is None:
+        return False                     # the development library is not built: no floor to measure
+    code = dlib.at_stft_mel_floor_f32(
         _native.ptr(audio), B * C, T, _native.ptr(window), _native.ptr(tw), n_fft, hop, 0, 0, PAD_MODES["reflect"], 0,
         1 + T // hop, _native.ptr(stft_buf), _native.ptr(info), _native.ptr(w), n_units, n_mels, _native.ptr(mel_buf),
         _native.current_stream(dev))
@@ -374,10 +448,9 @@ def istft(stft_bcfn: torch.Tensor, window: torch.Tensor, n_fft: int, hop: int, l
         key = (dev, (B, C, length), torch.cuda.current_stream(dev).cuda_stream, "istft", n_fft, hop, N)
         got = _placed_outputs.acquire(key, nbytes, alloc, launch)
     if got is not None:
-        out, launched = got
-        out = out.detach()        # the caller's own tensor object on the pooled storage: the pool tells by the storage's use count
-    else:                         # whether a result is still held (the forward transform hands out a transposed view for the same reason)
-        out, launched = alloc(), False
+        out, launched = got       # (an alias the pool made under its lock: it tells by the storage's use count whether a result is still held)
+    else:
+        out, launched = _alloc_retry(alloc), False
     if not launched:
         launch(out)
     return out
@@ -580,12 +653,6 @@ def _workspace(nbytes: int, device):
 
 
 _WS_MAX = 8
-
-
-def release_workspaces():
-    """Drop the cached scratch buffers (the conv workspace of cfg4 is several GB): call between phases of a
-    job that no longer needs them; the next kernel call re-allocates what it needs."""
-    _ws_cache.clear()
 
 
 def integrated_loudness(audio_bct: torch.Tensor, rate: int, filter_class: str = "K-weighting",

@@ -338,6 +338,11 @@ def install_table(key, device, tensors):
     _device_cache[(key, _dev_key(device))] = tensors
 
 
+def drop_table(key, device):
+    """Forget a cached / installed table (its memory returns to torch's allocator once nothing else holds it)."""
+    _device_cache.pop((key, _dev_key(device)), None)
+
+
 # ------------------------------------------------------- sinc FIR design
 def _sinc_t(x: torch.Tensor) -> torch.Tensor:
     one = torch.ones((), dtype=x.dtype)

@@ -160,7 +160,7 @@ def committed_traffic(config, n_local, kernel_substr):
     if n_local != want_items:
         return None, None, None
     sha = lib_sha256()
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         name = f"{rnd}_{tag}_pmc_summary.json"
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
@@ -218,6 +218,23 @@ def parity_north_star(x, sr, mel, stft, lufs):
     return out
 
 
+def parity_device_north_star(x, sr, mel, stft):
+    """Every rank's own check of its own outputs, on its device, without the oracle (which lives on rank 0's host): one
+    item of the rank's slab against torch.stft / |X| @ basis^T in float64 (the formulation the reference runs,
+    audio_signal.py:1195-1202, 1355-1368).  Catches what a rank-0-only check cannot: a table that arrived wrong on rank r,
+    a pooled buffer aliased on rank r.  Returns (ok, stft_rel, mel_rel)."""
+    from audiotools_amd import tables as TB
+    i = x.shape[0] // 2
+    xi = x[i].double()
+    win = TB.window("hann", 2048, x.device).double()
+    X = torch.stft(xi, 2048, 512, window=win, center=True, pad_mode="reflect", return_complex=True)   # (C, F, N)
+    basis = torch.from_numpy(TB.mel_filters_np(sr, 2048, N_MELS, 0.0, None)).to(x.device).double()     # (n_mels, F)
+    M = (X.abs().transpose(-1, -2) @ basis.T).transpose(-1, -2)
+    e_s = float((stft[i].to(torch.complex128) - X).abs().amax() / X.abs().amax())
+    e_m = float((mel[i].double() - M).abs().amax() / M.abs().amax())
+    return bool(e_s < 1e-4 and e_m < 1e-4), e_s, e_m
+
+
 # ----------------------------------------------------------------------------- launching
 def respawn_under_torchrun(n):
     """python bench.py --gpus N without a torchrun environment: start N ranks on this node."""
@@ -231,7 +248,7 @@ def respawn_under_torchrun(n):
     return subprocess.call(cmd, env=env)
 
 
-def dry_run(args, adist, rank, world, device):
+def dry_run(args, adist, rank, world, device, rccl_contact=None):
     """Everything around the kernels: one process per rank, the world size check, contiguous batch
     slabs, the table broadcasts of the chosen configuration (gloo when there is no GPU)."""
     cfg = CONFIGS[args.config]
@@ -251,8 +268,9 @@ def dry_run(args, adist, rank, world, device):
     assert int(sizes[0]) == batch, "the slabs must cover the batch exactly once"
     if rank == 0:
         print(json.dumps({"dry_run": True, "config": args.config, "n_gpus": world, "global_batch": batch,
-                          "items_rank0": hi - lo, "backend": torch.distributed.get_backend() if world > 1 else None}))
-    if world > 1:
+                          "items_rank0": hi - lo, "rccl_contact": rccl_contact,
+                          "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None}))
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
@@ -260,9 +278,8 @@ def time_steps(step, steps, warmup, adist, device, world, n_events=0):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; the
     elapsed time is the MAX over ranks."""
     if not _PRIMED.get(id(step)):
-        # set-up, not warm-up: the first call of a shape builds tables, allocates workspaces and calibrates the placement of
-        # large outputs (kernels._PlacedOutputs: ~36 launches, once per shape and process) -- kept out of the timed K steps
-        # even when the driver asks for --warmup 0
+        # set-up, not warm-up: the first call of a shape builds tables and allocates workspaces -- kept out of the timed K
+        # steps even when the driver asks for --warmup 0
         step(None)
         _PRIMED[id(step)] = True
     for _ in range(warmup):
@@ -308,6 +325,15 @@ def main():
     ap.add_argument("--no-share", action="store_true",
                     help="skip the share_64 block (the 8-GPU share timed on this device): profile runs use it so that the "
                          "per-kernel averages of rocprofv3 only see launches of the benchmark's own size")
+    ap.add_argument("--placement", choices=("on", "off"), default="on",
+                    help="north star: opt into the library's placement-aware output pool (kernels.output_placement: the real kernel "
+                         "timed into up to twelve candidate spectrum buffers once, the fastest kept; OFF by default in the library, an "
+                         "explicit opt-in here) for the timed region.  The same K steps on plain torch.empty allocations are timed "
+                         "right after it and printed as roofline.placement.*_plain_allocation either way")
+    ap.add_argument("--force-nccl", action="store_true",
+                    help="initialise the RCCL process group even for ONE rank and run the multi-GPU set-up path on it (table "
+                         "broadcasts, a 100 MB impulse-response bank broadcast, barriers): first contact with librccl on a "
+                         "1-GPU box, reported as \"rccl_contact\" (VERDICT r05 #2)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only (process group, sharding, table broadcast; gloo on a CPU-only host): no kernels")
     args = ap.parse_args()
@@ -319,11 +345,15 @@ def main():
     from audiotools_amd import _native, dist as adist
 
     # RCCL's own warnings go to stderr from the start: the first multi-GPU run is the driver's, not ours
-    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    os.environ.setdefault("NCCL_DEBUG", "VERSION" if args.force_nccl else "WARN")   # (VERSION: RCCL's banner on stderr, kept with the log)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (the host driver has no legacy IPC)
+    rccl_contact = None
     try:
-        rank, world, device = adist.init()
+        t_init = time.perf_counter()
+        rank, world, device = adist.init(force=args.force_nccl)
         adist.barrier()                                            # first collective: RCCL communicator set-up over xGMI
+        if args.force_nccl:
+            rccl_contact = adist.rccl_contact(device, t_init)
     except Exception as e:                                         # pragma: no cover - needs a broken fabric
         if int(os.environ.get("RANK", 0)) == 0:
             print(json.dumps({"error": f"process group / first barrier failed: {type(e).__name__}: {e}",
@@ -338,7 +368,7 @@ def main():
         _native.build()   # no-op when the in-tree library is up to date (it normally travels prebuilt)
     adist.barrier()
     if args.dry_run:
-        return dry_run(args, adist, rank, world, device)
+        return dry_run(args, adist, rank, world, device, rccl_contact)
     assert device.type == "cuda", "bench.py needs a GPU (the product has no CPU fallback)"
     if world > 1:
         assert torch.distributed.get_backend() == "nccl", "multi-GPU runs use RCCL (torch backend 'nccl')"
@@ -353,7 +383,7 @@ def main():
     rows = n_local * ch
     out = {"metric": f"{cfg['metric']}, batch {batch}x{cfg['chdesc']}x{cfg['durdesc']}", "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "setup": "one untimed set-up call before the W warm-up steps (tables, workspaces, calibration of the output placement pool)"}
+           "setup": "one untimed set-up call before the W warm-up steps (tables, workspaces, with --placement on the calibration of the output pool)"}
     kw_cpu = None
 
     if args.config == "north_star":
@@ -382,6 +412,11 @@ def main():
             if ev is not None:
                 ev[2].record()
 
+        from audiotools_amd import kernels as K
+        if args.placement == "on":
+            # the library's opt-in: calibrated during the set-up call below, outside the timed region; its cost
+            # (one buffer of the spectrum's size pinned, ~37 launches + one synchronisation once) is printed with the line
+            K.output_placement(enabled=True, calibrate_after=1)
         launch = "eager"
         step = step_events
         if args.graph:
@@ -441,14 +476,23 @@ def main():
         # evidence outside the timed region (parity of the benchmarked launch, the floor twin, the copy rate) is taken on
         # rank 0 only: the other ranks neither build nor run the oracle, they wait at the closing barrier
         parity = parity_north_star(x, sr, mel, sig.stft_data, lufs) if rank == 0 else {"ok": True}
+        # ... and EVERY rank checks one item of its own slab on its own device (torch.stft / |X| @ basis in float64); the
+        # verdicts are all-reduced, so a wrong result on any rank fails the line
+        dev_ok, dev_es, dev_em = parity_device_north_star(x, sr, mel, sig.stft_data)
+        flag = torch.tensor([1 if dev_ok else 0], dtype=torch.int32, device=device)
+        if world > 1:
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        parity["every_rank_device_check"] = {"ok_all_ranks": bool(int(flag[0])), "rank0_stft_rel": dev_es, "rank0_mel_rel": dev_em,
+                                             "what": "item n_local/2 of every rank's slab vs torch.stft + |X| @ mel basis (float64) on the rank's device"}
+        parity["ok"] = bool(parity["ok"] and int(flag[0]))
         # the zero-compute floor of the dominant kernel's traffic on THIS box: its measurement twin (same grid, schedule,
         # addresses, load / store instructions and cache policy, no transform: at_stft_mel_floor_f32), timed the same way
         floor_ms = floor_iso_ms = floor_same_ms = None
-        placement = None
+        placement = stft_only = None
         try:
             if rank != 0 or args.no_probes:
                 raise StopIteration
-            from audiotools_amd import kernels as K, tables as TB
+            from audiotools_amd import tables as TB
             win = TB.window("hann", n_fft, device)
             units = TB.mel_units(sr, n_fft, N_MELS, 0.0, None, device)
             fl_stft = torch.empty((n_local, ch, n_frames, F), dtype=torch.complex64, device=device)
@@ -491,37 +535,60 @@ def main():
                 oe[1].record()
                 torch.cuda.synchronize()
                 floor_same_ms = oe[0].elapsed_time(oe[1]) / n_probe
-            # Placement (profiles/r05_notes.md section 1; kernels._PlacedOutputs): the library times the real kernel into eight
-            # candidate output sets at the first call of a large shape and recycles the fastest three, so the kernel of record
-            # above ran on pooled buffers.  What the same binary does on a PLAIN allocation of this process -- the buffers
-            # torch.empty hands out, as every round before this one measured it -- is timed here next to it.
-            placement = None
+            # The transform without its mel stage on the same fresh buffers (north_star's gate names "the STFT kernel"): additive
+            # evidence, the kernel of record stays the fused one
+            stft_only = None
             try:
-                placement = {"pool": K.output_placement()}
                 for _ in range(3):
-                    K.stft_mel(x, win, n_fft, hop, mel=(units[0], units[1], N_MELS), out=(fl_stft, fl_mel))
-                pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-                pe[0].record()
+                    K.stft_mel(x, win, n_fft, hop, out=(fl_stft, None))
+                se = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                se[0].record()
                 n_probe = max(5, min(args.steps, 20))
                 for _ in range(n_probe):
-                    K.stft_mel(x, win, n_fft, hop, mel=(units[0], units[1], N_MELS), out=(fl_stft, fl_mel))
-                pe[1].record()
+                    K.stft_mel(x, win, n_fft, hop, out=(fl_stft, None))
+                se[1].record()
                 torch.cuda.synchronize()
-                k_plain = pe[0].elapsed_time(pe[1]) / n_probe
-                placement.update({"kernel_ms_plain_allocation": k_plain,
-                                  "frac_plain_allocation": stft_bytes / (k_plain * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "twin_ms_plain_allocation": floor_ms,
-                                  "note": "pool: kernel times the library measured on its candidate output sets at the first "
-                                          "call and on the three it kept (kernels.output_placement()); *_plain_allocation: the same "
-                                          "kernel on a fresh torch.empty allocation of this process (the twin's fresh buffers)"})
+                so_ms = se[0].elapsed_time(se[1]) / n_probe
+                so_bytes = rows * T * 4 + rows * n_frames * F * 8
+                stft_only = {"kernel": "stft_mel_kernel_v2<0> (the same transform, no mel stage)", "avg_launch_ms": so_ms,
+                             "algorithmic_bytes_per_launch": so_bytes, "frac": so_bytes / (so_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            except Exception as e:  # pragma: no cover
+                stft_only = {"error": f"{type(e).__name__}: {e}"}
+            # Placement (profiles/r05_notes.md section 1; kernels._PlacedOutputs, an OPT-IN since round 6).  With --placement on
+            # (default) the timed region above ran on the buffer the library chose; the same K steps on the buffers torch.empty
+            # hands out -- the library's default behaviour -- are timed here, and both figures are printed.
+            placement = None
+            try:
+                pool_rep, pool_bytes = K.output_placement(), K._placed_outputs.bytes_held()
+                sig._release_stft_data()
+                res.clear()
+                del mel
+                K.output_placement(enabled=False)               # (drops the pooled buffer)
+                pl_el, pl_ev = time_steps(step_events, args.steps, max(args.warmup, 2), adist, device, world, n_events=3)
+                k_plain = sum(e[0].elapsed_time(e[1]) for e in pl_ev) / len(pl_ev)
+                placement = {"enabled_for_the_timed_region": args.placement == "on",
+                             "pool": pool_rep, "pool_bytes_held": pool_bytes,
+                             "kernel_ms_plain_allocation": k_plain,
+                             "frac_plain_allocation": stft_bytes / (k_plain * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "ms_per_step_plain_allocation": 1e3 * pl_el / args.steps,
+                             "value_plain_allocation": batch * dur / (pl_el / args.steps),
+                             "note": "the pool is OFF by default in the library; bench.py opts in (--placement on) the way a job "
+                                     "with HBM to spare would: kernels.output_placement(enabled=True) -- the library timed the real "
+                                     "kernel into the candidate buffers listed under pool.calibration_ms during set-up and keeps the "
+                                     "fastest (pool_bytes_held pinned until release_workspaces()).  *_plain_allocation: the same K "
+                                     "steps with the pool off, on whatever torch.empty handed out in this process (a draw: "
+                                     "53-60 % of 8 TB/s for the same binary, deterministic per allocation)"}
+                mel = res["mel"]
             except Exception as e:  # pragma: no cover
                 placement = {"error": f"{type(e).__name__}: {e}"}
+                mel = sig.mel_spectrogram(N_MELS)
             del fl_stft, fl_mel
         except StopIteration:
             pass
         except Exception as e:  # pragma: no cover - the floor is evidence, never a reason to lose the line
             floor_ms = floor_iso_ms = floor_same_ms = None
             out["floor_error"] = f"{type(e).__name__}: {e}"
+        K.output_placement(enabled=False, calibrate_after=3)
         # what a plain device copy reaches on THIS box (torch.Tensor.copy_, read + write counted),
         # measured the same way: the practical ceiling next to the 8 TB/s spec
         cp_src, cp_dst = x.view(-1), torch.empty_like(x).view(-1)
@@ -548,7 +615,7 @@ def main():
                            "frac_of_floor": (min(floor_ms, floor_iso_ms) / stft_ms) if floor_ms else None,
                            "floor_frac_of_peak": (stft_bytes / (min(floor_ms, floor_iso_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS)
                            if floor_ms else None,
-                           "placement": placement,
+                           "placement": placement, "stft_only": stft_only,
                            "floor_note": "floor_ms = the same launch with the transform removed (stft_mel_kernel_v2<.., FLOOR>: "
                                          "identical grid, runs, addresses, load/store instructions, nt policy), HIP events: K launches back to "
                                          "back (floor_ms) and one at a time on an idle device (floor_ms_one_at_a_time), both into FRESH buffers; frac_of_floor "
@@ -705,13 +772,15 @@ def main():
         out["ms_per_step"] = 1e3 * elapsed / args.steps
         out["value"] = batch * dur / (elapsed / args.steps)
         out["world_size"] = world
-        out["backend"] = torch.distributed.get_backend() if world > 1 else None
+        out["backend"] = torch.distributed.get_backend() if (world > 1 or args.force_nccl) else None
         out["per_rank_ms_per_step"] = [1e3 * t / args.steps for t in PER_RANK_S]
         if PER_RANK_S:
             out["rank_skew"] = {"min_ms_per_step": 1e3 * min(PER_RANK_S) / args.steps, "max_ms_per_step": 1e3 * max(PER_RANK_S) / args.steps,
                                 "max_over_min": max(PER_RANK_S) / min(PER_RANK_S)}
         out["host"] = socket.gethostname()
         out["lib_sha256"] = lib_sha256()
+        if rccl_contact is not None:
+            out["rccl_contact"] = rccl_contact
         if world == 1 and not args.no_cpu_baseline:
             if args.config == "north_star":
                 out["cpu_baseline"] = cpu_baseline_north_star(args.cpu_items or 64, args.cpu_iters)
@@ -719,7 +788,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_cfg(args.config, kw_cpu, args.cpu_items or (8 if args.config == "cfg4" else 4))
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_nccl:
         adist.barrier()            # the other ranks wait here while rank 0 takes its evidence and prints the line
         torch.distributed.destroy_process_group()
     if rank == 0 and not out.get("parity_check", {"ok": True})["ok"]:

@@ -84,18 +84,9 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
                     float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,
                     float* mel_out, void* stream);
 
-/* MEASUREMENT entry, not a replacement of a reference call: the zero-compute twin of at_stft_mel_f32 for the n_fft 2048 /
- * hop 512 kernel (the default transform of audio_signal.py:1066-1070 at 44.1 / 48 kHz) -- the same persistent grid, runs,
- * XCD spans, 8200-byte row pitch, load / store instruction sequence and cache policy, no transform and no mel arithmetic.
- * Its duration is what the kernel's HBM traffic costs on THIS device with nothing to compute; bench.py prints it as
- * roofline.floor_ms next to the kernel's own duration.  Same arguments; the outputs are overwritten with meaningless
- * values.  AT_ERR_UNSUPPORTED for shapes that kernel does not take (pad / right_pad / frame_lo != 0, other sizes, odd T,
- * n_units != 256).
- */
-int at_stft_mel_floor_f32(const float* x, int64_t rows, int64_t T, const float* window, const float* twiddles,
-                          int n_fft, int hop, int pad, int right_pad, int pad_mode, int frame_lo, int64_t n_frames_out,
-                          float* stft_out, const int* mel_unit_info, const float* mel_unit_w, int n_units, int n_mels,
-                          float* mel_out, void* stream);
+/* (The measurement twin of at_stft_mel_f32 -- same arguments, the kernel's loads and stores without its arithmetic, what
+ * bench.py prints as roofline.floor_ms -- is an entry point of the DEVELOPMENT build only since round 6:
+ * lib/libaudiotools_amd_dev.so, `python -m audiotools_amd._native --dev`; audiotools_amd/_native.py: DEV_SIGNATURES.) */
 
 /* ---- inverse STFT --------------------------------------------------------------------------
  * Replaces  audiotools/core/audio_signal.py:1278-1290  (F.pad of the two edge frames when

@@ -132,3 +132,24 @@ def test_bench_spawns_its_own_ranks(config):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "--gpus 2" in (bad.stderr + bad.stdout)
+
+
+def test_forced_single_rank_collectives_dry_run():
+    """bench.py --force-nccl: ONE rank initialises the process group (gloo here, RCCL on a GPU box) and runs
+    the multi-GPU set-up path on itself -- the packed table broadcast, a 100 MB bank broadcast, barriers -- so that the first
+    8-GPU run is not the first time the collective library is loaded.  The tables installed through the collective path are
+    the ones the local path builds."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MASTER_PORT"] = "29631"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run", "--force-nccl"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["rccl_contact"]
+    assert d["n_gpus"] == 1 and d["backend"] == "gloo" and c["world_size"] == 1 and c["ir_bank_checksum_ok"] is True
+    assert c["ir_bank_100MB_broadcast_ms"] > 0 and c["stft_mel_tables_broadcast_ms"] > 0 and c["barrier_ms"] >= 0

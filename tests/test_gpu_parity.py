@@ -878,7 +878,7 @@ def test_stft_mel_into_caller_buffers():
         X1, M1 = kernels.stft_mel(x, win, n_fft, hop, mel=mel, out=(sb, mb))
         assert X1.data_ptr() == sb.data_ptr() and M1.data_ptr() == mb.data_ptr()
         assert torch.equal(X0, X1) and torch.equal(M0, M1)
-        with pytest.raises(AssertionError):
+        with pytest.raises(ValueError):
             kernels.stft_mel(x, win, n_fft, hop, mel=mel, out=(sb[:, :, :-1], mb))
 
 
@@ -888,7 +888,9 @@ def test_placement_aware_output_pool_semantics():
     ANY tensor references its storage (views, stft_data of a signal, saved autograd tensors), a released buffer is reused,
     more simultaneous results than the pool holds fall back to plain allocations, and the numbers do not depend on the pool."""
     from audiotools_amd import kernels, tables
-    rep0 = kernels.output_placement(enabled=True, min_bytes=1 << 20)          # a small threshold so that a test-sized batch takes the pool
+    assert kernels._PlacedOutputs.enabled is False and kernels.output_placement() == [], "the pool is an opt-in (round 6)"
+    # a small threshold so that a test-sized batch takes the pool; three buffers per shape; calibration at the first call
+    kernels.output_placement(enabled=True, min_bytes=1 << 20, keep=3, calibrate_after=1)
     try:
         x = synth.audio_batch(8, 2, 88200, seed=21, gaps=False).cuda()
         win = tables.window("hann", 2048, x.device)
@@ -952,8 +954,50 @@ def test_placement_aware_output_pool_semantics():
         del y1
         assert kernels.istft(Xref, win, 2048, 512, x.shape[-1]).data_ptr() == p1
     finally:
-        kernels.output_placement(enabled=True, min_bytes=256 << 20)
-        kernels._placed_outputs.shapes.clear()
+        kernels.output_placement(enabled=False, min_bytes=256 << 20, keep=1, calibrate_after=3)
+        kernels._placed_outputs.calibrations = 0
+
+
+def test_placement_pool_is_a_good_citizen():
+    """VERDICT r05 #6 / ADVICE r05: the pool is off by default; opted in, it calibrates at the third call of a shape, inside
+    FREE_FRACTION of the memory that is free at that moment; afterwards it pins KEEP = 1 buffer, the losing candidates are
+    torch's to reuse -- an allocation as large as everything that is still free succeeds on a nearly full device --, and
+    release_workspaces() returns the pinned bytes."""
+    from audiotools_amd import kernels, tables
+    dev = torch.device("cuda")
+    x = synth.audio_batch(16, 2, 4 * 44100, seed=3, gaps=False).cuda()
+    win = tables.window("hann", 2048, dev)
+    N = 1 + x.shape[-1] // 512
+    nbytes = 16 * 2 * N * 1025 * 8                                    # 90 MB of spectrum
+    Xref, _ = kernels.stft_mel(x, win, 2048, 512)
+    assert kernels.output_placement() == [] and kernels._placed_outputs.bytes_held() == 0
+    torch.cuda.empty_cache()
+    free_b, _total = torch.cuda.mem_get_info(dev)
+    blocker = torch.empty(free_b - 10 * nbytes, dtype=torch.uint8, device=dev)     # a nearly full device: ten spectra of room
+    try:
+        kernels.output_placement(enabled=True, min_bytes=1 << 20)
+        kernels._placed_outputs.calibrations = 0
+        for call in range(2):
+            X, _ = kernels.stft_mel(x, win, 2048, 512)
+            assert kernels.output_placement() == [], "no calibration before the third call of a shape"
+            del X
+        X, _ = kernels.stft_mel(x, win, 2048, 512)
+        rep = kernels.output_placement()
+        assert len(rep) == 1 and 2 <= len(rep[0]["calibration_ms"]) <= 5, rep         # half of what was free, not all of it
+        assert len(rep[0]["kept_ms"]) == 1 and rep[0]["bytes_held"] == nbytes == kernels._placed_outputs.bytes_held()
+        assert torch.equal(X, Xref)
+        p = X.data_ptr()
+        del X
+        big = torch.empty(7 * nbytes, dtype=torch.uint8, device=dev)    # everything but the pinned buffer (and a margin) is still available
+        X2, _ = kernels.stft_mel(x, win, 2048, 512)
+        assert X2.data_ptr() == p and torch.equal(X2, Xref)
+        del big, X2
+        assert kernels.release_workspaces() == nbytes and kernels._placed_outputs.bytes_held() == 0
+    finally:
+        del blocker
+        kernels.output_placement(enabled=False, min_bytes=256 << 20, keep=1, calibrate_after=3)
+        kernels._placed_outputs.calibrations = 0
+        torch.cuda.empty_cache()
 
 
 def test_c_abi_error_codes_and_degenerate_inputs():

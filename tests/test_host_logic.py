@@ -607,10 +607,11 @@ def test_long_fir_as_one_circular_convolution(monkeypatch):
 
 def test_placed_outputs_pool_logic_on_cpu(monkeypatch):
     """kernels._PlacedOutputs without a GPU: the device queries and events are stand-ins (every "launch" takes as long as the
-    candidate's index), the bookkeeping is the real one -- calibration keeps the fastest KEEP, as many candidates as the
-    free memory holds, a buffer is handed out again only when nothing references its storage (a view, a detached alias
-    and the pool's own tensor object are three different cases: the last one is invisible to the storage use count, which
-    is why callers always get an alias), the least recently used shape is dropped beyond MAX_POOL_BYTES."""
+    candidate's index), the bookkeeping is the real one -- OFF unless opted in; a shape is calibrated at its CALIBRATE_AFTER-th
+    call and at most MAX_CALIBRATIONS shapes per process; calibration keeps the fastest KEEP out of as many candidates as
+    FREE_FRACTION of the free memory holds; callers get an ALIAS made under the pool's lock, and a buffer is handed out
+    again only when nothing references its storage (an alias, a view); the least recently used shape is dropped beyond
+    MAX_POOL_BYTES; release() gives everything back."""
     import torch
     from audiotools_amd import kernels
 
@@ -631,6 +632,7 @@ def test_placed_outputs_pool_logic_on_cpu(monkeypatch):
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (free["bytes"], 1 << 40))
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    assert kernels._PlacedOutputs.enabled is False and kernels._PlacedOutputs.KEEP == 1, "the pool is an opt-in"
     pool = kernels._PlacedOutputs()
     monkeypatch.setattr(kernels._PlacedOutputs, "MIN_BYTES", 1024)
     made = []
@@ -641,32 +643,39 @@ def test_placed_outputs_pool_logic_on_cpu(monkeypatch):
         return t
 
     def launch(t):                       # candidate i "takes" 10 - i ms (the last allocations are the fastest), and writes its result
-        i = next(k for k, m in enumerate(made) if m is t)
+        i = next(k for k, m in enumerate(made) if m.data_ptr() == t.data_ptr())
         clock["now"] += 10.0 - i
         t.fill_(7.0)
 
     key = ("cpu", (1024,), 0, "fake")
+    assert pool.acquire(key, 4096, alloc, launch) is None and not made, "disabled: never"
+    monkeypatch.setattr(kernels._PlacedOutputs, "enabled", True)
+    monkeypatch.setattr(kernels._PlacedOutputs, "available", True)
+    monkeypatch.setattr(kernels._PlacedOutputs, "KEEP", 3)
+    # the first CALIBRATE_AFTER - 1 calls of a shape take plain allocations: a workload of ever-changing shapes never calibrates
+    assert kernels._PlacedOutputs.CALIBRATE_AFTER == 3
+    assert pool.acquire(key, 4096, alloc, launch) is None and pool.acquire(key, 4096, alloc, launch) is None and not made
     got = pool.acquire(key, 4096, alloc, launch)
     assert got is not None and got[1] is True                      # calibrated: the buffer already holds the result
     rep = pool.report()
     assert rep[0]["op"] == "fake" and len(rep[0]["calibration_ms"]) == kernels._PlacedOutputs.CANDIDATES == len(made)
-    assert rep[0]["kept_ms"] == sorted(rep[0]["calibration_ms"])[:3]
+    assert rep[0]["kept_ms"] == sorted(rep[0]["calibration_ms"])[:3] and rep[0]["bytes_held"] == 3 * 4096 == pool.bytes_held()
     fastest = made[-1]
-    assert got[0] is fastest and float(got[0][0]) == 7.0
-    # the pool's OWN tensor object does not count as a holder: the launchers hand out an alias (detach / transposed view)
-    held = got[0].detach()
+    assert got[0] is not fastest and got[0].data_ptr() == fastest.data_ptr() and float(got[0][0]) == 7.0, "callers get an alias"
+    # the alias made under the lock IS the holder: a second caller (another host thread, before the first has launched) gets the next one
     nxt = pool.acquire(key, 4096, alloc, launch)
-    assert nxt[1] is False and nxt[0] is made[-2], "the fastest buffer is held: the next fastest is handed out"
+    assert nxt[1] is False and nxt[0].data_ptr() == made[-2].data_ptr(), "the fastest buffer is held: the next fastest is handed out"
     view = nxt[0].view(32, 32)                                     # a view holds the storage just the same
+    del nxt
     third = pool.acquire(key, 4096, alloc, launch)
-    assert third[0] is made[-3]
-    alias3 = third[0].detach()
+    assert third[0].data_ptr() == made[-3].data_ptr()
     assert pool.acquire(key, 4096, alloc, launch) is None, "all three held: plain allocation"
-    del held
-    assert pool.acquire(key, 4096, alloc, launch)[0] is fastest    # released -> reused at once
-    del view, alias3
-    # as many candidates as the free memory holds next to two more results; fewer than two: no pool for the shape
-    free["bytes"] = 7 * 4096
+    del got
+    assert pool.acquire(key, 4096, alloc, launch)[0].data_ptr() == fastest.data_ptr()    # released -> reused at once
+    del view, third
+    # as many candidates as FREE_FRACTION of the free memory holds; fewer than two: no pool for the shape
+    monkeypatch.setattr(kernels._PlacedOutputs, "CALIBRATE_AFTER", 1)
+    free["bytes"] = 11 * 4096
     made.clear()
     assert pool.acquire(("cpu", (1024,), 0, "tight"), 4096, alloc, launch) is not None and len(made) == 5
     free["bytes"] = 3 * 4096
@@ -681,6 +690,16 @@ def test_placed_outputs_pool_logic_on_cpu(monkeypatch):
     assert pool.acquire(("cpu", (1024,), 0, "third"), 4096, alloc, launch) is not None
     ops = sorted(r["op"] for r in pool.report())
     assert ops == ["fake", "third"], ops
+    # at most MAX_CALIBRATIONS calibrations per process ("fake", "tight", "third" so far)
+    assert pool.calibrations == 3 and kernels._PlacedOutputs.MAX_CALIBRATIONS == 4
+    monkeypatch.setattr(kernels._PlacedOutputs, "MAX_POOL_BYTES", 1 << 30)
+    assert pool.acquire(("cpu", (1024,), 0, "fourth"), 4096, alloc, launch) is not None
+    made.clear()
+    assert pool.acquire(("cpu", (1024,), 0, "fifth"), 4096, alloc, launch) is None and not made
+    # release(): everything goes back, the counters start over
+    assert pool.bytes_held() > 0
+    pool.release()
+    assert pool.bytes_held() == 0 and pool.report() == []
     # below the threshold, or disabled: never
     assert pool.acquire(("cpu", (8,), 0, "small"), 512, alloc, launch) is None
     monkeypatch.setattr(kernels._PlacedOutputs, "enabled", False)

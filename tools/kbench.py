@@ -17,7 +17,10 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--what", default="stft,stftmel,lufs")
 ap.add_argument("--sr", type=int, default=44100)
 ap.add_argument("--nfft", type=int, default=2048)
+ap.add_argument("--placed", type=int, default=1, help="1: opt into the placement-aware output pool (best of 12 buffers: comparable across processes); 0: plain allocations")
 args = ap.parse_args()
+if args.placed:
+    kernels.output_placement(enabled=True, calibrate_after=1)
 
 dev = torch.device("cuda")
 B, C, SR = args.batch, 2, args.sr

@@ -32,6 +32,7 @@ win = tables.window("hann", n_fft, dev)
 tw = tables.stft_twiddles(n_fft, dev)
 info, w = tables.mel_units(SR, n_fft, n_mels, 0.0, None, dev)
 lib = _native.lib()
+_native.dev_lib()          # binds the measurement entry points (the tools run the development build: same handle)
 st = _native.current_stream(dev)
 nbytes = nx + ns + nm
 

@@ -55,6 +55,7 @@ win = tables.window("hann", n_fft, dev)
 tw = tables.stft_twiddles(n_fft, dev)
 info, w = tables.mel_units(SR, n_fft, n_mels, 0.0, None, dev)
 lib = _native.lib()
+_native.dev_lib()          # binds the measurement entry points (the tools run the development build: same handle)
 st = _native.current_stream(dev)
 sha = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()[:16]
 print(f"# regime {args.tag} lib={os.path.basename(_native.LIB_PATH)} sha256={sha} B={B} alg_bytes={ALG} dev={torch.cuda.get_device_name(0)}", flush=True)
