@@ -340,6 +340,20 @@ def stft_mel_floor(audio: torch.Tensor, window: torch.Tensor, n_fft: int, hop: i
     return True
 
 
+def _ola_envelope(window: torch.Tensor, hop: int, n_frames: int, dtype=torch.float32) -> torch.Tensor:
+    """sum_f w^2[n - f hop] over ``n_frames`` frames: the overlap-add envelope torch.istft divides by, length
+    (n_frames - 1) hop + n_fft.  One index_add_ in float64 (the order of <= n_fft / hop additions per sample cannot show in
+    the float32 result).  Deliberately NOT ``conv_transpose1d``: that is a MIOpen call, and the first MIOpen call of a process
+    made from autograd's worker thread -- where the adjoints below run -- aborted the interpreter on this stack (round 6,
+    sessions s05 / s06: a backward pass before any forward convolution)."""
+    n_fft = window.shape[-1]
+    w2 = window.to(torch.float64) ** 2
+    idx = (torch.arange(n_frames, device=window.device)[:, None] * hop + torch.arange(n_fft, device=window.device)[None, :]).reshape(-1)
+    env = torch.zeros((n_frames - 1) * hop + n_fft, dtype=torch.float64, device=window.device)
+    env.index_add_(0, idx, w2.repeat(n_frames))
+    return env.to(dtype)
+
+
 _nola_cache = {}
 
 
@@ -549,8 +563,7 @@ def stft_adjoint_general(grad_bcfn: torch.Tensor, window: torch.Tensor, n_fft: i
         full = T2 + n_fft                         # the centre-padded, outer-padded signal
         length = full + K * hop - half
         x = istft_fn(Y, window, n_fft, hop, length, lead=lead, trail=trail)
-        w2 = (window.to(x.dtype) ** 2)[None, None]
-        env = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, n_all, dtype=x.dtype, device=x.device), w2, stride=hop)[0, 0]
+        env = _ola_envelope(window, hop, n_all, x.dtype)
         env = env[half: half + length]
         if env.numel() < length:
             env = torch.nn.functional.pad(env, (0, length - env.numel()))
@@ -611,8 +624,7 @@ def istft_adjoint(grad_bct: torch.Tensor, window: torch.Tensor, n_fft: int, hop:
     B, C, T = grad_bct.shape
     half = n_fft // 2
     dev = grad_bct.device
-    w2 = (window.to(torch.float32) ** 2)[None, None]
-    env = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, n_frames, device=dev), w2, stride=hop)[0, 0]
+    env = _ola_envelope(window, hop, n_frames)
     inv_env = torch.where(env > 1e-11, 1.0 / env, torch.zeros_like(env))
     seg = inv_env[half: half + T]
     if seg.numel() < T:              # samples no frame covers: zero output, zero gradient

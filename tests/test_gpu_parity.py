@@ -1128,6 +1128,31 @@ def test_mel_autograd_fused_backward(win, n_mels, T):
         assert rel_err(g_got, g_ref) < REL, use_X
 
 
+def test_backward_pass_as_the_first_gpu_work_of_a_process():
+    """Round 6 (sessions s05 / s06): the inverse transform's adjoint built its overlap-add envelope with conv_transpose1d -- a
+    MIOpen call -- and the FIRST MIOpen call of a process made from autograd's worker thread aborts the interpreter on this
+    stack.  It only showed when no forward convolution had run before (a test selection; a training script whose first step
+    is a spectral loss).  The adjoints are MIOpen-free now; this runs one in a fresh process, as its first GPU work."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import audiotools_amd as A\n"
+        "X = torch.randn(2, 2, 1025, 40, dtype=torch.complex64, device='cuda', requires_grad=True)\n"
+        "s = A.AudioSignal(torch.zeros(2, 2, 40 * 512 - 100), 44100).to('cuda')\n"
+        "s.stft_data = X\n"
+        "y = s.istft(2048, 512, 'hann', False, length=40 * 512 - 100).audio_data\n"
+        "(g,) = torch.autograd.grad((y ** 2).mean(), X)\n"
+        "x = torch.randn(2, 2, 30000, device='cuda', requires_grad=True)\n"
+        "m = A.AudioSignal(x, 44100).mel_spectrogram(80)\n"
+        "(gx,) = torch.autograd.grad(m.sum(), x)\n"
+        "torch.cuda.synchronize(); assert torch.isfinite(g).all() and torch.isfinite(gx).all(); print('ok')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.returncode, out.stderr[-1500:])
+
+
 @pytest.mark.parametrize("win,hop,nfr,T", [(2048, 512, 40, 40 * 512 - 100), (512, 128, 60, 59 * 128), (1024, 512, 21, 10007),
                                             (256, 32, 90, 89 * 32 + 5), (64, 4, 120, 470)])
 def test_istft_autograd_native(win, hop, nfr, T):
