@@ -218,21 +218,30 @@ def parity_north_star(x, sr, mel, stft, lufs):
     return out
 
 
-def parity_device_north_star(x, sr, mel, stft):
-    """Every rank's own check of its own outputs, on its device, without the oracle (which lives on rank 0's host): one
-    item of the rank's slab against torch.stft / |X| @ basis^T in float64 (the formulation the reference runs,
-    audio_signal.py:1195-1202, 1355-1368).  Catches what a rank-0-only check cannot: a table that arrived wrong on rank r,
-    a pooled buffer aliased on rank r.  Returns (ok, stft_rel, mel_rel)."""
+def parity_device_north_star(x, sr, mel, stft, chunk=16):
+    """Every rank's own check of its own outputs, on its device, without the oracle (which lives on rank 0's host): EVERY item
+    of the rank's slab, in chunks, against torch.stft / |X| @ basis^T in float64 (the formulation the reference runs,
+    audio_signal.py:1195-1202, 1355-1368), per-row relative error as in tests/test_gpu_parity.py.  Catches what a three-item
+    check on rank 0 cannot: a table that arrived wrong on rank r, a pooled buffer aliased on rank r, one bad row out of 1024.
+    Returns (ok, worst stft_rel, worst mel_rel, items checked)."""
     from audiotools_amd import tables as TB
-    i = x.shape[0] // 2
-    xi = x[i].double()
     win = TB.window("hann", 2048, x.device).double()
-    X = torch.stft(xi, 2048, 512, window=win, center=True, pad_mode="reflect", return_complex=True)   # (C, F, N)
     basis = torch.from_numpy(TB.mel_filters_np(sr, 2048, N_MELS, 0.0, None)).to(x.device).double()     # (n_mels, F)
-    M = (X.abs().transpose(-1, -2) @ basis.T).transpose(-1, -2)
-    e_s = float((stft[i].to(torch.complex128) - X).abs().amax() / X.abs().amax())
-    e_m = float((mel[i].double() - M).abs().amax() / M.abs().amax())
-    return bool(e_s < 1e-4 and e_m < 1e-4), e_s, e_m
+    e_s = e_m = 0.0
+    n = x.shape[0]
+    for lo in range(0, n, chunk):
+        xi = x[lo: lo + chunk].double()
+        B, C, T = xi.shape
+        X = torch.stft(xi.reshape(B * C, T), 2048, 512, window=win, center=True, pad_mode="reflect", return_complex=True)   # (BC, F, N)
+        M = (X.abs().transpose(-1, -2) @ basis.T).transpose(-1, -2)
+        got_s = stft[lo: lo + chunk].reshape(B * C, *stft.shape[2:]).to(torch.complex128)
+        got_m = mel[lo: lo + chunk].reshape(B * C, *mel.shape[2:]).double()
+        den_s = X.abs().amax((-1, -2)).clamp_min(1e-30)
+        den_m = M.abs().amax((-1, -2)).clamp_min(1e-30)
+        e_s = max(e_s, float(((got_s - X).abs().amax((-1, -2)) / den_s).max()))
+        e_m = max(e_m, float(((got_m - M).abs().amax((-1, -2)) / den_m).max()))
+        del X, M, got_s, got_m, xi
+    return bool(e_s < 1e-4 and e_m < 1e-4), e_s, e_m, n
 
 
 # ----------------------------------------------------------------------------- launching
@@ -476,14 +485,16 @@ def main():
         # evidence outside the timed region (parity of the benchmarked launch, the floor twin, the copy rate) is taken on
         # rank 0 only: the other ranks neither build nor run the oracle, they wait at the closing barrier
         parity = parity_north_star(x, sr, mel, sig.stft_data, lufs) if rank == 0 else {"ok": True}
-        # ... and EVERY rank checks one item of its own slab on its own device (torch.stft / |X| @ basis in float64); the
+        # ... and EVERY rank checks every item of its own slab on its own device (torch.stft / |X| @ basis in float64); the
         # verdicts are all-reduced, so a wrong result on any rank fails the line
-        dev_ok, dev_es, dev_em = parity_device_north_star(x, sr, mel, sig.stft_data)
+        dev_ok, dev_es, dev_em, dev_n = parity_device_north_star(x, sr, mel, sig.stft_data)
         flag = torch.tensor([1 if dev_ok else 0], dtype=torch.int32, device=device)
         if world > 1:
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         parity["every_rank_device_check"] = {"ok_all_ranks": bool(int(flag[0])), "rank0_stft_rel": dev_es, "rank0_mel_rel": dev_em,
-                                             "what": "item n_local/2 of every rank's slab vs torch.stft + |X| @ mel basis (float64) on the rank's device"}
+                                             "rank0_items_checked": dev_n,
+                                             "what": "EVERY item of every rank's slab vs torch.stft + |X| @ mel basis (float64) on the rank's "
+                                                     "device, worst per-row relative error"}
         parity["ok"] = bool(parity["ok"] and int(flag[0]))
         # the zero-compute floor of the dominant kernel's traffic on THIS box: its measurement twin (same grid, schedule,
         # addresses, load / store instructions and cache policy, no transform: at_stft_mel_floor_f32), timed the same way
@@ -554,17 +565,26 @@ def main():
                              "algorithmic_bytes_per_launch": so_bytes, "frac": so_bytes / (so_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             except Exception as e:  # pragma: no cover
                 stft_only = {"error": f"{type(e).__name__}: {e}"}
-            # Placement (profiles/r05_notes.md section 1; kernels._PlacedOutputs, an OPT-IN since round 6).  With --placement on
-            # (default) the timed region above ran on the buffer the library chose; the same K steps on the buffers torch.empty
-            # hands out -- the library's default behaviour -- are timed here, and both figures are printed.
-            placement = None
+            del fl_stft, fl_mel
+        except StopIteration:
+            pass
+        except Exception as e:  # pragma: no cover - the floor is evidence, never a reason to lose the line
+            floor_ms = floor_iso_ms = floor_same_ms = None
+            out["floor_error"] = f"{type(e).__name__}: {e}"
+        # Placement (profiles/r05_notes.md section 1; kernels._PlacedOutputs, an OPT-IN since round 6).  With --placement on
+        # (default) the timed region above ran on the buffer the library chose; the same K steps on the buffers torch.empty
+        # hands out -- the library's default behaviour -- are timed here, and both figures are printed.  EVERY rank takes part
+        # (time_steps is collective: barrier + max over ranks), after rank 0's probes above.
+        if not args.no_probes and not args.graph:
             try:
                 pool_rep, pool_bytes = K.output_placement(), K._placed_outputs.bytes_held()
                 sig._release_stft_data()
                 res.clear()
                 del mel
                 K.output_placement(enabled=False)               # (drops the pooled buffer)
+                saved_ranks = list(PER_RANK_S)
                 pl_el, pl_ev = time_steps(step_events, args.steps, max(args.warmup, 2), adist, device, world, n_events=3)
+                PER_RANK_S[:] = saved_ranks                      # (per_rank_ms_per_step reports the timed region of record)
                 k_plain = sum(e[0].elapsed_time(e[1]) for e in pl_ev) / len(pl_ev)
                 placement = {"enabled_for_the_timed_region": args.placement == "on",
                              "pool": pool_rep, "pool_bytes_held": pool_bytes,
@@ -577,17 +597,13 @@ def main():
                                      "kernel into the candidate buffers listed under pool.calibration_ms during set-up and keeps the "
                                      "fastest (pool_bytes_held pinned until release_workspaces()).  *_plain_allocation: the same K "
                                      "steps with the pool off, on whatever torch.empty handed out in this process (a draw: "
-                                     "53-60 % of 8 TB/s for the same binary, deterministic per allocation)"}
+                                     "53-60 % of 8 TB/s for the same binary, deterministic per allocation); rank 0's figures"}
                 mel = res["mel"]
             except Exception as e:  # pragma: no cover
                 placement = {"error": f"{type(e).__name__}: {e}"}
+                if world > 1:
+                    raise           # a rank that leaves the collective pass would hang the others: fail loudly instead
                 mel = sig.mel_spectrogram(N_MELS)
-            del fl_stft, fl_mel
-        except StopIteration:
-            pass
-        except Exception as e:  # pragma: no cover - the floor is evidence, never a reason to lose the line
-            floor_ms = floor_iso_ms = floor_same_ms = None
-            out["floor_error"] = f"{type(e).__name__}: {e}"
         K.output_placement(enabled=False, calibrate_after=3)
         # what a plain device copy reaches on THIS box (torch.Tensor.copy_, read + write counted),
         # measured the same way: the practical ceiling next to the 8 TB/s spec
