@@ -23,14 +23,18 @@ def env_world():
 _FORCE_COLLECTIVES = False      # init(force=True): a single rank runs the collective code paths too (first contact with RCCL)
 
 
-def init(backend: str = None, force: bool = False):
+def init(backend: str = None, force: bool = False, shared_device: bool = False):
     """Join the process group described by the environment (no-op for a single process unless ``force``: then ONE rank
     initialises the group -- RCCL on a HIP device, the reference's convention audiotools/ml/accelerator.py:43-48 -- and the
     table broadcasts below go through their collective path, so that a 1-GPU box exercises everything but the wire).
+    ``shared_device`` (tests only): every rank uses cuda:0 and the group runs over gloo -- RCCL refuses two ranks on one
+    GPU -- so that a 1-GPU box can walk the multi-rank control flow (which rank enters which collective).
     Returns (rank, world_size, device)."""
     global _FORCE_COLLECTIVES
     rank, local_rank, world = env_world()
     use_cuda = torch.cuda.is_available()
+    if shared_device:
+        local_rank, backend = 0, (backend or "gloo")
     if use_cuda:
         torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")

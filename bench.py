@@ -343,6 +343,9 @@ def main():
                     help="initialise the RCCL process group even for ONE rank and run the multi-GPU set-up path on it (table "
                          "broadcasts, a 100 MB impulse-response bank broadcast, barriers): first contact with librccl on a "
                          "1-GPU box, reported as \"rccl_contact\" (VERDICT r05 #2)")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="TEST ONLY: all ranks on cuda:0 over gloo (RCCL refuses two ranks on one GPU): walks the multi-rank "
+                         "control flow -- which rank enters which collective -- on a 1-GPU box; the numbers mean nothing")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only (process group, sharding, table broadcast; gloo on a CPU-only host): no kernels")
     args = ap.parse_args()
@@ -359,7 +362,7 @@ def main():
     rccl_contact = None
     try:
         t_init = time.perf_counter()
-        rank, world, device = adist.init(force=args.force_nccl)
+        rank, world, device = adist.init(force=args.force_nccl, shared_device=args.shared_device)
         adist.barrier()                                            # first collective: RCCL communicator set-up over xGMI
         if args.force_nccl:
             rccl_contact = adist.rccl_contact(device, t_init)
@@ -379,7 +382,7 @@ def main():
     if args.dry_run:
         return dry_run(args, adist, rank, world, device, rccl_contact)
     assert device.type == "cuda", "bench.py needs a GPU (the product has no CPU fallback)"
-    if world > 1:
+    if world > 1 and not args.shared_device:
         assert torch.distributed.get_backend() == "nccl", "multi-GPU runs use RCCL (torch backend 'nccl')"
 
     cfg = CONFIGS[args.config]

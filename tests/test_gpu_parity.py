@@ -1128,6 +1128,31 @@ def test_mel_autograd_fused_backward(win, n_mels, T):
         assert rel_err(g_got, g_ref) < REL, use_X
 
 
+@pytest.mark.parametrize("config", ["north_star", "cfg4", "cfg5"])
+def test_bench_multi_rank_control_flow_on_one_device(config):
+    """bench.py with TWO ranks sharing cuda:0 over gloo (`--shared-device`, a test-only switch: RCCL refuses two ranks on one
+    GPU): every rank must enter the same collectives in the same order -- table broadcasts, the timed regions' barriers and
+    reductions, the all-reduced parity verdict, the collective plain-allocation pass, the closing barrier -- or the run hangs,
+    which on the driver's 8-GPU node would be the first time anybody saw it."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    batch = {"north_star": 40, "cfg4": 16, "cfg5": 8}[config]      # (north star: 20 items per rank = a 282 MB spectrum, so the output pool calibrates on both ranks)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--shared-device", "--config", config,
+                          "--batch", str(batch), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "gloo" and d["parity_check"]["ok"] is True
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["config"]["items_per_gpu"] * 2 == batch
+    if config == "north_star":
+        assert d["parity_check"]["every_rank_device_check"]["ok_all_ranks"] is True
+        assert d["roofline"]["placement"]["kernel_ms_plain_allocation"] > 0
+
+
 def test_backward_pass_as_the_first_gpu_work_of_a_process():
     """Round 6 (sessions s05 / s06): the inverse transform's adjoint built its overlap-add envelope with conv_transpose1d -- a
     MIOpen call -- and the FIRST MIOpen call of a process made from autograd's worker thread aborts the interpreter on this
