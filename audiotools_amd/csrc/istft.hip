@@ -816,6 +816,16 @@ static int istft_run(const float* X, int64_t rows, int64_t n_x, const float* win
   const int M = n_fft / 2;
   const int FW = 64 / (M / 16);
   const int sh = fused_shift(n_fft, hop);
+  {
+    // n_fft <= 128 take the generic one-pass kernel (consecutive frames per tile, overlap-add in LDS) instead of the fused one,
+    // whose 16 / 32 frame slots per wave walk different row segments: its loads are 16- and 32-byte pieces there.  Round 6, s09,
+    // B = 512 x 2 ch x 10 s @ 8 kHz, hop = n_fft / 4: n_fft 64: 4.89 -> 1.22 ms, 128: 1.32 -> 1.10 ms; 256 / 512 stay fused (0.42 /
+    // 0.35 against 1.08 ms).  (AT_ISTFT_SMALL_OLA = largest n_fft routed this way: development A/B.)
+    static const int small_ola = at::env_int_once("AT_ISTFT_SMALL_OLA", 128);
+    if (small_ola && n_fft <= small_ola && !edit && lead == 0 && n_frames == n_x && at::istft_generic_ola_supported(n_fft, hop))
+      return at::istft_generic_ola(X, rows, n_frames, window, twiddles, n_fft, hop, length, out,
+                                   reinterpret_cast<float*>(workspace), st);
+  }
   if (sh) {
     IstftFusedArgs F;
     F.X = reinterpret_cast<const float2*>(X); F.window = window; F.tw = reinterpret_cast<const float2*>(twiddles);
