@@ -775,3 +775,18 @@ def test_run_store_index_algebra(M):
                 assert slab[f * SLOTS + k] == (f, k)
                 stored[idx] = (f, k)                    # (duplicates of the clamped lanes carry the same value)
         assert sorted(stored) == list(range(tot))
+
+
+def test_ola_envelope_equals_the_transposed_convolution():
+    """kernels._ola_envelope (one index_add_ in float64) is the overlap-add envelope torch.istft divides by; the adjoints used
+    conv_transpose1d for it until round 6 -- a MIOpen call that aborts the interpreter when it is a process's first one and comes
+    from autograd's worker thread (profiles/r06_notes.md 5.2)."""
+    import torch
+    from audiotools_amd import kernels
+
+    for n_fft, hop, nf in [(2048, 512, 40), (512, 128, 60), (1024, 512, 21), (256, 32, 90), (64, 4, 120), (400, 160, 33), (2048, 700, 9), (64, 64, 1)]:
+        w = torch.hann_window(n_fft) + 0.01
+        ref = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, nf), (w ** 2)[None, None], stride=hop)[0, 0]
+        got = kernels._ola_envelope(w, hop, nf)
+        assert got.shape == ref.shape and got.dtype == torch.float32
+        assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), (n_fft, hop, nf)
