@@ -340,6 +340,17 @@ def test_mel_options():
     mel = s.mel_spectrogram(64, mel_fmin=50.0, mel_fmax=8000.0, window_length=1024, hop_length=256)
     ref = restate.mel_spectrogram(restate.stft(x, 1024, 256), 44100, 64, 50.0, 8000.0)
     assert rel_err(mel, ref) < REL
+    # the n_fft 2048 / hop 512 kernel with banks of other sizes: a band-limited bank is 128 units (TWO rounds of its
+    # cross-frame round pipeline instead of the four of the 80-band default); runs of several frames, a row end inside a run
+    from audiotools_amd import tables
+    X = restate.stft(x, 2048, 512)
+    for n_mels, fmin, fmax in [(40, 0.0, 4000.0), (64, 200.0, 6000.0), (128, 0.0, None), (32, 0.0, None)]:
+        units = tables.mel_units(44100, 2048, n_mels, fmin, fmax, torch.device("cpu"))
+        assert units is not None and units[0].shape[0] in (128, 256, 384), (n_mels, fmin, fmax)
+        mel = s.mel_spectrogram(n_mels, mel_fmin=fmin, mel_fmax=fmax)
+        ref = restate.mel_spectrogram(X, 44100, n_mels, fmin, fmax)
+        assert mel.shape == ref.shape and rel_err(mel, ref) < REL, (n_mels, fmin, fmax, units[0].shape[0])
+    assert tables.mel_units(44100, 2048, 40, 0.0, 4000.0, torch.device("cpu"))[0].shape[0] == 128
 
 
 # ------------------------------------------------------------------------- loudness
