@@ -89,6 +89,11 @@
                                 // 1.93: the kernel pays for LDS traffic (the 32 ds_read_b128 of the unit rounds, the 16 magnitude writes), not for VALU
                                 // instructions (33 selects: nothing; 16 v_sqrt: nothing)
 #endif
+#ifndef AT_STFT_V2_HX
+#define AT_STFT_V2_HX 0         // A/B build (1): the ascending butterflies of pass 3 take their inputs by v_permlane16/32_swap instead of through the
+                                // slab (8 ds_write_b64 + 8 ds_read_b64 fewer per frame, 16 swaps more).  Bit-compatible results (60 parity tests);
+                                // same box, interleaved, three rounds: 1.958 / 1.963 / 1.965 vs 1.969 / 1.960 / 1.916 ms -- a draw (session s12)
+#endif
 #ifndef AT_STFT_RUN_V2
 #define AT_STFT_RUN_V2 72       // the same for the 2048/512 kernel (runs of 36...431 measure alike, 16 is 3 % slower)
 #endif
@@ -687,6 +692,7 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
   // instructions.  The magnitudes stay in the slab until then (pass 1 overwrites it only after the last unit read); the band sums
   // are gathered in a per-wave region of their own and leave with the exchange reads of pass 1.  A stretch drains its last frame.
   constexpr int PIPE = (MEL && STATIC_STORES && !FLOOR) ? ((VAR >> 2) & 3) : 0;
+  constexpr bool HX = !FLOOR && (VAR & 16) != 0;      // VAR bit 4: half of the pass 2 -> 3 exchange in registers (see pass 3)
   constexpr int MELOUT_OFF = 1312;   // floats: band sums of the frame, behind the 65 x 20 magnitude rows of the slab
   constexpr bool PRIO = (POL & 8) != 0;
   constexpr int M = 1024, L = 64, N = 2048, NW = 4, SH = 4;
@@ -1043,15 +1049,58 @@ __global__ __launch_bounds__(256, 2) void stft_mel_kernel_v2(const StftArgs A) {
         tw2[2 * i + 1] = make_float2(v.x, v.y);
         if (i < 7) tw2[2 * i + 2] = make_float2(v.z, v.w);
       }
-      pass_compute_store<16, 16, L, true>(a, fbuf, t, tw2);
+      if constexpr (!HX) {
+        pass_compute_store<16, 16, L, true>(a, fbuf, t, tw2);
+      } else {
+        // pass 2's butterfly; only the outputs the DESCENDING butterflies of pass 3 read (r = 8 .. 15: points j >= 128 of every
+        // 256-block) go through the slab -- the ascending ones stay in registers (below)
+#pragma unroll
+        for (int r = 1; r < 16; ++r) a[r] = cmul(a[r], tw2[r]);
+        Dft<16>::run(a);
+        const int o0 = (t >> 4) * 256 + (t & 15);
+#pragma unroll
+        for (int r = 8; r < 16; ++r) fbuf[phys<L, true>(o0 + 16 * r)] = a[r];
+      }
     }
-    wave_sync();
     // ---- pass 3 (radix 4), paired butterflies, results stay in registers
     float2 Z[4][4];
+    if constexpr (HX) {
+      // HALF EXCHANGE (round 6).  After pass 2 lane 16 a + b holds, in register r, point 256 a + 16 r + b.  Butterfly j of pass 3
+      // reads points j + 256 q: register j >> 4 of the four lanes 16 q + (j & 15).  For the ascending butterflies of the paired
+      // pass (j = t and 64 + t) that is a 4 x 4 transpose between the wave's four 16-lane rows and the registers 0 .. 3 (4 .. 7):
+      // two v_permlane16_swap + two v_permlane32_swap per dword quadruple (gfx950; tools/micro/permlane_test.hip prints their
+      // semantics) instead of 8 ds_write_b64 + 8 ds_read_b64.  The descending butterflies (256 - t, 192 - t) pair lane b with
+      // lane 16 - b -- and lanes 0, 16, 32, 48 with a register index one higher --: they keep the slab.
+      // (the two results are read into plain unsigned variables first: `__builtin_bit_cast(float, r_[1])` on the builtin's vector
+      //  result compiled to element 0 with ROCm 7.2's clang -- found in the ISA: half of the swaps were dead)
+      auto swap16 = [](float& u, float& v) __attribute__((always_inline)) {
+        auto r_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(v), false, false);
+        const unsigned x0 = r_[0], x1 = r_[1];
+        u = __uint_as_float(x0); v = __uint_as_float(x1);
+      };
+      auto swap32 = [](float& u, float& v) __attribute__((always_inline)) {
+        auto r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(v), false, false);
+        const unsigned x0 = r_[0], x1 = r_[1];
+        u = __uint_as_float(x0); v = __uint_as_float(x1);
+      };
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+      for (int g = 0; g < 2; ++g) {
+        float2 &r0 = a[4 * g], &r1 = a[4 * g + 1], &r2 = a[4 * g + 2], &r3 = a[4 * g + 3];
+        swap16(r0.x, r1.x); swap16(r0.y, r1.y); swap16(r2.x, r3.x); swap16(r2.y, r3.y);
+        swap32(r0.x, r2.x); swap32(r0.y, r2.y); swap32(r1.x, r3.x); swap32(r1.y, r3.y);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Z[b][r] = fbuf[pj[b] + 257 * r];
+        for (int q = 0; q < 4; ++q) Z[2 * g][q] = a[4 * g + q];      // g = 0: butterfly t, g = 1: butterfly 64 + t
+      }
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { Z[1][r] = fbuf[pj[1] + 257 * r]; Z[3][r] = fbuf[pj[3] + 257 * r]; }
+    } else {
+      wave_sync();
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[b][r] = fbuf[pj[b] + 257 * r];
+    }
     wave_sync();   // slab free: it is reused for |X| below
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -1549,16 +1598,17 @@ int at_stft_mel_f32(const float* x, int64_t rows, int64_t T, const float* window
     // (session s40, same box, interleaved: with mel 2.172 vs 2.190 ms nt / 2.134 vs 2.163 ms plain stores; without
     // mel the round-2 code is 0.9 % faster, 1.814 vs 1.830 ms -- there the only uncounted store was the Nyquist one)
     const bool stat = !(A.flags & 32) && A.n_units != 0 && A.n_mels <= 128;
-    constexpr int SV = 1 + 4 * AT_STFT_V2_PIPE;   // static store count (+ the pipelined mel stage)
+    constexpr int HXV = 16 * AT_STFT_V2_HX;       // half exchange (every v2 variant)
+    constexpr int SV = 1 + 4 * AT_STFT_V2_PIPE + HXV;   // static store count (+ the pipelined mel stage)
     switch (A.n_units / 64) {
 #define AT_V2_POL(NRV, SV)                                                                   \
   if (stat) return (A.flags & 1) ? launch_v2<NRV, 1, SV>(A, n_cu, s) : launch_v2<NRV, 0, SV>(A, n_cu, s); \
-  return (A.flags & 1) ? launch_v2<NRV, 1, 0>(A, n_cu, s) : launch_v2<NRV, 0, 0>(A, n_cu, s);
-      case 0: AT_V2_POL(0, 1)
-      case 2: return stat ? launch_v2<2, 0, SV>(A, n_cu, s) : launch_v2<2, 0, 0>(A, n_cu, s);
+  return (A.flags & 1) ? launch_v2<NRV, 1, HXV>(A, n_cu, s) : launch_v2<NRV, 0, HXV>(A, n_cu, s);
+      case 0: AT_V2_POL(0, 1 + HXV)
+      case 2: return stat ? launch_v2<2, 0, SV>(A, n_cu, s) : launch_v2<2, 0, HXV>(A, n_cu, s);
       case 4: AT_V2_POL(4, SV)
 #undef AT_V2_POL
-      case 6: return stat ? launch_v2<6, 0, SV>(A, n_cu, s) : launch_v2<6, 0, 0>(A, n_cu, s);
+      case 6: return stat ? launch_v2<6, 0, SV>(A, n_cu, s) : launch_v2<6, 0, HXV>(A, n_cu, s);
     }
   }
   switch (M) {
