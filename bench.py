@@ -645,7 +645,10 @@ def main():
                                          "deterministic per allocation, profiles/r05_notes.md section 1), so this is the figure that says "
                                          "which regime the kernel of record ran in"}
         out["parity_check"] = parity
-        out["kernels_ms"] = {"stft_mel": stft_ms, "lufs_total": lufs_ms, "lufs_GBps": lufs_bytes / (lufs_ms * 1e-3) / 1e9,
+        per_step = sorted(e[0].elapsed_time(e[1]) for e in events)
+        out["kernels_ms"] = {"stft_mel": stft_ms, "stft_mel_min": per_step[0], "stft_mel_median": per_step[len(per_step) // 2],
+                             "stft_mel_max": per_step[-1],
+                             "lufs_total": lufs_ms, "lufs_GBps": lufs_bytes / (lufs_ms * 1e-3) / 1e9,
                              "timing": timing_note}
         if share is not None:
             out["share_64" if n_local == 512 else f"share_{n_local // 8}"] = share
