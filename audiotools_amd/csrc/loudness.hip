@@ -830,11 +830,21 @@ int at_lufs_f32(const float* x, int64_t B, int64_t C, int64_t T, const double* s
     const int64_t slots = (int64_t)n_cu * 4 * (use_dma ? (nstage <= 2 ? AT_LUFS_WPS_DMA : 3) : AT_LUFS_WPS);
     int64_t best_s = 1;
     double best_cost = 1e300;
+    // Cost of a segmentation (round 6, sessions s14 / s15): a wave's work (segment + warm-up) times what its SIMD's residents cost
+    // it.  Until round 6 the model was rounds x work -- every resident wave at full speed up to the slot count -- and picked as
+    // many segments as one round holds: 3200 waves of 21.8 k samples at 64 items, where 1920 waves of 35 k run 10 % faster.
+    // Measured per-wave time / work against the waves q on the busiest SIMD (B = 64, 128 rows, nine segmentations):
+    // 1.24 / 1.9 / 2.6 / 3.5 for q = 1 .. 4 -- a SIMD's throughput is 0.81 / 1.05 / 1.15 / 1.15 of q = 1's: two residents nearly
+    // saturate it, a lone wave is latency-bound.
+    static const double G_OF_Q[5] = {0.0, 1.24, 1.9, 2.6, 3.5};
+    const int64_t n_simd = (int64_t)n_cu * 4;
+    const int64_t wps = slots / n_simd;                            // resident waves per SIMD (3 or 4)
     for (int64_t sp = 1; sp <= H_data && sp <= 4096; ++sp) {
       const int64_t sh = (H_data + sp - 1) / sp;                  // hops per segment
       if ((H_data + sh - 1) / sh != sp) continue;                 // not a distinct segmentation
-      const int64_t rounds = (rows * sp + slots - 1) / slots;
-      const double cost = (double)rounds * ((double)sh * S + (sp > 1 ? (double)warm : 0.0));
+      const int64_t q = (rows * sp + n_simd - 1) / n_simd;        // waves the busiest SIMD runs
+      const double g = q <= wps ? G_OF_Q[q] : G_OF_Q[wps] * (double)q / (double)wps;
+      const double cost = g * ((double)sh * S + (sp > 1 ? (double)warm : 0.0));
       if (cost < best_cost * 0.999) { best_cost = cost; best_s = sp; }
     }
     seg = (H_data + best_s - 1) / best_s;
